@@ -1,0 +1,35 @@
+// Shared helpers for the libdana_hip.so C-ABI layer (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+
+#define DANA_OK 0
+#define DANA_ERR_ARG (-1)
+#define DANA_ERR_HIP (-2)
+#define DANA_ERR_WORKSPACE (-3)
+
+// thread-local last-error text, read back through dana_last_error().
+void dana_set_error(const char* fmt, ...);
+
+#define DANA_CHECK_ARG(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      dana_set_error(__VA_ARGS__);                \
+      return DANA_ERR_ARG;                        \
+    }                                             \
+  } while (0)
+
+#define DANA_CHECK_LAUNCH(name)                                               \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      dana_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+      return DANA_ERR_HIP;                                                    \
+    }                                                                         \
+  } while (0)
+
+static inline int dana_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t dana_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,338 @@
+// HBM-bound layout / pooling / packing kernels of the DAnA forward path (gfx950).
+// All activations are NHWC; every kernel moves 16 B per lane along the channel axis where the
+// shape allows it, one pass over its input, grid >> 256 workgroups.
+//
+// Reference semantics replaced (not code):
+//   nn.MaxPool2d(3, 2, padding=0, ceil_mode=True)      lib/model/framework/resnet.py:113
+//   nn.AvgPool2d(14, stride=1) on the support maps     lib/model/framework/dana.py:42,105-108
+//   .mean(3).mean(2) after layer4                      lib/model/framework/dana.py:387-389
+//   PositionalEncoding.forward (x + pe)                lib/model/framework/dana.py:322-324
+//   q - q.mean(1, keepdim=True)                        lib/model/framework/dana.py:125,141,267,272
+//   frozen BatchNorm2d (eval) folded to scale/shift    lib/model/framework/dana.py:362-385
+#include "common.h"
+#include "../../include/dana_hip.h"
+#include <float.h>
+
+namespace {
+
+int grid_for(long total, int block) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 65535L * 16 ? 65535L * 16 : g));
+}
+
+// [B][C][H][W] -> [B][H][W][ldo], channels >= C zero-filled up to cpad
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int cpad, long ldo,
+                    long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % cpad);
+    const long pix = i / cpad;  // b*HW + hw
+    const long b = pix / HW, hw = pix % HW;
+    out[pix * ldo + c] = c < C ? in[(b * C + c) * HW + hw] : 0.f;
+  }
+}
+
+// [B][HW][ldi] -> [B][C][HW]
+__global__ void __launch_bounds__(256)
+nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, long ldi, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const long hw = i % HW;
+    const long c = (i / HW) % C;
+    const long b = i / HW / C;
+    out[i] = in[(b * HW + hw) * ldi + c];
+  }
+}
+
+// 3x3 stride-2 max pool, pad 0, ceil_mode: windows are clipped at the bottom/right edge.
+__global__ void __launch_bounds__(256)
+maxpool3x3s2_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, int W, int OH, int OW, int C4,
+                    long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const int ow = (int)((i / C4) % OW);
+    const int oh = (int)((i / C4 / OW) % OH);
+    const long b = i / C4 / OW / OH;
+    float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    const int h0 = oh * 2, w0 = ow * 2;
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = h0 + dh;
+      if (h >= H) break;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = w0 + dw;
+        if (w >= W) break;
+        const float4 v = in[((b * H + h) * W + w) * C4 + c];
+        m.x = fmaxf(m.x, v.x);
+        m.y = fmaxf(m.y, v.y);
+        m.z = fmaxf(m.z, v.z);
+        m.w = fmaxf(m.w, v.w);
+      }
+    }
+    out[i] = m;
+  }
+}
+
+// k x k average pool, given stride, no padding (dana.py:42: AvgPool2d(14, stride=1))
+__global__ void __launch_bounds__(256)
+avgpool_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, int W, int OH, int OW, int C4, int k,
+               int stride, long total) {
+  const float cnt = (float)(k * k);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const int ow = (int)((i / C4) % OW);
+    const int oh = (int)((i / C4 / OW) % OH);
+    const long b = i / C4 / OW / OH;
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int dh = 0; dh < k; ++dh)
+      for (int dw = 0; dw < k; ++dw) {
+        const float4 v = in[((b * H + oh * stride + dh) * W + ow * stride + dw) * C4 + c];
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+      }
+    out[i] = make_float4(s.x / cnt, s.y / cnt, s.z / cnt, s.w / cnt);
+  }
+}
+
+// out[g][c] = mean_p in[g][p][c]
+__global__ void __launch_bounds__(256)
+spatial_mean_kernel(const float4* __restrict__ in, float4* __restrict__ out, int P, int C4, long ldi4, long total) {
+  const float cnt = (float)P;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const long g = i / C4;
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int p = 0; p < P; ++p) {
+      const float4 v = in[(g * P + p) * ldi4 + c];
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+    out[i] = make_float4(s.x / cnt, s.y / cnt, s.z / cnt, s.w / cnt);
+  }
+}
+
+// out[r][c] = in[r][c] + pe[r % L][c]   (rows = groups * L)
+__global__ void __launch_bounds__(256)
+add_pe_kernel(const float4* __restrict__ in, const float4* __restrict__ pe, float4* __restrict__ out, int L, int C4,
+              long ldi4, long ldo4, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const long r = i / C4;
+    const float4 a = in[r * ldi4 + c], b = pe[(r % L) * C4 + c];
+    out[r * ldo4 + c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+// x[g][l][d] -= mean_l x[g][l][d]; grid = (D/64 column slabs, G); block = 64 columns x 4 row lanes
+__global__ void __launch_bounds__(256)
+colmean_sub_kernel(float* __restrict__ x, int L, int D, long ld) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float* base = x + (long)blockIdx.y * L * ld;
+  float s = 0.f;
+  if (col < D)
+    for (int l = rl; l < L; l += 4) s += base[(long)l * ld + col];
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  const float mean = (part[0][threadIdx.x & 63] + part[1][threadIdx.x & 63] + part[2][threadIdx.x & 63] +
+                      part[3][threadIdx.x & 63]) /
+                     (float)L;
+  if (col < D)
+    for (int l = rl; l < L; l += 4) base[(long)l * ld + col] -= mean;
+}
+
+// batched transpose in[g][R][C] -> out[g][C][ldo] (32x32 LDS tiles); columns R..ldo-1 are left untouched
+__global__ void __launch_bounds__(256)
+transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, long ldi, long ldo,
+                 long in_batch, long out_batch) {
+  __shared__ float t[32][33];
+  const float* ib = in + (long)blockIdx.z * in_batch;
+  float* ob = out + (long)blockIdx.z * out_batch;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    t[j][tx] = (r < R && c < C) ? ib[(long)r * ldi + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < C && r < R) ob[(long)c * ldo + r] = t[tx][j];
+  }
+}
+
+// OIHW -> [O][KH][KW][I]
+__global__ void __launch_bounds__(256)
+pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int I, int KH, int KW, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int ci = (int)(i % I);
+    const int kw = (int)((i / I) % KW);
+    const int kh = (int)((i / I / KW) % KH);
+    const long o = i / I / KW / KH;
+    out[i] = w[((o * I + ci) * KH + kh) * KW + kw];
+  }
+}
+
+// stem: [O][3][7][7] -> [O][7][8][4] with zero taps/channels
+__global__ void __launch_bounds__(256)
+pack_stem_kernel(const float* __restrict__ w, float* __restrict__ out, int CI, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int ci = (int)(i % 4);
+    const int kw = (int)((i / 4) % 8);
+    const int kh = (int)((i / 32) % 7);
+    const long o = i / 224;
+    out[i] = (ci < CI && kw < 7) ? w[((o * CI + ci) * 7 + kh) * 7 + kw] : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+               const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ shift,
+               int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = gamma[i] / sqrtf(var[i] + eps);
+  scale[i] = s;
+  shift[i] = beta[i] - mean[i] * s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dana_nchw_to_nhwc(const float* in, float* out, int batch, int channels, int height, int width, int cpad,
+                      long out_pix_stride, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && channels > 0 && height > 0 && width > 0 && cpad >= channels,
+                 "dana_nchw_to_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && out, "dana_nchw_to_nhwc: null pointer");
+  if (out_pix_stride <= 0) out_pix_stride = cpad;
+  const long total = (long)batch * height * width * cpad;
+  nchw_to_nhwc_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(in, out, channels, height * width, cpad,
+                                                                             out_pix_stride, total);
+  DANA_CHECK_LAUNCH("dana_nchw_to_nhwc");
+  return DANA_OK;
+}
+
+int dana_nhwc_to_nchw(const float* in, float* out, int batch, int channels, int height, int width,
+                      long in_pix_stride, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && channels > 0 && height > 0 && width > 0, "dana_nhwc_to_nchw: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && out, "dana_nhwc_to_nchw: null pointer");
+  if (in_pix_stride <= 0) in_pix_stride = channels;
+  const long total = (long)batch * height * width * channels;
+  nhwc_to_nchw_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(in, out, channels, height * width,
+                                                                             in_pix_stride, total);
+  DANA_CHECK_LAUNCH("dana_nhwc_to_nchw");
+  return DANA_OK;
+}
+
+int dana_maxpool3x3s2_ceil_nhwc(const float* in, float* out, int batch, int height, int width, int channels,
+                                dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && height >= 3 && width >= 3 && channels > 0 && channels % 4 == 0,
+                 "dana_maxpool3x3s2_ceil_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && out, "dana_maxpool3x3s2_ceil_nhwc: null pointer");
+  int oh = (height - 3 + 1) / 2 + 1, ow = (width - 3 + 1) / 2 + 1;  // ceil((H-3)/2)+1
+  if ((oh - 1) * 2 >= height) --oh;                                  // window must start inside the input
+  if ((ow - 1) * 2 >= width) --ow;
+  const long total = (long)batch * oh * ow * (channels / 4);
+  maxpool3x3s2_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)in, (float4*)out, height,
+                                                                             width, oh, ow, channels / 4, total);
+  DANA_CHECK_LAUNCH("dana_maxpool3x3s2_ceil_nhwc");
+  return DANA_OK;
+}
+
+int dana_avgpool_nhwc(const float* in, float* out, int batch, int height, int width, int channels, int k, int stride,
+                      dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && k > 0 && stride > 0 && height >= k && width >= k && channels % 4 == 0,
+                 "dana_avgpool_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && out, "dana_avgpool_nhwc: null pointer");
+  const int oh = (height - k) / stride + 1, ow = (width - k) / stride + 1;
+  const long total = (long)batch * oh * ow * (channels / 4);
+  avgpool_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)in, (float4*)out, height,
+                                                                        width, oh, ow, channels / 4, k, stride, total);
+  DANA_CHECK_LAUNCH("dana_avgpool_nhwc");
+  return DANA_OK;
+}
+
+int dana_spatial_mean_nhwc(const float* in, float* out, int groups, int positions, int channels, long in_pix_stride,
+                           dana_stream_t stream) {
+  DANA_CHECK_ARG(groups >= 0 && positions > 0 && channels % 4 == 0, "dana_spatial_mean_nhwc: bad shape");
+  if (groups == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && out, "dana_spatial_mean_nhwc: null pointer");
+  if (in_pix_stride <= 0) in_pix_stride = channels;
+  DANA_CHECK_ARG(in_pix_stride % 4 == 0, "dana_spatial_mean_nhwc: stride %% 4 != 0");
+  const long total = (long)groups * (channels / 4);
+  spatial_mean_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      (const float4*)in, (float4*)out, positions, channels / 4, in_pix_stride / 4, total);
+  DANA_CHECK_LAUNCH("dana_spatial_mean_nhwc");
+  return DANA_OK;
+}
+
+int dana_add_pe(const float* in, const float* pe, float* out, long rows, int length, int channels,
+                long in_stride, long out_stride, dana_stream_t stream) {
+  DANA_CHECK_ARG(rows >= 0 && length > 0 && channels > 0 && channels % 4 == 0, "dana_add_pe: bad shape");
+  if (rows == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && pe && out, "dana_add_pe: null pointer");
+  if (in_stride <= 0) in_stride = channels;
+  if (out_stride <= 0) out_stride = channels;
+  DANA_CHECK_ARG(in_stride % 4 == 0 && out_stride % 4 == 0, "dana_add_pe: strides %% 4 != 0");
+  const long total = rows * (channels / 4);
+  add_pe_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      (const float4*)in, (const float4*)pe, (float4*)out, length, channels / 4, in_stride / 4, out_stride / 4, total);
+  DANA_CHECK_LAUNCH("dana_add_pe");
+  return DANA_OK;
+}
+
+int dana_colmean_sub(float* x, int groups, int length, int dim, long ld, dana_stream_t stream) {
+  DANA_CHECK_ARG(groups >= 0 && length > 0 && dim > 0, "dana_colmean_sub: bad shape");
+  if (groups == 0) return DANA_OK;
+  DANA_CHECK_ARG(x, "dana_colmean_sub: null pointer");
+  if (ld <= 0) ld = dim;
+  dim3 grid(dana_ceil_div(dim, 64), groups);
+  colmean_sub_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, length, dim, ld);
+  DANA_CHECK_LAUNCH("dana_colmean_sub");
+  return DANA_OK;
+}
+
+int dana_transpose_batched(const float* in, float* out, int groups, int rows, int cols, long ldi, long ldo,
+                           long in_batch, long out_batch, dana_stream_t stream) {
+  DANA_CHECK_ARG(groups >= 0 && rows > 0 && cols > 0 && ldi >= cols && ldo >= rows, "dana_transpose_batched: bad shape");
+  if (groups == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && out, "dana_transpose_batched: null pointer");
+  dim3 grid(dana_ceil_div(cols, 32), dana_ceil_div(rows, 32), groups);
+  transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, out, rows, cols, ldi, ldo, in_batch, out_batch);
+  DANA_CHECK_LAUNCH("dana_transpose_batched");
+  return DANA_OK;
+}
+
+int dana_pack_conv_weight(const float* w_oihw, float* out, int cout, int cin, int kh, int kw, int stem7,
+                          dana_stream_t stream) {
+  DANA_CHECK_ARG(cout > 0 && cin > 0 && kh > 0 && kw > 0, "dana_pack_conv_weight: bad shape");
+  DANA_CHECK_ARG(w_oihw && out, "dana_pack_conv_weight: null pointer");
+  if (stem7) {
+    DANA_CHECK_ARG(kh == 7 && kw == 7 && cin <= 4, "dana_pack_conv_weight: stem7 needs 7x7, cin<=4");
+    const long total = (long)cout * 224;
+    pack_stem_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, out, cin, total);
+  } else {
+    const long total = (long)cout * cin * kh * kw;
+    pack_weight_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, out, cin, kh, kw, total);
+  }
+  DANA_CHECK_LAUNCH("dana_pack_conv_weight");
+  return DANA_OK;
+}
+
+int dana_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                 float* shift, int n, dana_stream_t stream) {
+  DANA_CHECK_ARG(n > 0 && gamma && beta && mean && var && scale && shift, "dana_bn_fold: bad args");
+  bn_fold_kernel<<<dana_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, mean, var, eps, scale, shift, n);
+  DANA_CHECK_LAUNCH("dana_bn_fold");
+  return DANA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,263 @@
+// RPN proposal path on device: anchor grid + delta decode + clip + fg score, per-image
+// descending sort, top-N gather, batched NMS, zero-padded roi assembly.
+//
+// Replaces (semantics, not code) the reference's
+//   lib/model/rpn/proposal_layer.py:49-190   (_ProposalLayer.forward)
+//   lib/model/rpn/bbox_transform.py:77-103   (bbox_transform_inv), :125-133 (clip_boxes)
+//   lib/model/rpn/rpn.py:67-69               (2-way softmax of the bg/fg score pair)
+// which run as ~15 small torch kernels, a host numpy anchor grid and a python loop over the
+// batch with a blocking NMS per image. Here: 4 launches for the whole batch, no host sync.
+//
+// Compiled with -ffp-contract=off (decode rounds like the reference's unfused torch ops).
+#include "common.h"
+#include "../../include/dana_hip.h"
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+// one lane per (image, cell k=h*W+w, anchor a); output index i = k*A + a (proposal_layer.py:98-103)
+__global__ void __launch_bounds__(256)
+rpn_decode_kernel(const float* __restrict__ cls, long cls_sb, long cls_sc, long cls_sp, int cls_is_prob,
+                  const float* __restrict__ bbox, long bbox_sb, long bbox_sc, long bbox_sp,
+                  const float* __restrict__ im_info, const float* __restrict__ base_anchors, int A, int H, int W,
+                  int feat_stride, float4* __restrict__ proposals, float* __restrict__ scores) {
+  const int b = blockIdx.y;
+  const int n = H * W * A;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = i % A, k = i / A;
+  const int w = k % W, h = k / W;
+  // fg probability: channel A+a (proposal_layer.py:67); softmax over the (bg=a, fg=A+a) pair (rpn.py:67-69)
+  const float* cp = cls + b * cls_sb + k * cls_sp;
+  float fg = cp[(long)(A + a) * cls_sc];
+  if (!cls_is_prob) {
+    float bg = cp[(long)a * cls_sc];
+    float m = fmaxf(bg, fg);
+    float e0 = expf(bg - m), e1 = expf(fg - m);
+    fg = e1 / (e0 + e1);
+  }
+  const float* bp = bbox + b * bbox_sb + k * bbox_sp + (long)(4 * a) * bbox_sc;
+  const float dx = bp[0], dy = bp[bbox_sc], dw = bp[2 * bbox_sc], dh = bp[3 * bbox_sc];
+  const float sx = (float)(w * feat_stride), sy = (float)(h * feat_stride);
+  const float ax1 = base_anchors[a * 4 + 0] + sx, ay1 = base_anchors[a * 4 + 1] + sy;
+  const float ax2 = base_anchors[a * 4 + 2] + sx, ay2 = base_anchors[a * 4 + 3] + sy;
+  const float widths = ax2 - ax1 + 1.0f, heights = ay2 - ay1 + 1.0f;
+  const float ctr_x = ax1 + 0.5f * widths, ctr_y = ay1 + 0.5f * heights;
+  const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+  const float pw = expf(dw) * widths, ph = expf(dh) * heights;  // unclamped exp (bbox_transform.py:90-91)
+  const float im_h = im_info[b * 3 + 0], im_w = im_info[b * 3 + 1];
+  float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+  x1 = fminf(fmaxf(x1, 0.f), im_w - 1.f);
+  y1 = fminf(fmaxf(y1, 0.f), im_h - 1.f);
+  x2 = fminf(fmaxf(x2, 0.f), im_w - 1.f);
+  y2 = fminf(fmaxf(y2, 0.f), im_h - 1.f);
+  proposals[(long)b * n + i] = make_float4(x1, y1, x2, y2);
+  scores[(long)b * n + i] = fg;
+}
+
+__global__ void __launch_bounds__(256) iota_kernel(int* __restrict__ v, int n, int total) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) v[i] = i % n;
+}
+
+struct SegOffset {
+  int n;
+  __host__ __device__ int operator()(int i) const { return i * n; }
+};
+
+__global__ void __launch_bounds__(256)
+gather_boxes_kernel(const float4* __restrict__ src, const int* __restrict__ order, int n, int order_stride, int topn,
+                    float4* __restrict__ dst) {
+  const int b = blockIdx.y;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= topn) return;
+  dst[(long)b * topn + r] = src[(long)b * n + order[(long)b * order_stride + r]];
+}
+
+// rois[b][r] = (b, box[keep[r]]) for r < num_keep[b], (b,0,0,0,0) after (proposal_layer.py:186-188)
+__global__ void __launch_bounds__(256)
+rois_assemble_kernel(const float4* __restrict__ boxes, const int* __restrict__ keep, const int* __restrict__ num_keep,
+                     int topn, int keep_stride, int post_n, float* __restrict__ rois) {
+  const int b = blockIdx.y;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= post_n) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < num_keep[b]) v = boxes[(long)b * topn + keep[(long)b * keep_stride + r]];
+  float* o = rois + ((long)b * post_n + r) * 5;
+  o[0] = (float)b;
+  o[1] = v.x;
+  o[2] = v.y;
+  o[3] = v.z;
+  o[4] = v.w;
+}
+
+size_t sort_temp_bytes(int B, int n) {
+  size_t bytes = 0;
+  auto off = rocprim::make_transform_iterator(rocprim::make_counting_iterator(0), SegOffset{n});
+  (void)rocprim::segmented_radix_sort_pairs_desc(nullptr, bytes, (const float*)nullptr, (float*)nullptr,
+                                                 (const int*)nullptr, (int*)nullptr, (unsigned)((size_t)B * n),
+                                                 (unsigned)B, off, off + 1, 0, 32, (hipStream_t)0);
+  return bytes;
+}
+
+struct SortPlan {
+  size_t temp, keys_out, vals_in, total;
+};
+SortPlan sort_plan(int B, int n) {
+  SortPlan p;
+  size_t t = dana_align_up(sort_temp_bytes(B, n), 256);
+  size_t kb = dana_align_up((size_t)B * n * 4, 256);
+  p.temp = 0;
+  p.keys_out = t;
+  p.vals_in = t + kb;
+  p.total = t + 2 * kb;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dana_rpn_decode(const float* cls, long cls_sb, long cls_sc, long cls_sp, int cls_is_prob, const float* bbox,
+                    long bbox_sb, long bbox_sc, long bbox_sp, const float* im_info, const float* base_anchors,
+                    int B, int A, int H, int W, int feat_stride, float* proposals, float* scores,
+                    dana_stream_t stream) {
+  DANA_CHECK_ARG(B >= 0 && A > 0 && H > 0 && W > 0, "dana_rpn_decode: bad shape B=%d A=%d H=%d W=%d", B, A, H, W);
+  if (B == 0) return DANA_OK;
+  DANA_CHECK_ARG(cls && bbox && im_info && base_anchors && proposals && scores, "dana_rpn_decode: null pointer");
+  const int n = H * W * A;
+  dim3 grid(dana_ceil_div(n, 256), B);
+  rpn_decode_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(cls, cls_sb, cls_sc, cls_sp, cls_is_prob, bbox, bbox_sb,
+                                                           bbox_sc, bbox_sp, im_info, base_anchors, A, H, W,
+                                                           feat_stride, (float4*)proposals, scores);
+  DANA_CHECK_LAUNCH("dana_rpn_decode");
+  return DANA_OK;
+}
+
+size_t dana_sort_desc_workspace_bytes(int B, int n) {
+  if (B <= 0 || n <= 0) return 0;
+  return sort_plan(B, n).total;
+}
+
+// Stable descending sort of each row of scores[B][n]; order[B][n] = source index within the row.
+int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_scores, void* workspace,
+                   size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(B >= 0 && n >= 0, "dana_sort_desc: bad shape");
+  if (B == 0 || n == 0) return DANA_OK;
+  DANA_CHECK_ARG(scores && order, "dana_sort_desc: null pointer");
+  SortPlan p = sort_plan(B, n);
+  if (!workspace || workspace_bytes < p.total) {
+    dana_set_error("dana_sort_desc: workspace %zu < %zu", workspace_bytes, p.total);
+    return DANA_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  float* keys_out = sorted_scores ? sorted_scores : (float*)(ws + p.keys_out);
+  int* vals_in = (int*)(ws + p.vals_in);
+  const int total = B * n;
+  iota_kernel<<<dana_ceil_div(total, 256), 256, 0, s>>>(vals_in, n, total);
+  DANA_CHECK_LAUNCH("dana_sort_desc(iota)");
+  size_t temp = p.keys_out;  // bytes available to rocprim
+  auto off = rocprim::make_transform_iterator(rocprim::make_counting_iterator(0), SegOffset{n});
+  hipError_t e = rocprim::segmented_radix_sort_pairs_desc((void*)(ws + p.temp), temp, scores, keys_out,
+                                                          (const int*)vals_in, order, (unsigned)total, (unsigned)B,
+                                                          off, off + 1, 0, 32, s);
+  if (e != hipSuccess) {
+    dana_set_error("dana_sort_desc: rocprim sort failed: %s", hipGetErrorString(e));
+    return DANA_ERR_HIP;
+  }
+  return DANA_OK;
+}
+
+int dana_gather_boxes(const float* src, const int* order, int B, int n, int order_stride, int topn, float* dst,
+                      dana_stream_t stream) {
+  DANA_CHECK_ARG(B >= 0 && n >= 0 && topn >= 0 && topn <= n, "dana_gather_boxes: bad shape");
+  if (B == 0 || topn == 0) return DANA_OK;
+  DANA_CHECK_ARG(src && order && dst, "dana_gather_boxes: null pointer");
+  dim3 grid(dana_ceil_div(topn, 256), B);
+  gather_boxes_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)src, order, n, order_stride, topn,
+                                                             (float4*)dst);
+  DANA_CHECK_LAUNCH("dana_gather_boxes");
+  return DANA_OK;
+}
+
+int dana_rois_assemble(const float* sorted_boxes, const int* keep, const int* num_keep, int B, int topn,
+                       int keep_stride, int post_n, float* rois, dana_stream_t stream) {
+  DANA_CHECK_ARG(B >= 0 && topn >= 0 && post_n >= 0, "dana_rois_assemble: bad shape");
+  if (B == 0 || post_n == 0) return DANA_OK;
+  DANA_CHECK_ARG(sorted_boxes && keep && num_keep && rois, "dana_rois_assemble: null pointer");
+  dim3 grid(dana_ceil_div(post_n, 256), B);
+  rois_assemble_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)sorted_boxes, keep, num_keep, topn,
+                                                              keep_stride, post_n, rois);
+  DANA_CHECK_LAUNCH("dana_rois_assemble");
+  return DANA_OK;
+}
+
+// ---- whole proposal layer in one call --------------------------------------------------------
+struct ProposalPlan {
+  size_t proposals, scores, order, sorted_boxes, keep, num_keep, sort_ws, nms_ws, total;
+  int topn;
+};
+static ProposalPlan proposal_plan(int B, int n, int pre_nms_topn, int post_nms_topn) {
+  ProposalPlan p;
+  // proposal_layer.py:148: `pre_nms_topN < scores_keep.numel()` compares against the WHOLE batch's count
+  p.topn = (pre_nms_topn > 0 && (long)pre_nms_topn < (long)B * n) ? (pre_nms_topn < n ? pre_nms_topn : n) : n;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o += dana_align_up(bytes, 256);
+    return at;
+  };
+  p.proposals = take((size_t)B * n * 16);
+  p.scores = take((size_t)B * n * 4);
+  p.order = take((size_t)B * n * 4);
+  p.sorted_boxes = take((size_t)B * p.topn * 16);
+  int mk = (post_nms_topn > 0 && post_nms_topn < p.topn) ? post_nms_topn : p.topn;
+  p.keep = take((size_t)B * mk * 4);
+  p.num_keep = take((size_t)B * 4);
+  p.sort_ws = take(dana_sort_desc_workspace_bytes(B, n));
+  p.nms_ws = take(dana_nms_workspace_bytes(p.topn, B));
+  p.total = o;
+  return p;
+}
+
+size_t dana_proposal_layer_workspace_bytes(int B, int A, int H, int W, int pre_nms_topn, int post_nms_topn) {
+  if (B <= 0 || A <= 0 || H <= 0 || W <= 0) return 0;
+  return proposal_plan(B, H * W * A, pre_nms_topn, post_nms_topn).total;
+}
+
+int dana_proposal_layer(const float* cls, long cls_sb, long cls_sc, long cls_sp, int cls_is_prob, const float* bbox,
+                        long bbox_sb, long bbox_sc, long bbox_sp, const float* im_info, const float* base_anchors,
+                        int B, int A, int H, int W, int feat_stride, int pre_nms_topn, int post_nms_topn,
+                        float nms_thresh, int nms_inclusive, float* rois, void* workspace, size_t workspace_bytes,
+                        dana_stream_t stream) {
+  DANA_CHECK_ARG(B >= 0 && A > 0 && H > 0 && W > 0 && post_nms_topn > 0, "dana_proposal_layer: bad shape");
+  if (B == 0) return DANA_OK;
+  const int n = H * W * A;
+  ProposalPlan p = proposal_plan(B, n, pre_nms_topn, post_nms_topn);
+  if (!workspace || workspace_bytes < p.total) {
+    dana_set_error("dana_proposal_layer: workspace %zu < %zu", workspace_bytes, p.total);
+    return DANA_ERR_WORKSPACE;
+  }
+  char* ws = (char*)workspace;
+  float* proposals = (float*)(ws + p.proposals);
+  float* scores = (float*)(ws + p.scores);
+  int* order = (int*)(ws + p.order);
+  float* sorted_boxes = (float*)(ws + p.sorted_boxes);
+  int* keep = (int*)(ws + p.keep);
+  int* num_keep = (int*)(ws + p.num_keep);
+  const int mk = post_nms_topn < p.topn ? post_nms_topn : p.topn;
+  int rc = dana_rpn_decode(cls, cls_sb, cls_sc, cls_sp, cls_is_prob, bbox, bbox_sb, bbox_sc, bbox_sp, im_info,
+                           base_anchors, B, A, H, W, feat_stride, proposals, scores, stream);
+  if (rc) return rc;
+  rc = dana_sort_desc(scores, B, n, order, nullptr, ws + p.sort_ws, p.nms_ws - p.sort_ws, stream);
+  if (rc) return rc;
+  rc = dana_gather_boxes(proposals, order, B, n, n, p.topn, sorted_boxes, stream);
+  if (rc) return rc;
+  rc = dana_nms(sorted_boxes, p.topn, B, nms_thresh, nms_inclusive, mk, keep, mk, num_keep, ws + p.nms_ws,
+                p.total - p.nms_ws, stream);
+  if (rc) return rc;
+  return dana_rois_assemble(sorted_boxes, keep, num_keep, B, p.topn, mk, post_nms_topn, rois, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,366 @@
+// RoIAlign / RoIPool for gfx950 -- HBM-bound gather kernels behind the C ABI.
+//
+// Replaces the reference's native ops (semantics, not code):
+//   RoIAlignForward          lib/model/csrc/cuda/ROIAlign_cuda.cu:64-122
+//   RoIAlignBackwardFeature  lib/model/csrc/cuda/ROIAlign_cuda.cu:177-254
+//   RoIPoolFForward/Backward lib/model/csrc/cuda/ROIPool_cuda.cu:16-108
+//
+// Two feature-map layouts:
+//   NCHW  -- the layout the reference's `_C.roi_align_forward` contract hands over.
+//   NHWC  -- the layout of this build's trunk: one workgroup per (roi, bin), 256 lanes
+//            x float4 sweep the channel axis, so every bilinear tap is a fully
+//            coalesced 16 B/lane read and the output row [C] is one contiguous store.
+//
+// This file is compiled with -ffp-contract=off so the per-sample arithmetic
+// (w1*v1 + w2*v2 + w3*v3 + w4*v4, running sum, final divide) rounds exactly like the
+// reference's C++ and like oracle/dana_oracle.c: parity is bit-exact.
+#include "common.h"
+#include "../../include/dana_hip.h"
+#include <float.h>
+
+namespace {
+
+struct AxisSample {  // one bilinear sample position along one axis
+  int lo, hi;
+  float l, h;  // l = frac toward hi, h = 1 - l
+  bool empty;
+};
+
+// ROIAlign_cuda.cu:22-47 (bilinear_interpolate), split per axis. `size` = H or W.
+__device__ __forceinline__ AxisSample axis_sample(float v, int size) {
+  AxisSample s;
+  s.empty = (v < -1.0f || v > (float)size);
+  if (v <= 0.f) v = 0.f;
+  int lo = (int)v;
+  int hi;
+  if (lo >= size - 1) {
+    hi = lo = size - 1;
+    v = (float)lo;
+  } else {
+    hi = lo + 1;
+  }
+  s.lo = lo;
+  s.hi = hi;
+  s.l = v - (float)lo;
+  s.h = 1.f - s.l;
+  return s;
+}
+
+struct RoiGeom {
+  int batch;
+  float start_w, start_h, bin_w, bin_h;
+  int grid_h, grid_w;
+  float count;
+};
+
+// ROIAlign_cuda.cu:78-103
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int ph, int pw, int sampling_ratio) {
+  RoiGeom g;
+  g.batch = (int)roi[0];
+  g.start_w = roi[1] * scale;
+  g.start_h = roi[2] * scale;
+  float end_w = roi[3] * scale;
+  float end_h = roi[4] * scale;
+  float rw = fmaxf(end_w - g.start_w, 1.f);
+  float rh = fmaxf(end_h - g.start_h, 1.f);
+  g.bin_h = rh / (float)ph;
+  g.bin_w = rw / (float)pw;
+  g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph);
+  g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw);
+  g.count = (float)(g.grid_h * g.grid_w);
+  return g;
+}
+
+// ---------------------------------------------------------------------------------
+// NCHW forward: one lane per output element, grid-stride.
+__global__ void __launch_bounds__(256)
+roi_align_fwd_nchw(const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out,
+                   long total, int C, int H, int W, int PH, int PW, float scale, int sr) {
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long)blockDim.x * gridDim.x) {
+    int pw = (int)(index % PW);
+    int ph = (int)((index / PW) % PH);
+    int c = (int)((index / PW / PH) % C);
+    int n = (int)(index / PW / PH / C);
+    RoiGeom g = roi_geom(rois + (long)n * 5, scale, PH, PW, sr);
+    const float* plane = in + ((long)g.batch * C + c) * H * W;
+    float acc = 0.f;
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      float y = g.start_h + ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+      AxisSample sy = axis_sample(y, H);
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        float x = g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+        AxisSample sx = axis_sample(x, W);
+        float val = 0.f;
+        if (!(sy.empty || sx.empty)) {
+          float v1 = plane[sy.lo * W + sx.lo], v2 = plane[sy.lo * W + sx.hi];
+          float v3 = plane[sy.hi * W + sx.lo], v4 = plane[sy.hi * W + sx.hi];
+          float w1 = sy.h * sx.h, w2 = sy.h * sx.l, w3 = sy.l * sx.h, w4 = sy.l * sx.l;
+          val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        }
+        acc += val;
+      }
+    }
+    out[index] = acc / g.count;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// NHWC forward: workgroup = (roi, bin); lane = 4 consecutive channels (float4), stride 256*4.
+// in pixel (b,y,x) lives at in + ((b*H+y)*W+x)*in_pix_stride; out[n][bin][C] (+ optional second
+// output out2 = out + add2[bin][C], used to emit the positional-encoded copy in the same pass).
+__global__ void __launch_bounds__(256)
+roi_align_fwd_nhwc(const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out,
+                   float* __restrict__ out2, const float* __restrict__ add2,
+                   int C, int H, int W, int PH, int PW, float scale, int sr, long in_pix_stride,
+                   long out_pix_stride, long out2_pix_stride) {
+  const int n = blockIdx.x;
+  const int bin = blockIdx.y;
+  const int ph = bin / PW, pw = bin % PW;
+  RoiGeom g = roi_geom(rois + (long)n * 5, scale, PH, PW, sr);
+  const float* img = in + (long)g.batch * H * W * in_pix_stride;
+  for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      float y = g.start_h + ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+      AxisSample sy = axis_sample(y, H);
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        float x = g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+        AxisSample sx = axis_sample(x, W);
+        if (sy.empty || sx.empty) continue;  // contributes exactly +0
+        const float4 v1 = *(const float4*)(img + ((long)sy.lo * W + sx.lo) * in_pix_stride + c);
+        const float4 v2 = *(const float4*)(img + ((long)sy.lo * W + sx.hi) * in_pix_stride + c);
+        const float4 v3 = *(const float4*)(img + ((long)sy.hi * W + sx.lo) * in_pix_stride + c);
+        const float4 v4 = *(const float4*)(img + ((long)sy.hi * W + sx.hi) * in_pix_stride + c);
+        float w1 = sy.h * sx.h, w2 = sy.h * sx.l, w3 = sy.l * sx.h, w4 = sy.l * sx.l;
+        acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+        acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+        acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+        acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+      }
+    }
+    float4 r = make_float4(acc.x / g.count, acc.y / g.count, acc.z / g.count, acc.w / g.count);
+    *(float4*)(out + ((long)n * PH * PW + bin) * out_pix_stride + c) = r;
+    if (out2) {
+      const float4 a = *(const float4*)(add2 + (long)bin * C + c);
+      *(float4*)(out2 + ((long)n * PH * PW + bin) * out2_pix_stride + c) =
+          make_float4(r.x + a.x, r.y + a.y, r.z + a.z, r.w + a.w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Backward (NCHW and NHWC): scatter grad*w/count to the four taps with fp32 atomics
+// (ROIAlign_cuda.cu:233-250; summation order is not deterministic there either).
+template <bool NHWC>
+__global__ void __launch_bounds__(256)
+roi_align_bwd(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin,
+              long total, int C, int H, int W, int PH, int PW, float scale, int sr) {
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long)blockDim.x * gridDim.x) {
+    int pw, ph, c, n;
+    if (NHWC) {  // gout [n][ph][pw][c]
+      c = (int)(index % C);
+      pw = (int)((index / C) % PW);
+      ph = (int)((index / C / PW) % PH);
+      n = (int)(index / C / PW / PH);
+    } else {  // gout [n][c][ph][pw]
+      pw = (int)(index % PW);
+      ph = (int)((index / PW) % PH);
+      c = (int)((index / PW / PH) % C);
+      n = (int)(index / PW / PH / C);
+    }
+    RoiGeom g = roi_geom(rois + (long)n * 5, scale, PH, PW, sr);
+    const float go = gout[index];
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      float y = g.start_h + ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+      AxisSample sy = axis_sample(y, H);
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        float x = g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+        AxisSample sx = axis_sample(x, W);
+        if (sy.empty || sx.empty) continue;
+        float w1 = sy.h * sx.h, w2 = sy.h * sx.l, w3 = sy.l * sx.h, w4 = sy.l * sx.l;
+        float g1 = go * w1 / g.count, g2 = go * w2 / g.count, g3 = go * w3 / g.count, g4 = go * w4 / g.count;
+        if (NHWC) {
+          float* base = gin + (long)g.batch * H * W * C + c;
+          atomicAdd(base + ((long)sy.lo * W + sx.lo) * C, g1);
+          atomicAdd(base + ((long)sy.lo * W + sx.hi) * C, g2);
+          atomicAdd(base + ((long)sy.hi * W + sx.lo) * C, g3);
+          atomicAdd(base + ((long)sy.hi * W + sx.hi) * C, g4);
+        } else {
+          float* base = gin + ((long)g.batch * C + c) * H * W;
+          atomicAdd(base + sy.lo * W + sx.lo, g1);
+          atomicAdd(base + sy.lo * W + sx.hi, g2);
+          atomicAdd(base + sy.hi * W + sx.lo, g3);
+          atomicAdd(base + sy.hi * W + sx.hi, g4);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// RoIPool (NCHW): ROIPool_cuda.cu:16-77 forward (max + int32 argmax), :79-108 backward.
+__global__ void __launch_bounds__(256)
+roi_pool_fwd_nchw(const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out,
+                  int* __restrict__ argmax, long total, int C, int H, int W, int PH, int PW, float scale) {
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long)blockDim.x * gridDim.x) {
+    int pw = (int)(index % PW);
+    int ph = (int)((index / PW) % PH);
+    int c = (int)((index / PW / PH) % C);
+    int n = (int)(index / PW / PH / C);
+    const float* roi = rois + (long)n * 5;
+    int b = (int)roi[0];
+    int rsw = (int)roundf(roi[1] * scale), rsh = (int)roundf(roi[2] * scale);
+    int rew = (int)roundf(roi[3] * scale), reh = (int)roundf(roi[4] * scale);
+    int rw = max(rew - rsw + 1, 1), rh = max(reh - rsh + 1, 1);
+    float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    int hs = (int)floorf((float)ph * bh), ws = (int)floorf((float)pw * bw);
+    int he = (int)ceilf((float)(ph + 1) * bh), we = (int)ceilf((float)(pw + 1) * bw);
+    hs = min(max(hs + rsh, 0), H);
+    he = min(max(he + rsh, 0), H);
+    ws = min(max(ws + rsw, 0), W);
+    we = min(max(we + rsw, 0), W);
+    bool empty = (he <= hs) || (we <= ws);
+    float m = empty ? 0.f : -FLT_MAX;
+    int mi = -1;
+    const float* plane = in + ((long)b * C + c) * H * W;
+    for (int h = hs; h < he; ++h)
+      for (int w = ws; w < we; ++w) {
+        float v = plane[h * W + w];
+        if (v > m) {
+          m = v;
+          mi = h * W + w;
+        }
+      }
+    out[index] = m;
+    argmax[index] = mi;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+roi_pool_bwd_nchw(const float* __restrict__ gout, const int* __restrict__ argmax, const float* __restrict__ rois,
+                  float* __restrict__ gin, long total, int C, int H, int W, int PH, int PW) {
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long)blockDim.x * gridDim.x) {
+    int c = (int)((index / PW / PH) % C);
+    int n = (int)(index / PW / PH / C);
+    int b = (int)rois[(long)n * 5];
+    int a = argmax[index];
+    if (a != -1) atomicAdd(gin + ((long)b * C + c) * H * W + a, gout[index]);
+  }
+}
+
+int stream_grid(long total, int block) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 8192 ? (g < 1 ? 1 : g) : 8192);  // 256 CUs x 32 resident blocks, grid-stride the rest
+}
+
+}  // namespace
+
+extern "C" {
+
+int dana_roi_align_forward(const float* input, const float* rois, float* output, int batch, int channels,
+                           int height, int width, int num_rois, float spatial_scale, int pooled_h,
+                           int pooled_w, int sampling_ratio, int layout, long in_pix_stride,
+                           long out_pix_stride, float* output2, const float* add2, long out2_pix_stride,
+                           dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && channels > 0 && height > 0 && width > 0 && num_rois >= 0 && pooled_h > 0 &&
+                     pooled_w > 0,
+                 "dana_roi_align_forward: bad shape B=%d C=%d H=%d W=%d R=%d P=%dx%d", batch, channels, height,
+                 width, num_rois, pooled_h, pooled_w);
+  if (num_rois == 0) return DANA_OK;  // ROIAlign_cuda.cu:278-281: empty -> no launch
+  DANA_CHECK_ARG(input && rois && output, "dana_roi_align_forward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (layout == DANA_LAYOUT_NCHW) {
+    DANA_CHECK_ARG(!output2, "dana_roi_align_forward: second output is NHWC-only");
+    long total = (long)num_rois * channels * pooled_h * pooled_w;
+    roi_align_fwd_nchw<<<stream_grid(total, 256), 256, 0, s>>>(input, rois, output, total, channels, height, width,
+                                                              pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  } else if (layout == DANA_LAYOUT_NHWC) {
+    if (in_pix_stride <= 0) in_pix_stride = channels;
+    if (out_pix_stride <= 0) out_pix_stride = channels;
+    if (out2_pix_stride <= 0) out2_pix_stride = channels;
+    DANA_CHECK_ARG(channels % 4 == 0 && in_pix_stride % 4 == 0 && out_pix_stride % 4 == 0 &&
+                       out2_pix_stride % 4 == 0,
+                   "dana_roi_align_forward: NHWC needs C and pixel strides %% 4 == 0");
+    DANA_CHECK_ARG(!output2 || add2, "dana_roi_align_forward: output2 needs add2");
+    dim3 grid(num_rois, pooled_h * pooled_w);
+    roi_align_fwd_nhwc<<<grid, 256, 0, s>>>(input, rois, output, output2, add2, channels, height, width, pooled_h,
+                                            pooled_w, spatial_scale, sampling_ratio, in_pix_stride,
+                                            out_pix_stride, out2_pix_stride);
+  } else {
+    DANA_CHECK_ARG(false, "dana_roi_align_forward: unknown layout %d", layout);
+  }
+  DANA_CHECK_LAUNCH("dana_roi_align_forward");
+  return DANA_OK;
+}
+
+int dana_roi_align_backward(const float* grad_out, const float* rois, float* grad_in, int batch, int channels,
+                            int height, int width, int num_rois, float spatial_scale, int pooled_h,
+                            int pooled_w, int sampling_ratio, int layout, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && channels > 0 && height > 0 && width > 0 && num_rois >= 0,
+                 "dana_roi_align_backward: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  size_t bytes = (size_t)batch * channels * height * width * sizeof(float);
+  if (bytes) {
+    DANA_CHECK_ARG(grad_in, "dana_roi_align_backward: null grad_in");
+    if (hipMemsetAsync(grad_in, 0, bytes, s) != hipSuccess) {  // ROIAlign_cuda.cu:316 zero-init
+      dana_set_error("dana_roi_align_backward: memset failed");
+      return DANA_ERR_HIP;
+    }
+  }
+  if (num_rois == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad_out && rois, "dana_roi_align_backward: null pointer");
+  long total = (long)num_rois * channels * pooled_h * pooled_w;
+  if (layout == DANA_LAYOUT_NCHW)
+    roi_align_bwd<false><<<stream_grid(total, 256), 256, 0, s>>>(grad_out, rois, grad_in, total, channels, height,
+                                                                 width, pooled_h, pooled_w, spatial_scale,
+                                                                 sampling_ratio);
+  else
+    roi_align_bwd<true><<<stream_grid(total, 256), 256, 0, s>>>(grad_out, rois, grad_in, total, channels, height,
+                                                                width, pooled_h, pooled_w, spatial_scale,
+                                                                sampling_ratio);
+  DANA_CHECK_LAUNCH("dana_roi_align_backward");
+  return DANA_OK;
+}
+
+int dana_roi_pool_forward(const float* input, const float* rois, float* output, int* argmax, int batch,
+                          int channels, int height, int width, int num_rois, float spatial_scale, int pooled_h,
+                          int pooled_w, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && channels > 0 && height > 0 && width > 0 && num_rois >= 0,
+                 "dana_roi_pool_forward: bad shape");
+  if (num_rois == 0) return DANA_OK;
+  DANA_CHECK_ARG(input && rois && output && argmax, "dana_roi_pool_forward: null pointer");
+  long total = (long)num_rois * channels * pooled_h * pooled_w;
+  roi_pool_fwd_nchw<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(
+      input, rois, output, argmax, total, channels, height, width, pooled_h, pooled_w, spatial_scale);
+  DANA_CHECK_LAUNCH("dana_roi_pool_forward");
+  return DANA_OK;
+}
+
+int dana_roi_pool_backward(const float* grad_out, const int* argmax, const float* rois, float* grad_in,
+                           int batch, int channels, int height, int width, int num_rois, int pooled_h,
+                           int pooled_w, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && channels > 0 && height > 0 && width > 0 && num_rois >= 0,
+                 "dana_roi_pool_backward: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  size_t bytes = (size_t)batch * channels * height * width * sizeof(float);
+  if (bytes) {
+    DANA_CHECK_ARG(grad_in, "dana_roi_pool_backward: null grad_in");
+    if (hipMemsetAsync(grad_in, 0, bytes, s) != hipSuccess) {
+      dana_set_error("dana_roi_pool_backward: memset failed");
+      return DANA_ERR_HIP;
+    }
+  }
+  if (num_rois == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad_out && argmax && rois, "dana_roi_pool_backward: null pointer");
+  long total = (long)num_rois * channels * pooled_h * pooled_w;
+  roi_pool_bwd_nchw<<<stream_grid(total, 256), 256, 0, s>>>(grad_out, argmax, rois, grad_in, total, channels,
+                                                            height, width, pooled_h, pooled_w);
+  DANA_CHECK_LAUNCH("dana_roi_pool_backward");
+  return DANA_OK;
+}
+
+}  // extern "C"

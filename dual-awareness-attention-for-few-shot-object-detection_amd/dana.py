@@ -1,0 +1,469 @@
+"""DAnARCNN on MI355X: the reference's module API (lib/model/framework/dana.py:19-389) over the
+hand-written gfx950 kernels of libdana_hip.so.
+
+Drop-in contract: same constructor, ``create_architecture()``, 5-tensor ``forward``
+returning the 8-tuple, ``train()`` override, and a key/shape-compatible ``state_dict`` (346 entries):
+the parameter containers below are ordinary ``nn`` modules laid out exactly like the reference's
+``RCNN_base`` / ``RCNN_top`` / heads, but they are never *called* -- the forward pass walks them,
+packs their weights once (re-packed when a parameter's version counter moves) and launches HIP
+kernels on NHWC buffers. There is no torch fallback: CPU tensors raise.
+
+Data layout in HBM (all fp32):
+  activations   NHWC flat ``[pixels][channels]``; producers write with a row stride so that
+                base_feat | attended feature share one ``[B*h*w][2048]`` buffer (dana.py:153-154's
+                torch.cat never materialises), same for the RoI-level ``[n*49][2048]`` concat (:284).
+  conv weights  ``[cout][kh][kw][cin]``; nn.Linear weights ``[out][in]`` used as stored.
+  frozen BN     folded to per-channel scale/shift applied in the conv epilogue (dana.py:362-385).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .config import cfg
+from . import targets as T
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers with the reference's names (lib/model/framework/resnet.py:66-146)
+# ------------------------------------------------------------------------------------------------
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride, bias=False)  # stride on the 1x1
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+def _make_layer(inplanes, planes, blocks, stride):
+    downsample = None
+    if stride != 1 or inplanes != planes * 4:
+        downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                   nn.BatchNorm2d(planes * 4))
+    layers = [Bottleneck(inplanes, planes, stride, downsample)]
+    layers += [Bottleneck(planes * 4, planes) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
+class _ResNet50Params(nn.Module):
+    """resnet50() of resnet.py:188 (layers [3,4,6,3]); init as resnet.py:122-128."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=0, ceil_mode=True)
+        self.layer1 = _make_layer(64, 64, 3, 1)
+        self.layer2 = _make_layer(256, 128, 4, 2)
+        self.layer3 = _make_layer(512, 256, 6, 2)
+        self.layer4 = _make_layer(1024, 512, 3, 2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+
+class FFN(nn.Module):
+    """dana.py:295-306 (parameters only here)."""
+
+    def __init__(self, in_channel, hidden):
+        super().__init__()
+        self.linear1 = nn.Linear(in_channel, hidden)
+        self.linear2 = nn.Linear(hidden, 2)
+
+
+class _RPNParams(nn.Module):
+    """lib/model/rpn/rpn.py:17-45 (parameters only)."""
+
+    def __init__(self, din):
+        super().__init__()
+        self.din = din
+        self.anchor_scales = cfg.ANCHOR_SCALES
+        self.anchor_ratios = cfg.ANCHOR_RATIOS
+        self.feat_stride = cfg.FEAT_STRIDE[0]
+        self.RPN_Conv = nn.Conv2d(din, 512, 3, 1, 1, bias=True)
+        self.nc_score_out = len(self.anchor_scales) * len(self.anchor_ratios) * 2
+        self.RPN_cls_score = nn.Conv2d(512, self.nc_score_out, 1, 1, 0)
+        self.nc_bbox_out = len(self.anchor_scales) * len(self.anchor_ratios) * 4
+        self.RPN_bbox_pred = nn.Conv2d(512, self.nc_bbox_out, 1, 1, 0)
+
+
+def positional_encoding_table(max_len, d_model=1024):
+    """dana.py:309-320; a plain attribute in the reference (not in state_dict), regenerated here."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0., max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0., d_model, 2) * -(math.log(10000.0) / float(d_model)))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+class DAnARCNN(nn.Module):
+    """Dual-Awareness-Attention Faster R-CNN (dana.py:19,327)."""
+
+    def __init__(self, classes, attention_type="concat", rpn_reduce_dim=256, rcnn_reduce_dim=256, gamma=0.1,
+                 semantic_enhance=False, num_layers=50, pretrained=False, num_way=2, num_shot=5, pos_encoding=True):
+        super().__init__()
+        if attention_type != "concat":
+            raise NotImplementedError("only attention_type='concat' (what utils.get_model builds, utils.py:120)")
+        self.model_path = "data/pretrained_model/resnet50_caffe.pth"
+        self.dout_base_model = 1024
+        self.pretrained = pretrained
+        self.classes = classes
+        self.n_classes = len(classes)
+        self.n_way = num_way
+        self.n_shot = num_shot
+        self.attention_type = attention_type
+        self.channel_gamma = gamma
+        self.unary_gamma = 0.1
+        self.semantic_enhance = semantic_enhance
+        self.rpn_reduce_dim = rpn_reduce_dim
+        self.rcnn_reduce_dim = rcnn_reduce_dim
+        self.pos_encoding = pos_encoding
+        self.pool_feat_dim = 1024
+        self.rcnn_dim = 64
+        self.nms_inclusive = False  # False: IoU > thr as the reference CUDA op (nms.cu:60); True: CPU op (>=)
+        dim_in = self.pool_feat_dim
+
+        def lin(i, o):
+            m = nn.Linear(i, o)
+            nn.init.normal_(m.weight, std=0.01)
+            nn.init.constant_(m.bias, 0)
+            return m
+
+        self.rpn_unary_layer = lin(dim_in, 1)
+        self.rcnn_unary_layer = lin(dim_in, 1)
+        self.rpn_adapt_q_layer = lin(dim_in, rpn_reduce_dim)
+        self.rpn_adapt_k_layer = lin(dim_in, rpn_reduce_dim)
+        self.rcnn_adapt_q_layer = lin(dim_in, rcnn_reduce_dim)
+        self.rcnn_adapt_k_layer = lin(dim_in, rcnn_reduce_dim)
+        if self.semantic_enhance:
+            self.rpn_channel_k_layer = lin(dim_in, 1)
+        self.RCNN_rpn = _RPNParams(2048)
+        self.rcnn_transform_layer = nn.Linear(2048, self.rcnn_dim)
+        self.output_score_layer = FFN(64 * 49, dim_in)
+        self._plan = None
+        self._consts = {}
+
+    # ---- reference API -------------------------------------------------------------------------
+    def create_architecture(self):
+        self._init_modules()
+        self._init_weights()
+
+    def _init_modules(self):
+        resnet = _ResNet50Params()
+        if self.pretrained:
+            print("Loading pretrained weights from %s" % (self.model_path))
+            state_dict = torch.load(self.model_path)
+            resnet.load_state_dict({k: v for k, v in state_dict.items() if k in resnet.state_dict()})
+        self.RCNN_base = nn.Sequential(resnet.conv1, resnet.bn1, resnet.relu, resnet.maxpool, resnet.layer1,
+                                       resnet.layer2, resnet.layer3)
+        self.RCNN_top = nn.Sequential(resnet.layer4)
+        self.RCNN_bbox_pred = nn.Linear(2048, 4)
+        for p in self.RCNN_base[0].parameters():
+            p.requires_grad = False
+        for p in self.RCNN_base[1].parameters():
+            p.requires_grad = False
+        assert 0 <= cfg.RESNET.FIXED_BLOCKS < 4
+        for blk, idx in ((3, 6), (2, 5), (1, 4)):
+            if cfg.RESNET.FIXED_BLOCKS >= blk:
+                for p in self.RCNN_base[idx].parameters():
+                    p.requires_grad = False
+        for m in list(self.RCNN_base.modules()) + list(self.RCNN_top.modules()):
+            if isinstance(m, nn.BatchNorm2d):
+                for p in m.parameters():
+                    p.requires_grad = False
+
+    def _init_weights(self):
+        for m, std in ((self.RCNN_rpn.RPN_Conv, 0.01), (self.RCNN_rpn.RPN_cls_score, 0.01),
+                       (self.RCNN_rpn.RPN_bbox_pred, 0.01), (self.RCNN_bbox_pred, 0.001)):
+            m.weight.data.normal_(0, std)
+            m.bias.data.zero_()
+
+    def train(self, mode=True):
+        nn.Module.train(self, mode)
+        if mode and hasattr(self, "RCNN_base"):
+            self.RCNN_base.eval()
+            self.RCNN_base[5].train()
+            self.RCNN_base[6].train()
+            for m in list(self.RCNN_base.modules()) + list(self.RCNN_top.modules()):
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+    # ---- weight plan: packed conv weights + folded BN, cached by parameter versions ------------
+    def _sig(self):
+        dev = str(self.RCNN_bbox_pred.weight.device)
+        cached = self._consts.get("sig_tensors")
+        if cached is None or cached[0] != dev:  # module.to(device) swaps buffers: re-collect the tensor list
+            cached = (dev, list(self.state_dict(keep_vars=True).values()))
+            self._consts["sig_tensors"] = cached
+        return (dev,) + tuple(t._version for t in cached[1])
+
+    def _conv_bn(self, conv, bn, stem=False):
+        w = ops.pack_conv_weight(conv.weight, stem=stem)
+        scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        return dict(w=w, scale=scale, shift=shift, cin=conv.in_channels, cout=conv.out_channels,
+                    k=conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0])
+
+    def _block_plan(self, blk):
+        d = dict(c1=self._conv_bn(blk.conv1, blk.bn1), c2=self._conv_bn(blk.conv2, blk.bn2),
+                 c3=self._conv_bn(blk.conv3, blk.bn3), ds=None)
+        if blk.downsample is not None:
+            d["ds"] = self._conv_bn(blk.downsample[0], blk.downsample[1])
+        return d
+
+    def _get_plan(self):
+        sig = self._sig()
+        if self._plan is not None and self._plan["sig"] == sig:
+            return self._plan
+        dev = self.RCNN_bbox_pred.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("DAnARCNN.forward needs the model on a HIP device (model.cuda()); no CPU path")
+        p = dict(sig=sig)
+        p["stem"] = self._conv_bn(self.RCNN_base[0], self.RCNN_base[1], stem=True)
+        p["layers"] = [[self._block_plan(b) for b in self.RCNN_base[i]] for i in (4, 5, 6)]
+        p["layer4"] = [self._block_plan(b) for b in self.RCNN_top[0]]
+        rpn = self.RCNN_rpn
+        p["rpn_conv_w"] = ops.pack_conv_weight(rpn.RPN_Conv.weight)
+        p["rpn_conv_b"] = rpn.RPN_Conv.bias.detach().contiguous()
+        p["rpn_head_w"] = torch.cat([rpn.RPN_cls_score.weight.detach().view(rpn.nc_score_out, -1),
+                                     rpn.RPN_bbox_pred.weight.detach().view(rpn.nc_bbox_out, -1)], 0).contiguous()
+        p["rpn_head_b"] = torch.cat([rpn.RPN_cls_score.bias.detach(), rpn.RPN_bbox_pred.bias.detach()], 0).contiguous()
+        anchors = T.generate_anchors(scales=np.array(cfg.ANCHOR_SCALES), ratios=np.array(cfg.ANCHOR_RATIOS))
+        p["anchors"] = torch.from_numpy(anchors).float().to(dev)
+        p["pe400"] = positional_encoding_table(400).to(dev)
+        p["pe49"] = positional_encoding_table(49).to(dev)
+        self._plan = p
+        return p
+
+    @staticmethod
+    def _w(layer):
+        return layer.weight.detach().contiguous(), layer.bias.detach().contiguous()
+
+    # ---- trunk -----------------------------------------------------------------------------------
+    @staticmethod
+    def _conv(x, n, h, w, c, relu, residual=None, res_stride=0, out=None, out_stride=0, in_stride=0):
+        return ops.conv2d_nhwc(x, n, h, w, c["cin"], c["w"], c["cout"], c["k"], c["k"], c["stride"], c["pad"],
+                               scale=c["scale"], shift=c["shift"], residual=residual, relu=relu,
+                               in_stride=in_stride, out=out, out_stride=out_stride, res_stride=res_stride)
+
+    def _bottleneck(self, x, n, h, w, bp, out=None, out_stride=0, in_stride=0):
+        o1, h1, w1 = self._conv(x, n, h, w, bp["c1"], True, in_stride=in_stride)
+        o2, _, _ = self._conv(o1, n, h1, w1, bp["c2"], True)
+        if bp["ds"] is not None:
+            res, _, _ = self._conv(x, n, h, w, bp["ds"], False, in_stride=in_stride)
+            rs = 0
+        else:
+            res, rs = x, in_stride
+        o3, _, _ = self._conv(o2, n, h1, w1, bp["c3"], True, residual=res, res_stride=rs, out=out,
+                              out_stride=out_stride)
+        return o3, h1, w1
+
+    def _rcnn_base(self, im, plan, out_stride=0):
+        """RCNN_base (dana.py:344-345) on NCHW input -> (NHWC flat buffer [n*h*w][out_stride or 1024], h, w)."""
+        n, _, H, W = im.shape
+        x4 = ops.nchw_to_nhwc(im, cpad=4)
+        st = plan["stem"]
+        x, h, w = ops.conv2d_nhwc(x4, n, H, W, 4, st["w"], 64, 7, 7, 2, 3, scale=st["scale"], shift=st["shift"],
+                                  relu=True, stem=True)
+        x, h, w = ops.maxpool3x3s2_ceil(x, n, h, w, 64)
+        nl = len(plan["layers"])
+        for li, layer in enumerate(plan["layers"]):
+            for bi, bp in enumerate(layer):
+                last = (li == nl - 1) and (bi == len(layer) - 1)
+                out = None
+                if last and out_stride:
+                    hh = (h - 1) // bp["c1"]["stride"] + 1
+                    ww = (w - 1) // bp["c1"]["stride"] + 1
+                    out = torch.empty((n * hh * ww, out_stride), dtype=torch.float32, device=im.device)
+                x, h, w = self._bottleneck(x, n, h, w, bp, out=out, out_stride=out_stride if last else 0)
+        return x, h, w
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, im_data, im_info, gt_boxes, num_boxes, support_ims, all_cls_gt_boxes=None):
+        plan = self._get_plan()
+        dev = im_data.device
+        training = self.training
+        self.num_of_rois = cfg.TRAIN.BATCH_SIZE if training else cfg.TEST.RPN_POST_NMS_TOP_N
+        B = im_data.size(0)
+        im_info = im_info.data.float().contiguous()
+        gt_boxes = gt_boxes.data
+        shot = self.n_shot
+        way = self.n_way if training else 1  # eval reshapes supports as [*, n_shot] (dana.py:111)
+        inter = getattr(self, "_capture", None)
+
+        # -- feature extraction (dana.py:98-115) --
+        corr, fh, fw = self._rcnn_base(im_data, plan, out_stride=2048)  # base_feat = corr[:, :1024]
+        hw = fh * fw
+        sup_ims = support_ims.reshape(-1, support_ims.size(2), support_ims.size(3), support_ims.size(4))
+        sup, sh_, sw_ = self._rcnn_base(sup_ims, plan)  # [Ns*400][1024]
+        if (sh_, sw_) != (20, 20):
+            raise RuntimeError("support images must be 320x320 (20x20 stride-16 map), as the reference hard-codes "
+                               "(dana.py:105); got a %dx%d map" % (sh_, sw_))
+        Ns = sup_ims.size(0)
+        if Ns != B * way * shot:
+            raise RuntimeError("support_ims must hold batch*way*shot = %d images, got %d" % (B * way * shot, Ns))
+        L = 400
+
+        # -- RPN-level dual-awareness attention (dana.py:118-154) --
+        wq, bq = self._w(self.rpn_adapt_q_layer)
+        qp = ops.gemm_nt(corr, wq, B * hw, self.rpn_reduce_dim, 1024, lda=2048, shift=bq)
+        ops.colmean_sub_(qp, B, hw, self.rpn_reduce_dim)
+        s_pe = torch.empty((B, shot * L, 1024), dtype=torch.float32, device=dev)
+        sup3 = sup.view(Ns, L * 1024)
+        for b in range(B):  # positives = the first `shot` supports of each image (dana.py:103)
+            ops.add_pe(sup3[b * way * shot], plan["pe400"], shot * L, L, 1024, out=s_pe[b])
+        if self.semantic_enhance:  # BA block (dana.py:133-137)
+            wc, bc = self._w(self.rpn_channel_k_layer)
+            wgt = ops.rowdot(s_pe, wc, bc, B * shot * L, 1024)
+            ops.softmax_rows_(wgt, B * shot, L)
+            ops.ba_apply_(s_pe, wgt, B * shot, L, 1024, gamma=self.channel_gamma, slope=0.01)
+        wk, bk = self._w(self.rpn_adapt_k_layer)
+        kp = ops.gemm_nt(s_pe, wk, B * shot * L, self.rpn_reduce_dim, 1024, shift=bk)
+        ops.colmean_sub_(kp, B * shot, L, self.rpn_reduce_dim)
+        wu, bu = self._w(self.rpn_unary_layer)
+        unary = ops.rowdot(s_pe, wu, bu, B * shot * L, 1024)
+        ops.softmax_rows_(unary, B * shot, L)
+        K1 = shot * L
+        scores = torch.empty((B, hw, K1), dtype=torch.float32, device=dev)
+        d = self.rpn_reduce_dim
+        ops.gemm_nt(qp, kp, hw, K1, d, out=scores, ldc=K1, batch=B, batch_a=hw * d, batch_b=K1 * d, batch_c=hw * K1,
+                    alpha=1.0 / math.sqrt(d))
+        ops.attn_softmax_unary_(scores, unary, B * hw, hw, shot, L, K1, K1, self.unary_gamma, 1.0 / shot)
+        s_t = ops.transpose_batched(s_pe, B, K1, 1024)  # [B][1024][K1]
+        ops.gemm_nt(scores, s_t, hw, 1024, K1, lda=K1, ldb=K1, out=corr.view(-1)[1024:], ldc=2048, batch=B,
+                    batch_a=hw * K1, batch_b=1024 * K1, batch_c=hw * 2048)
+        if inter is not None:
+            inter["corr"] = (corr, B, fh, fw)
+
+        # -- RPN head + proposals (rpn.py:58-78, proposal_layer.py:49-190) --
+        rpn = self.RCNN_rpn
+        x, _, _ = ops.conv2d_nhwc(corr, B, fh, fw, 2048, plan["rpn_conv_w"], 512, 3, 3, 1, 1, shift=plan["rpn_conv_b"],
+                                  relu=True)
+        nh = rpn.nc_score_out + rpn.nc_bbox_out
+        heads = ops.gemm_nt(x, plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])  # [B*hw][2A | 4A]
+        A = plan["anchors"].size(0)
+        key = "TRAIN" if training else "TEST"
+        rois = ops.proposal_layer(heads, (hw * nh, 1, nh), False, heads.view(-1)[rpn.nc_score_out:], (hw * nh, 1, nh),
+                                  im_info, plan["anchors"], B, A, fh, fw, rpn.feat_stride,
+                                  cfg[key].RPN_PRE_NMS_TOP_N, cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH,
+                                  self.nms_inclusive)
+        if inter is not None:
+            inter["rpn_heads"] = heads
+            inter["rpn_rois"] = rois
+
+        rpn_loss_cls = rpn_loss_bbox = 0
+        rois_label = None
+        if training:
+            heads4 = heads.view(B, fh, fw, nh)
+            rpn_cls_score = heads4[..., :rpn.nc_score_out].permute(0, 3, 1, 2)  # [B,2A,H,W] view
+            rpn_bbox_pred = heads4[..., rpn.nc_score_out:].permute(0, 3, 1, 2)
+            labels, bt, biw, bow = T.anchor_target_layer(fh, fw, gt_boxes, im_info, plan["anchors"])
+            sc = rpn_cls_score.reshape(B, 2, A * fh, fw).permute(0, 2, 3, 1).reshape(-1, 2)
+            lab = labels.view(-1)
+            keep = lab.ne(-1).nonzero().view(-1)
+            rpn_loss_cls = F.cross_entropy(sc[keep], lab[keep].long())
+            rpn_loss_bbox = T._smooth_l1_loss(rpn_bbox_pred, bt, biw, bow, sigma=3, dim=[1, 2, 3])
+            rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = T.proposal_target_layer(rois, gt_boxes)
+            rois_label = rois_label.view(-1).long()
+            rois_target = rois_target.view(-1, 4)
+            rois_inside_ws = rois_inside_ws.view(-1, 4)
+            rois_outside_ws = rois_outside_ws.view(-1, 4)
+        R = rois.size(1)
+        n_roi = B * R
+
+        # -- RoIAlign on base_feat (dana.py:181-186), emitting pooled and pooled+PE in one pass --
+        if cfg.POOLING_MODE != "align":
+            raise NotImplementedError("POOLING_MODE '%s': the DAnA recipe uses 'align' (cfgs/res50.yml:35)"
+                                      % cfg.POOLING_MODE)
+        P = cfg.POOLING_SIZE
+        P2 = P * P
+        cat = torch.empty((n_roi * P2, 2048), dtype=torch.float32, device=dev)  # [q+PE | attended] (dana.py:284)
+        pooled, _ = ops.roi_align_forward_nhwc(corr, B, fh, fw, 1024, 2048, rois.view(-1, 5), 1.0 / 16.0, P, 0,
+                                               pe=plan["pe49"], out_pe=cat, out_pe_stride=2048)
+        if inter is not None:
+            inter["pooled"] = pooled
+
+        # -- box regression branch: layer4 + mean + Linear (dana.py:246,387-389); shared by pos/neg heads --
+        y, h4, w4 = pooled, P, P
+        for bp in plan["layer4"]:
+            y, h4, w4 = self._bottleneck(y, n_roi, h4, w4, bp)
+        fc7 = ops.spatial_mean(y, n_roi, h4 * w4, 2048)
+        wb, bb = self._w(self.RCNN_bbox_pred)
+        bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
+
+        # -- RoI-level CISA (dana.py:248-292); K / unary projections once per support (not per RoI) --
+        dq = self.rcnn_reduce_dim
+        wq2, bq2 = self._w(self.rcnn_adapt_q_layer)
+        q2 = ops.gemm_nt(cat, wq2, n_roi * P2, dq, 1024, lda=2048, shift=bq2)
+        ops.colmean_sub_(q2, n_roi, P2, dq)
+        sp = ops.avgpool(sup, Ns, 20, 20, 1024, 14, 1)  # [Ns][49][1024]  (dana.py:105-108)
+        sp_pe = ops.add_pe(sp, plan["pe49"], Ns * P2, P2, 1024)
+        wk2, bk2 = self._w(self.rcnn_adapt_k_layer)
+        k2 = ops.gemm_nt(sp_pe, wk2, Ns * P2, dq, 1024, shift=bk2)
+        ops.colmean_sub_(k2, Ns, P2, dq)
+        wu2, bu2 = self._w(self.rcnn_unary_layer)
+        un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
+        ops.softmax_rows_(un2, Ns, P2)
+        K2 = shot * P2
+        K2p = (K2 + 31) // 32 * 32
+        wt, bt_ = self._w(self.rcnn_transform_layer)
+        w1, b1 = self._w(self.output_score_layer.linear1)
+        w2, b2 = self._w(self.output_score_layer.linear2)
+
+        def head(offset):  # offset 0: positive supports, `shot`: negatives (dana.py:189-190)
+            kb = k2.view(-1)[offset * P2 * dq:]
+            ub = un2.view(-1)[offset * P2:]
+            sb = sp_pe.view(-1)[offset * P2 * 1024:]
+            sc2 = torch.empty((B, R * P2, K2p), dtype=torch.float32, device=dev)
+            ops.gemm_nt(q2, kb, R * P2, K2, dq, out=sc2, ldc=K2p, batch=B, batch_a=R * P2 * dq,
+                        batch_b=way * shot * P2 * dq, batch_c=R * P2 * K2p, alpha=1.0 / math.sqrt(dq))
+            ops.attn_softmax_unary_(sc2, ub, n_roi * P2, R * P2, shot, P2, K2p, K2p, self.unary_gamma, 1.0 / shot,
+                                    unary_batch_stride=way * shot * P2)
+            st2 = ops.transpose_batched(sb, B, K2, 1024, ldi=1024, ldo=K2p, in_batch=way * shot * P2 * 1024)
+            ops.gemm_nt(sc2, st2, R * P2, 1024, K2p, lda=K2p, ldb=K2p, out=cat.view(-1)[1024:], ldc=2048, batch=B,
+                        batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 2048)
+            tr = ops.gemm_nt(cat, wt, n_roi * P2, self.rcnn_dim, 2048, shift=bt_)  # [n*49][64] == [n][3136]
+            hid = ops.gemm_nt(tr, w1, n_roi, w1.size(0), P2 * self.rcnn_dim, shift=b1, relu=True)
+            score = ops.gemm_nt(hid, w2, n_roi, 2, w1.size(0), shift=b2)
+            prob = ops.softmax_rows_(score.clone(), n_roi, 2)
+            return prob, score
+
+        cls_prob, cls_score_all = head(0)
+        RCNN_loss_cls = RCNN_loss_bbox = 0
+        if training:
+            neg_prob, neg_score = head(shot)
+            cls_prob = torch.cat([cls_prob, neg_prob], 0)
+            cls_score_all = torch.cat([cls_score_all, neg_score], 0)
+            rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
+            RCNN_loss_bbox = T._smooth_l1_loss(bbox_pred, rois_target, rois_inside_ws, rois_outside_ws)
+            # 2-way classification loss with 1:2:1 hard-negative mining (dana.py:203-215)
+            fg_inds = (rois_label == 1).nonzero().squeeze(-1)
+            bg_inds = (rois_label == 0).nonzero().squeeze(-1)
+            bg_soft = F.softmax(cls_score_all, dim=1)[bg_inds, :]
+            n_all = rois_label.shape[0]
+            bg_num_0 = max(1, min(fg_inds.shape[0] * 2, int(n_all * 0.25)))
+            bg_num_1 = max(1, min(fg_inds.shape[0], bg_num_0))
+            _, order = torch.sort(bg_soft[:, 1], descending=True)
+            real_bg = bg_inds[order]
+            top0 = real_bg[real_bg < int(n_all * 0.5)][:bg_num_0]
+            top1 = real_bg[real_bg >= int(n_all * 0.5)][:bg_num_1]
+            topk = torch.cat([fg_inds, top0, top1], dim=0)
+            RCNN_loss_cls = F.cross_entropy(cls_score_all[topk], rois_label[topk])
+        return rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox, rois_label

@@ -1,0 +1,338 @@
+"""Tensor-level wrappers over the libdana_hip.so C ABI (include/dana_hip.h).
+
+PyTorch is used here only for device memory and streams: every function hands raw device pointers
+and the current HIP stream to a hand-written gfx950 kernel. Non-CUDA tensors are rejected -- there
+is no CPU fallback on the product path.
+"""
+import torch
+
+from ._lib import lib, DanaError  # noqa: F401
+
+NCHW, NHWC = 0, 1
+EPI_RELU, CONV_STEM7 = 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (HIP) tensor: this build has no CPU path" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# native operators of the reference's `model._C`
+# ------------------------------------------------------------------------------------------------
+def roi_align_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio):
+    """NCHW contract of lib/model/csrc/ROIAlign.h:11 (-> [R, C, PH, PW])."""
+    input = _chk(input.contiguous(), "input")
+    rois = _chk(rois.contiguous(), "rois")
+    B, C, H, W = input.shape
+    R = rois.shape[0]
+    out = torch.empty((R, C, pooled_h, pooled_w), dtype=input.dtype, device=input.device)
+    lib().call("dana_roi_align_forward", _p(input), _p(rois), _p(out), B, C, H, W, R, float(spatial_scale),
+               pooled_h, pooled_w, sampling_ratio, NCHW, 0, 0, None, None, 0, _stream())
+    return out
+
+
+def roi_align_forward_nhwc(feat, B, H, W, C, pix_stride, rois, spatial_scale, pooled, sampling_ratio, pe=None,
+                           out=None, out_pe=None, out_stride=0, out_pe_stride=0):
+    """NHWC fast path: feat is a flat buffer whose pixel (b,y,x) starts at ((b*H+y)*W+x)*pix_stride.
+    Returns pooled [R, P*P, C] (and pooled+pe written with row stride out_pe_stride when pe given)."""
+    _chk(feat, "feat")
+    rois = _chk(rois.contiguous(), "rois")
+    R = rois.shape[0]
+    P2 = pooled * pooled
+    if out is None:
+        out = torch.empty((R, P2, C), dtype=torch.float32, device=feat.device)
+        out_stride = C
+    if pe is not None and out_pe is None:
+        out_pe = torch.empty((R, P2, C), dtype=torch.float32, device=feat.device)
+        out_pe_stride = C
+    lib().call("dana_roi_align_forward", _p(feat), _p(rois), _p(out), B, C, H, W, R, float(spatial_scale), pooled,
+               pooled, sampling_ratio, NHWC, pix_stride, out_stride, _p(out_pe) if pe is not None else None,
+               _p(pe), out_pe_stride, _stream())
+    return out, out_pe
+
+
+def roi_align_backward(grad, rois, spatial_scale, pooled_h, pooled_w, batch, channels, height, width,
+                       sampling_ratio, layout=NCHW):
+    grad = _chk(grad.contiguous(), "grad")
+    rois = _chk(rois.contiguous(), "rois")
+    shape = (batch, channels, height, width) if layout == NCHW else (batch, height, width, channels)
+    gin = torch.empty(shape, dtype=grad.dtype, device=grad.device)
+    lib().call("dana_roi_align_backward", _p(grad), _p(rois), _p(gin), batch, channels, height, width,
+               rois.shape[0], float(spatial_scale), pooled_h, pooled_w, sampling_ratio, layout, _stream())
+    return gin
+
+
+def roi_pool_forward(input, rois, spatial_scale, pooled_h, pooled_w):
+    input = _chk(input.contiguous(), "input")
+    rois = _chk(rois.contiguous(), "rois")
+    B, C, H, W = input.shape
+    R = rois.shape[0]
+    out = torch.empty((R, C, pooled_h, pooled_w), dtype=input.dtype, device=input.device)
+    argmax = torch.empty((R, C, pooled_h, pooled_w), dtype=torch.int32, device=input.device)
+    lib().call("dana_roi_pool_forward", _p(input), _p(rois), _p(out), _p(argmax), B, C, H, W, R,
+               float(spatial_scale), pooled_h, pooled_w, _stream())
+    return out, argmax
+
+
+def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_h, pooled_w, batch, channels, height,
+                      width):
+    grad = _chk(grad.contiguous(), "grad")
+    rois = _chk(rois.contiguous(), "rois")
+    argmax = _chk(argmax.contiguous(), "argmax", torch.int32)
+    gin = torch.empty((batch, channels, height, width), dtype=grad.dtype, device=grad.device)
+    lib().call("dana_roi_pool_backward", _p(grad), _p(argmax), _p(rois), _p(gin), batch, channels, height, width,
+               rois.shape[0], pooled_h, pooled_w, _stream())
+    return gin
+
+
+def sort_desc(scores):
+    """scores [B, n] -> (order int32 [B, n], sorted scores) ; stable, descending."""
+    scores = _chk(scores.contiguous(), "scores")
+    B, n = scores.shape
+    order = torch.empty((B, n), dtype=torch.int32, device=scores.device)
+    sorted_scores = torch.empty_like(scores)
+    nbytes = lib().query("dana_sort_desc_workspace_bytes", B, n)
+    ws = _ws(nbytes, scores.device)
+    lib().call("dana_sort_desc", _p(scores), B, n, _p(order), _p(sorted_scores), _p(ws), ws.numel(), _stream())
+    return order, sorted_scores
+
+
+def nms_sorted(boxes, thr, inclusive=False, max_keep=0):
+    """boxes [P, n, 4] already in descending-score order -> (keep int32 [P, mk], num_keep int32 [P])."""
+    boxes = _chk(boxes.contiguous(), "boxes")
+    P, n, _ = boxes.shape
+    mk = n if (max_keep <= 0 or max_keep > n) else max_keep
+    keep = torch.empty((P, max(mk, 1)), dtype=torch.int32, device=boxes.device)
+    num = torch.empty((P,), dtype=torch.int32, device=boxes.device)
+    nbytes = lib().query("dana_nms_workspace_bytes", n, P)
+    ws = _ws(nbytes, boxes.device)
+    lib().call("dana_nms", _p(boxes), n, P, float(thr), int(bool(inclusive)), mk, _p(keep), max(mk, 1), _p(num),
+               _p(ws), ws.numel(), _stream())
+    return keep, num
+
+
+def nms(dets, scores, threshold, inclusive=False):
+    """Reference contract (lib/model/csrc/nms.h:10): dets [N,4], scores [N] -> kept ORIGINAL indices,
+    int64, ascending. The variable-length result needs one D2H read of the count (as the reference's
+    own host scan does); the fused proposal path (proposal_layer) has no host sync."""
+    if dets.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device="cpu")  # nms.h:17-18
+    dets = _chk(dets.contiguous(), "dets")
+    scores = _chk(scores.contiguous(), "scores")
+    order, _ = sort_desc(scores.view(1, -1))
+    boxes = dets[order[0].long()].contiguous().view(1, -1, 4)
+    keep, num = nms_sorted(boxes, threshold, inclusive)
+    k = int(num[0].item())
+    kept = order[0][keep[0, :k].long()].long()
+    return torch.sort(kept)[0]
+
+
+def proposal_layer(cls, cls_strides, cls_is_prob, bbox, bbox_strides, im_info, base_anchors, B, A, H, W,
+                   feat_stride, pre_nms_topn, post_nms_topn, nms_thresh, nms_inclusive=False):
+    """_ProposalLayer.forward (lib/model/rpn/proposal_layer.py:49-190) in one C call -> rois [B, post, 5]."""
+    _chk(cls, "cls")
+    _chk(bbox, "bbox")
+    im_info = _chk(im_info.contiguous(), "im_info")
+    base_anchors = _chk(base_anchors.contiguous(), "base_anchors")
+    rois = torch.empty((B, post_nms_topn, 5), dtype=torch.float32, device=cls.device)
+    nbytes = lib().query("dana_proposal_layer_workspace_bytes", B, A, H, W, pre_nms_topn, post_nms_topn)
+    ws = _ws(nbytes, cls.device)
+    lib().call("dana_proposal_layer", _p(cls), cls_strides[0], cls_strides[1], cls_strides[2], int(cls_is_prob),
+               _p(bbox), bbox_strides[0], bbox_strides[1], bbox_strides[2], _p(im_info), _p(base_anchors), B, A, H,
+               W, feat_stride, pre_nms_topn, post_nms_topn, float(nms_thresh), int(bool(nms_inclusive)), _p(rois),
+               _p(ws), ws.numel(), _stream())
+    return rois
+
+
+def rpn_decode(cls, cls_strides, cls_is_prob, bbox, bbox_strides, im_info, base_anchors, B, A, H, W, feat_stride):
+    _chk(cls, "cls")
+    _chk(bbox, "bbox")
+    n = H * W * A
+    proposals = torch.empty((B, n, 4), dtype=torch.float32, device=cls.device)
+    scores = torch.empty((B, n), dtype=torch.float32, device=cls.device)
+    lib().call("dana_rpn_decode", _p(cls), cls_strides[0], cls_strides[1], cls_strides[2], int(cls_is_prob),
+               _p(bbox), bbox_strides[0], bbox_strides[1], bbox_strides[2], _p(_chk(im_info.contiguous(), "im_info")),
+               _p(_chk(base_anchors.contiguous(), "base_anchors")), B, A, H, W, feat_stride, _p(proposals),
+               _p(scores), _stream())
+    return proposals, scores
+
+
+# ------------------------------------------------------------------------------------------------
+# dense contractions
+# ------------------------------------------------------------------------------------------------
+def conv2d_nhwc(x, batch, in_h, in_w, cin, weight, cout, kh, kw, stride, pad, scale=None, shift=None,
+                residual=None, relu=False, in_stride=0, out=None, out_stride=0, res_stride=0, stem=False):
+    """x: flat NHWC buffer; weight packed [cout][kh][kw][cin]. Returns (out, OH, OW)."""
+    _chk(x, "x")
+    _chk(weight, "weight")
+    oh = (in_h + 2 * pad - kh) // stride + 1
+    ow = (in_w + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((batch * oh * ow, cout), dtype=torch.float32, device=x.device)
+        out_stride = cout
+    flags = (EPI_RELU if relu else 0) | (CONV_STEM7 if stem else 0)
+    lib().call("dana_conv2d_nhwc", _p(x), _p(weight), _p(out), _p(scale), _p(shift), _p(residual), batch, in_h,
+               in_w, cin, cout, kh, kw, stride, pad, in_stride, out_stride, res_stride, flags, _stream())
+    return out, oh, ow
+
+
+def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None, residual=None, ldr=0, batch=1,
+            batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False):
+    """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous."""
+    _chk(a, "a")
+    _chk(b, "b")
+    lda = lda or k
+    ldb = ldb or k
+    if out is None:
+        out = torch.empty((batch, m, n) if batch > 1 else (m, n), dtype=torch.float32, device=a.device)
+        ldc = n
+        batch_c = m * n
+    lib().call("dana_gemm_nt", _p(a), _p(b), _p(out), _p(scale), _p(shift), _p(residual), m, n, k, lda, ldb, ldc,
+               ldr, batch, batch_a, batch_b, batch_c, float(alpha), EPI_RELU if relu else 0, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# layout / pooling / packing
+# ------------------------------------------------------------------------------------------------
+def nchw_to_nhwc(x, cpad=None, out=None, out_stride=0):
+    x = _chk(x.contiguous(), "x")
+    B, C, H, W = x.shape
+    cpad = cpad or C
+    if out is None:
+        out = torch.empty((B, H, W, cpad), dtype=torch.float32, device=x.device)
+    lib().call("dana_nchw_to_nhwc", _p(x), _p(out), B, C, H, W, cpad, out_stride, _stream())
+    return out
+
+
+def nhwc_to_nchw(x, B, C, H, W, in_stride=0):
+    _chk(x, "x")
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    lib().call("dana_nhwc_to_nchw", _p(x), _p(out), B, C, H, W, in_stride, _stream())
+    return out
+
+
+def maxpool3x3s2_ceil(x, B, H, W, C):
+    _chk(x, "x")
+    oh = (H - 3 + 1) // 2 + 1
+    ow = (W - 3 + 1) // 2 + 1
+    if (oh - 1) * 2 >= H:
+        oh -= 1
+    if (ow - 1) * 2 >= W:
+        ow -= 1
+    out = torch.empty((B * oh * ow, C), dtype=torch.float32, device=x.device)
+    lib().call("dana_maxpool3x3s2_ceil_nhwc", _p(x), _p(out), B, H, W, C, _stream())
+    return out, oh, ow
+
+
+def avgpool(x, B, H, W, C, k, stride):
+    _chk(x, "x")
+    oh, ow = (H - k) // stride + 1, (W - k) // stride + 1
+    out = torch.empty((B, oh * ow, C), dtype=torch.float32, device=x.device)
+    lib().call("dana_avgpool_nhwc", _p(x), _p(out), B, H, W, C, k, stride, _stream())
+    return out
+
+
+def spatial_mean(x, groups, positions, channels, in_stride=0):
+    _chk(x, "x")
+    out = torch.empty((groups, channels), dtype=torch.float32, device=x.device)
+    lib().call("dana_spatial_mean_nhwc", _p(x), _p(out), groups, positions, channels, in_stride, _stream())
+    return out
+
+
+def add_pe(x, pe, rows, length, channels, in_stride=0, out=None, out_stride=0):
+    _chk(x, "x")
+    _chk(pe, "pe")
+    if out is None:
+        out = torch.empty((rows, channels), dtype=torch.float32, device=x.device)
+    lib().call("dana_add_pe", _p(x), _p(pe), _p(out), rows, length, channels, in_stride, out_stride, _stream())
+    return out
+
+
+def colmean_sub_(x, groups, length, dim, ld=0):
+    _chk(x, "x")
+    lib().call("dana_colmean_sub", _p(x), groups, length, dim, ld, _stream())
+    return x
+
+
+def transpose_batched(x, groups, rows, cols, ldi=0, out=None, ldo=0, in_batch=0, out_batch=0):
+    _chk(x, "x")
+    ldi = ldi or cols
+    ldo = ldo or rows
+    in_batch = in_batch or rows * ldi
+    out_batch = out_batch or cols * ldo
+    if out is None:
+        out = torch.zeros((groups, cols, ldo), dtype=torch.float32, device=x.device)
+    lib().call("dana_transpose_batched", _p(x), _p(out), groups, rows, cols, ldi, ldo, in_batch, out_batch, _stream())
+    return out
+
+
+def pack_conv_weight(w, stem=False):
+    w = _chk(w.detach().contiguous(), "weight")
+    O, I, KH, KW = w.shape
+    out = torch.empty((O, 7 * 8 * 4) if stem else (O, KH * KW * I), dtype=torch.float32, device=w.device)
+    lib().call("dana_pack_conv_weight", _p(w), _p(out), O, I, KH, KW, int(stem), _stream())
+    return out
+
+
+def bn_fold(bn_weight, bn_bias, running_mean, running_var, eps):
+    n = bn_weight.numel()
+    scale = torch.empty((n,), dtype=torch.float32, device=bn_weight.device)
+    shift = torch.empty_like(scale)
+    lib().call("dana_bn_fold", _p(_chk(bn_weight.detach().contiguous(), "gamma")),
+               _p(_chk(bn_bias.detach().contiguous(), "beta")), _p(_chk(running_mean.contiguous(), "mean")),
+               _p(_chk(running_var.contiguous(), "var")), float(eps), _p(scale), _p(shift), n, _stream())
+    return scale, shift
+
+
+# ------------------------------------------------------------------------------------------------
+# attention reductions
+# ------------------------------------------------------------------------------------------------
+def rowdot(x, w, bias, rows, dim, ld=0):
+    _chk(x, "x")
+    out = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    lib().call("dana_rowdot", _p(x), _p(_chk(w.detach().contiguous(), "w")),
+               _p(_chk(bias.detach().contiguous(), "bias")) if bias is not None else None, _p(out), rows, dim, ld,
+               _stream())
+    return out
+
+
+def softmax_rows_(x, groups, length, ld=0):
+    _chk(x, "x")
+    lib().call("dana_softmax_rows", _p(x), groups, length, ld, _stream())
+    return x
+
+
+def ba_apply_(s, w, groups, length, dim, ld=0, gamma=0.1, slope=0.01):
+    _chk(s, "s")
+    _chk(w, "w")
+    lib().call("dana_ba_apply", _p(s), _p(w), groups, length, dim, ld, float(gamma), float(slope), _stream())
+    return s
+
+
+def attn_softmax_unary_(scores, unary, rows, rows_per_batch, nseg, length, ld, kpad, unary_gamma, out_scale,
+                        unary_batch_stride=0):
+    _chk(scores, "scores")
+    _chk(unary, "unary")
+    lib().call("dana_attn_softmax_unary", _p(scores), _p(unary), rows, rows_per_batch, unary_batch_stride, nseg, length,
+               ld, kpad,
+               float(unary_gamma), float(out_scale), _stream())
+    return scores

@@ -1,0 +1,170 @@
+/* libdana_hip.so -- C ABI of the MI355X (gfx950) DAnA forward hot path.
+ *
+ * Every entry point takes raw DEVICE pointers, explicit sizes/strides, scalars and a HIP stream
+ * (passed as void*); returns 0 on success or a negative DANA_ERR_* code, with the message
+ * available from dana_last_error() (thread-local). No entry point allocates device memory or
+ * synchronises with the host: scratch comes from the caller (`*_workspace_bytes`), launches go
+ * to the caller's stream, so the functions are re-entrant across threads/devices (the reference
+ * is driven from one Python thread per device under nn.DataParallel, train.py:104-105).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference
+ * repository root). INTEGRATION.md shows the binding a reference maintainer would add.
+ */
+#ifndef DANA_HIP_H
+#define DANA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dana_stream_t; /* hipStream_t */
+
+#define DANA_LAYOUT_NCHW 0
+#define DANA_LAYOUT_NHWC 1
+
+/* epilogue flags of dana_conv2d_nhwc / dana_gemm_nt */
+#define DANA_EPI_RELU 1
+#define DANA_CONV_STEM7 2 /* 7x7/2 stem over NHWC4 input, weight packed [cout][7][8][4] */
+
+const char* dana_last_error(void);
+int dana_abi_version(void);
+
+/* ---- native operators: lib/model/csrc/vision.cpp:7-13 (module `model._C`) ------------------- */
+
+/* ROIAlign_forward: lib/model/csrc/ROIAlign.h:11-25 -> cuda/ROIAlign_cuda.cu:257-305.
+ * rois[num_rois][5] = (batch_idx, x1, y1, x2, y2) in image pixels. layout NCHW: input
+ * [B][C][H][W] -> output [R][C][PH][PW] (the reference contract). layout NHWC: pixel (b,y,x) at
+ * input + ((b*H+y)*W+x)*in_pix_stride (stride 0 => C) -> output [R][PH*PW][out_pix_stride];
+ * optional output2 = output + add2[PH*PW][C] written in the same pass (fused positional
+ * encoding, dana.py:258-259). */
+int dana_roi_align_forward(const float* input, const float* rois, float* output, int batch, int channels,
+                           int height, int width, int num_rois, float spatial_scale, int pooled_h,
+                           int pooled_w, int sampling_ratio, int layout, long in_pix_stride,
+                           long out_pix_stride, float* output2, const float* add2, long out2_pix_stride,
+                           dana_stream_t stream);
+
+/* ROIAlign_backward: lib/model/csrc/ROIAlign.h:27-45 -> cuda/ROIAlign_cuda.cu:308-346.
+ * grad_in [B][C][H][W] (NCHW) or [B][H][W][C] (NHWC) is zero-filled here, then accumulated. */
+int dana_roi_align_backward(const float* grad_out, const float* rois, float* grad_in, int batch, int channels,
+                            int height, int width, int num_rois, float spatial_scale, int pooled_h,
+                            int pooled_w, int sampling_ratio, int layout, dana_stream_t stream);
+
+/* ROIPool_forward / ROIPool_backward: lib/model/csrc/ROIPool.h:11-46 -> cuda/ROIPool_cuda.cu:111-202. NCHW. */
+int dana_roi_pool_forward(const float* input, const float* rois, float* output, int* argmax, int batch,
+                          int channels, int height, int width, int num_rois, float spatial_scale, int pooled_h,
+                          int pooled_w, dana_stream_t stream);
+int dana_roi_pool_backward(const float* grad_out, const int* argmax, const float* rois, float* grad_in,
+                           int batch, int channels, int height, int width, int num_rois, int pooled_h,
+                           int pooled_w, dana_stream_t stream);
+
+/* nms: lib/model/csrc/nms.h:10-28 -> cuda/nms.cu:70-131 (nms_cuda) / cpu/nms_cpu.cpp:5-75.
+ * boxes[problems][n][4] must already be in descending-score order (the reference sorts inside
+ * nms_cuda, nms.cu:73-75; here the sort is dana_sort_desc). keep[p][0..num_keep[p]) receives
+ * the kept POSITIONS, ascending; at most max_keep (<=0: all). inclusive=0: suppress IoU > thr
+ * (nms.cu:60); inclusive=1: IoU >= thr (nms_cpu.cpp:60). */
+size_t dana_nms_workspace_bytes(int n, int problems);
+int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, int max_keep, int* keep,
+             int keep_stride, int* num_keep, void* workspace, size_t workspace_bytes, dana_stream_t stream);
+
+/* ---- RPN proposal path: lib/model/rpn/proposal_layer.py:49-190 ------------------------------- */
+
+/* Anchor grid + bbox_transform_inv (bbox_transform.py:77-103) + clip_boxes (:125-133) + fg score.
+ * cls element (b, ch, k=h*W+w) at cls + b*cls_sb + ch*cls_sc + k*cls_sp (2A channels: bg a, fg A+a);
+ * cls_is_prob=0 applies the pair softmax of rpn.py:67-69. bbox likewise with 4A channels.
+ * proposals[B][H*W*A][4], scores[B][H*W*A], index = k*A + a (proposal_layer.py:98-103). */
+int dana_rpn_decode(const float* cls, long cls_sb, long cls_sc, long cls_sp, int cls_is_prob, const float* bbox,
+                    long bbox_sb, long bbox_sc, long bbox_sp, const float* im_info, const float* base_anchors,
+                    int B, int A, int H, int W, int feat_stride, float* proposals, float* scores,
+                    dana_stream_t stream);
+
+/* torch.sort(scores, 1, True) (proposal_layer.py:135): stable, per row. sorted_scores may be NULL. */
+size_t dana_sort_desc_workspace_bytes(int B, int n);
+int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_scores, void* workspace,
+                   size_t workspace_bytes, dana_stream_t stream);
+
+/* proposals_single[order_single[:topn]] (proposal_layer.py:148-151) */
+int dana_gather_boxes(const float* src, const int* order, int B, int n, int order_stride, int topn, float* dst,
+                      dana_stream_t stream);
+
+/* output[i,:,0]=i; output[i,:num,1:]=kept boxes; zero padding (proposal_layer.py:136,183-188) */
+int dana_rois_assemble(const float* sorted_boxes, const int* keep, const int* num_keep, int B, int topn,
+                       int keep_stride, int post_n, float* rois, dana_stream_t stream);
+
+/* _ProposalLayer.forward as one call: decode -> sort -> top-N -> NMS -> rois[B][post_nms_topn][5]. */
+size_t dana_proposal_layer_workspace_bytes(int B, int A, int H, int W, int pre_nms_topn, int post_nms_topn);
+int dana_proposal_layer(const float* cls, long cls_sb, long cls_sc, long cls_sp, int cls_is_prob, const float* bbox,
+                        long bbox_sb, long bbox_sc, long bbox_sp, const float* im_info, const float* base_anchors,
+                        int B, int A, int H, int W, int feat_stride, int pre_nms_topn, int post_nms_topn,
+                        float nms_thresh, int nms_inclusive, float* rois, void* workspace, size_t workspace_bytes,
+                        dana_stream_t stream);
+
+/* ---- dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) --------------------- */
+
+/* nn.Conv2d + frozen BatchNorm2d/bias + residual + ReLU (resnet.py:66-102 Bottleneck, :109-112 stem;
+ * rpn.py:28,63 RPN_Conv). input NHWC [batch][in_h][in_w][in_pix_stride>=cin]; weight [cout][kh][kw][cin]
+ * (see dana_pack_conv_weight); out[m][n] = relu?( acc*scale[n] + shift[n] + residual[m][n] ) written
+ * with row stride out_pix_stride. scale/shift/residual may be NULL. cin % 32 == 0 unless STEM7. */
+int dana_conv2d_nhwc(const float* input, const float* weight, float* output, const float* scale,
+                     const float* shift, const float* residual, int batch, int in_h, int in_w, int cin,
+                     int cout, int kh, int kw, int stride, int pad, long in_pix_stride, long out_pix_stride,
+                     long res_pix_stride, int flags, dana_stream_t stream);
+
+/* nn.Linear / torch.bmm (dana.py:124,140,142,147,266-290): c[z][m][n] = epi(alpha * sum_k a[z][m][k]*b[z][n][k]).
+ * Both operands K-contiguous ("NT"); nn.Linear weights [out][in] are used as stored. k % 4 == 0. */
+int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, const float* shift,
+                 const float* residual, int m, int n, int k, long lda, long ldb, long ldc, long ldr, int batch,
+                 long batch_a, long batch_b, long batch_c, float alpha, int flags, dana_stream_t stream);
+
+/* ---- HBM-bound layout / pooling / packing kernels ---------------------------------------------- */
+
+/* boundary conversions between the reference's NCHW tensors and this build's NHWC activations */
+int dana_nchw_to_nhwc(const float* in, float* out, int batch, int channels, int height, int width, int cpad,
+                      long out_pix_stride, dana_stream_t stream);
+int dana_nhwc_to_nchw(const float* in, float* out, int batch, int channels, int height, int width,
+                      long in_pix_stride, dana_stream_t stream);
+/* nn.MaxPool2d(3, 2, padding=0, ceil_mode=True): resnet.py:113 */
+int dana_maxpool3x3s2_ceil_nhwc(const float* in, float* out, int batch, int height, int width, int channels,
+                                dana_stream_t stream);
+/* nn.AvgPool2d(14, stride=1) on the 20x20 support maps: dana.py:42,105-108 */
+int dana_avgpool_nhwc(const float* in, float* out, int batch, int height, int width, int channels, int k, int stride,
+                      dana_stream_t stream);
+/* RCNN_top(pool5).mean(3).mean(2): dana.py:387-389; in[groups][positions][stride] -> out[groups][channels] */
+int dana_spatial_mean_nhwc(const float* in, float* out, int groups, int positions, int channels, long in_pix_stride,
+                           dana_stream_t stream);
+/* PositionalEncoding.forward: dana.py:322-324; out[r] = in[r] + pe[r % length] */
+int dana_add_pe(const float* in, const float* pe, float* out, long rows, int length, int channels,
+                long in_stride, long out_stride, dana_stream_t stream);
+/* x - x.mean(1, keepdim=True): dana.py:125,141,267,272; x[groups][length][ld], in place */
+int dana_colmean_sub(float* x, int groups, int length, int dim, long ld, dana_stream_t stream);
+/* .transpose(1, 2).contiguous() of [groups][rows][cols] -> [groups][cols][ldo] */
+int dana_transpose_batched(const float* in, float* out, int groups, int rows, int cols, long ldi, long ldo,
+                           long in_batch, long out_batch, dana_stream_t stream);
+/* nn.Conv2d weight OIHW -> [O][KH][KW][I] (stem7: [O][7][8][4], zero padded) for dana_conv2d_nhwc */
+int dana_pack_conv_weight(const float* w_oihw, float* out, int cout, int cin, int kh, int kw, int stem7,
+                          dana_stream_t stream);
+/* eval-mode nn.BatchNorm2d (dana.py:362-385) -> scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
+int dana_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                 float* shift, int n, dana_stream_t stream);
+
+/* ---- BA block + CISA reductions: dana.py:133-147, 266-279 -------------------------------------- */
+
+/* nn.Linear(dim, 1): out[r] = x[r].w + bias[0] (rpn_unary_layer, rcnn_unary_layer, rpn_channel_k_layer) */
+int dana_rowdot(const float* x, const float* w, const float* bias, float* out, long rows, int dim, long ld,
+                dana_stream_t stream);
+/* F.softmax(x, last dim), in place, x[groups][length] */
+int dana_softmax_rows(float* x, long groups, int length, long ld, dana_stream_t stream);
+/* S += gamma * leaky_relu(w^T S): dana.py:136-137; s[groups][length][ld], w[groups][length] */
+int dana_ba_apply(float* s, const float* w, int groups, int length, int dim, long ld, float gamma, float slope,
+                  dana_stream_t stream);
+/* A = (softmax_keys(scores) + unary_gamma * unary^T) * out_scale per `length`-wide segment (one per shot):
+ * dana.py:143-146 / :274-278; unary + (row / rows_per_batch)*unary_batch_stride -> [nseg][length]; cols nseg*length..kpad-1 zeroed */
+int dana_attn_softmax_unary(float* scores, const float* unary, long rows, long rows_per_batch, long unary_batch_stride,
+                            int nseg, int length, long ld, int kpad, float unary_gamma, float out_scale,
+                            dana_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANA_HIP_H */

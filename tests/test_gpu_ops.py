@@ -1,0 +1,182 @@
+"""GPU parity of the native operators (through the C ABI) against the oracle and the reference's
+golden vectors. Bit-exact for index outputs and for RoIAlign / IoU arithmetic (kernels compiled
+with -ffp-contract=off); stated float tolerances elsewhere."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops.npz"))
+
+
+def _ops():
+    import dana_amd
+    return dana_amd.ops
+
+
+def _oracle():
+    from oracle import native
+    return native
+
+
+def test_roi_align_golden_nchw(G, dev):
+    ops = _ops()
+    feat, rois = torch.from_numpy(G["ra_feat"]).to(dev), torch.from_numpy(G["ra_rois"]).to(dev)
+    for sr, key in ((0, "ra_out_sr0"), (2, "ra_out_sr2")):
+        out = ops.roi_align_forward(feat, rois, 1.0 / 16, 7, 7, sr).cpu().numpy()
+        assert np.array_equal(out, G[key]), "RoIAlign NCHW differs from the reference golden (sr=%d)" % sr
+
+
+def test_roi_align_nhwc_matches_nchw_and_pe(G, dev):
+    ops = _ops()
+    feat = torch.from_numpy(G["ra_feat"]).to(dev)  # [2,8,38,63]
+    rois = torch.from_numpy(G["ra_rois"]).to(dev)
+    B, C, H, W = feat.shape
+    stride = 16  # channel block inside a wider pixel row, like base_feat inside the concat buffer
+    buf = torch.full((B * H * W, stride), 7.0, device=dev)
+    buf[:, :C] = feat.permute(0, 2, 3, 1).reshape(-1, C)
+    pe = torch.randn(49, C, device=dev)
+    pooled, pooled_pe = ops.roi_align_forward_nhwc(buf, B, H, W, C, stride, rois, 1.0 / 16, 7, 0, pe=pe)
+    ref = torch.from_numpy(G["ra_out_sr0"]).to(dev).permute(0, 2, 3, 1).reshape(-1, 49, C)
+    assert torch.equal(pooled, ref)
+    assert torch.equal(pooled_pe, ref + pe.unsqueeze(0))
+
+
+def test_roi_align_large_random_vs_oracle(dev):
+    ops, orc = _ops(), _oracle()
+    rng = np.random.default_rng(5)
+    feat = rng.normal(size=(2, 32, 38, 63)).astype(np.float32)
+    rois = np.zeros((300, 5), np.float32)
+    x1 = rng.uniform(-20, 990, 300); y1 = rng.uniform(-20, 590, 300)
+    rois[:, 0] = rng.integers(0, 2, 300)
+    rois[:, 1], rois[:, 2] = x1, y1
+    rois[:, 3], rois[:, 4] = x1 + rng.uniform(0, 500, 300), y1 + rng.uniform(0, 400, 300)
+    out = ops.roi_align_forward(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev), 1 / 16., 7, 7, 0)
+    assert np.array_equal(out.cpu().numpy(), orc.roi_align_forward(feat, rois, 1 / 16., 7, 7, 0))
+
+
+def test_roi_align_empty_and_cpu_raises(dev):
+    ops = _ops()
+    feat = torch.zeros(1, 4, 8, 8, device=dev)
+    out = ops.roi_align_forward(feat, torch.zeros(0, 5, device=dev), 1.0, 7, 7, 0)
+    assert out.shape == (0, 4, 7, 7)
+    with pytest.raises(RuntimeError):
+        ops.roi_align_forward(feat.cpu(), torch.zeros(1, 5), 1.0, 7, 7, 0)
+
+
+def test_roi_align_backward_matches_autograd_of_dense_formulation(dev):
+    """No reference CPU backward exists (ROIAlign.h:44); check against finite structure: the backward of
+    a linear op is its transpose, so <gout, fwd(x)> == <bwd(gout), x> for random x, gout."""
+    ops = _ops()
+    torch.manual_seed(0)
+    x = torch.randn(2, 6, 20, 30, device=dev)
+    rois = torch.tensor([[0, 10., 20., 200., 180.], [1, 0., 0., 479., 319.], [1, 100., 50., 130., 90.]], device=dev)
+    y = ops.roi_align_forward(x, rois, 1 / 16., 7, 7, 0)
+    g = torch.randn_like(y)
+    gx = ops.roi_align_backward(g, rois, 1 / 16., 7, 7, 2, 6, 20, 30, 0)
+    lhs, rhs = (g.double() * y.double()).sum().item(), (gx.double() * x.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_roi_pool_vs_oracle(dev):
+    ops, orc = _ops(), _oracle()
+    rng = np.random.default_rng(9)
+    feat = rng.normal(size=(2, 8, 38, 63)).astype(np.float32)
+    rois = np.zeros((64, 5), np.float32)
+    x1 = rng.uniform(0, 900, 64); y1 = rng.uniform(0, 500, 64)
+    rois[:, 0] = rng.integers(0, 2, 64)
+    rois[:, 1], rois[:, 2], rois[:, 3], rois[:, 4] = x1, y1, x1 + rng.uniform(0, 300, 64), y1 + rng.uniform(0, 300, 64)
+    out, arg = ops.roi_pool_forward(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev), 1 / 16., 7, 7)
+    o_ref, a_ref = orc.roi_pool_forward(feat, rois, 1 / 16., 7, 7)
+    assert np.array_equal(out.cpu().numpy(), o_ref) and np.array_equal(arg.cpu().numpy(), a_ref)
+    g = torch.randn_like(out)
+    gx = ops.roi_pool_backward(g, torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev), arg, 1 / 16., 7, 7,
+                               2, 8, 38, 63)
+    # scatter-add of g at argmax, done densely on the host
+    ref = np.zeros((2, 8, 38 * 63), np.float64)
+    gn, an = g.cpu().numpy(), arg.cpu().numpy()
+    for n in range(64):
+        b = int(rois[n, 0])
+        for c in range(8):
+            for p in range(49):
+                a = an[n, c].reshape(-1)[p]
+                if a >= 0:
+                    ref[b, c, a] += gn[n, c].reshape(-1)[p]
+    assert np.allclose(gx.cpu().numpy().reshape(2, 8, -1), ref, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag,thr", [("n256_t03", 0.3), ("n256_t07", 0.7), ("n2048_t07", 0.7)])
+def test_nms_golden(G, dev, tag, thr):
+    ops = _ops()
+    boxes, scores = torch.from_numpy(G["nms_%s_boxes" % tag]).to(dev), torch.from_numpy(G["nms_%s_scores" % tag]).to(dev)
+    keep_ge = ops.nms(boxes, scores, thr, inclusive=True).cpu().numpy()  # the reference CPU op's rule
+    assert np.array_equal(keep_ge, G["nms_%s_keep" % tag])
+    keep_gt = ops.nms(boxes, scores, thr, inclusive=False).cpu().numpy()  # the reference CUDA op's rule
+    assert np.array_equal(keep_gt, G["nms_%s_keep_gt" % tag])
+
+
+def test_nms_tie_and_empty(G, dev):
+    import dana_amd
+    ops = dana_amd.ops
+    b, s = torch.from_numpy(G["nms_tie_boxes"]).to(dev), torch.from_numpy(G["nms_tie_scores"]).to(dev)
+    assert list(ops.nms(b, s, 0.5, inclusive=True).cpu().numpy()) == list(G["nms_tie_keep_ge"])
+    assert list(dana_amd._C.nms(b, s, 0.5).cpu().numpy()) == [0, 1, 2]  # `>` keeps the exact tie (nms.cu:60)
+    e = dana_amd._C.nms(torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev), 0.5)
+    assert e.numel() == 0 and e.dtype == torch.int64
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 6000, 12000])
+def test_nms_sizes_vs_oracle(dev, n):
+    ops, orc = _ops(), _oracle()
+    rng = np.random.default_rng(n)
+    c = rng.uniform([0, 0], [1000, 600], size=(max(n // 10, 1), 2))
+    ctr = c[rng.integers(0, len(c), n)] + rng.normal(0, 10, size=(n, 2))
+    wh = rng.uniform(16, 300, size=(n, 2))
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    scores = rng.permutation(n).astype(np.float32)  # distinct -> unambiguous order
+    keep = ops.nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), 0.7).cpu().numpy()
+    assert np.array_equal(keep, orc.nms(boxes, scores, 0.7, inclusive=False))
+
+
+def test_nms_max_keep_truncates_in_order(dev):
+    ops, orc = _ops(), _oracle()
+    rng = np.random.default_rng(3)
+    n = 5000
+    ctr = rng.uniform([0, 0], [1000, 600], size=(n, 2))
+    wh = rng.uniform(16, 120, size=(n, 2))
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)  # already "sorted": index = rank
+    keep_all = orc.nms(boxes, -np.arange(n, dtype=np.float32), 0.7, inclusive=False)
+    keep, num = ops.nms_sorted(torch.from_numpy(boxes).to(dev).view(1, n, 4), 0.7, False, max_keep=300)
+    assert int(num[0]) == 300 and np.array_equal(keep[0].cpu().numpy(), keep_all[:300])
+
+
+def test_sort_desc_stable(dev):
+    ops = _ops()
+    rng = np.random.default_rng(0)
+    s = rng.uniform(size=(3, 28728)).astype(np.float32)
+    s[:, 100:200] = 0.5  # ties keep index order
+    order, ss = ops.sort_desc(torch.from_numpy(s).to(dev))
+    ref = np.argsort(-s, axis=1, kind="stable")
+    assert np.array_equal(order.cpu().numpy(), ref)
+    assert np.array_equal(ss.cpu().numpy(), np.take_along_axis(s, ref, 1))
+
+
+def test_decode_clip_golden(G, dev):
+    ops = _ops()
+    deltas = torch.from_numpy(G["dec_deltas"]).to(dev)  # [2, K*A, 4]
+    im_info = torch.from_numpy(G["dec_im_info"]).to(dev)
+    anchors = torch.from_numpy(G["anchors_a4"]).float().to(dev)
+    B, n, _ = deltas.shape
+    A, H, W = 12, 5, 7
+    cls = torch.zeros(B, n // A, 2 * A, device=dev)
+    bbox = deltas.reshape(B, H * W, A * 4).contiguous()
+    props, scores = ops.rpn_decode(cls, (H * W * 2 * A, 1, 2 * A), False, bbox, (H * W * 4 * A, 1, 4 * A), im_info, anchors,
+                                   B, A, H, W, 16)
+    assert np.allclose(props.cpu().numpy(), G["dec_out"], rtol=1e-5, atol=1e-3)  # expf vs torch.exp: few ulp
+    assert torch.allclose(scores, torch.full_like(scores, 0.5))
