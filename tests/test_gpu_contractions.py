@@ -1,0 +1,175 @@
+"""fp32 MFMA implicit-GEMM conv / GEMM and the small attention kernels vs a plain PyTorch fp32
+CPU reference of the same op. Tolerance: fp32 roundoff with a different summation order,
+|d| <= 2e-5 * sum|a*b| bound -> checked as rtol 1e-4 on the output scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import dana_amd
+    return dana_amd.ops
+
+
+def _close(a, b, tol=1e-4):
+    a, b = a.double(), b.double()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+CONV_CASES = [
+    # (N, H, W, Cin, Cout, k, stride, pad, relu, residual)
+    (2, 19, 23, 64, 64, 1, 1, 0, True, False),
+    (2, 19, 23, 64, 256, 1, 1, 0, True, True),
+    (1, 38, 63, 256, 256, 3, 1, 1, True, False),
+    (2, 37, 25, 256, 128, 1, 2, 0, True, False),     # strided 1x1 (Caffe bottleneck, resnet.py:71)
+    (3, 7, 7, 1024, 512, 1, 2, 0, True, False),      # layer4 entry on pooled RoIs 7x7 -> 4x4
+    (1, 12, 16, 2048, 512, 3, 1, 1, True, False),    # RPN conv (bias + relu)
+    (2, 20, 20, 512, 1024, 1, 1, 0, False, False),   # downsample-like (no relu)
+    (1, 9, 11, 128, 96, 3, 1, 1, False, True),       # N not a tile multiple
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_nhwc_vs_torch(dev, case):
+    ops = _ops()
+    N, H, W, Cin, Cout, k, stride, pad, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = torch.randn_like(ref) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    xd = ops.nchw_to_nhwc(x.to(dev))
+    wp = ops.pack_conv_weight(w.to(dev))
+    resd = ops.nchw_to_nhwc(res.to(dev)).view(-1, Cout) if use_res else None
+    out, oh, ow = ops.conv2d_nhwc(xd, N, H, W, Cin, wp, Cout, k, k, stride, pad, scale=scale.to(dev),
+                                  shift=shift.to(dev), residual=resd, relu=relu)
+    got = ops.nhwc_to_nchw(out, N, Cout, oh, ow).cpu()
+    assert got.shape == ref.shape
+    _close(got, ref)
+
+
+def test_conv_strided_io_inside_concat_buffer(dev):
+    """input read with a pixel stride and output written with a row stride (concat-buffer fusion)"""
+    ops = _ops()
+    torch.manual_seed(1)
+    N, H, W, Cin, Cout = 1, 10, 13, 64, 96
+    x = torch.randn(N, Cin, H, W)
+    w = torch.randn(Cout, Cin, 1, 1) / 8
+    ref = F.conv2d(x, w)
+    buf = torch.full((N * H * W, 160), 3.0, device=dev)
+    buf[:, :Cin] = ops.nchw_to_nhwc(x.to(dev)).view(-1, Cin)
+    out = torch.full((N * H * W, 256), -5.0, device=dev)
+    ops.conv2d_nhwc(buf, N, H, W, Cin, ops.pack_conv_weight(w.to(dev)), Cout, 1, 1, 1, 0, in_stride=160,
+                    out=out.view(-1)[128:], out_stride=256)
+    _close(out[:, 128:128 + Cout].cpu(), ref.permute(0, 2, 3, 1).reshape(-1, Cout))
+    assert (out[:, :128] == -5).all() and (out[:, 128 + Cout:] == -5).all()
+
+
+@pytest.mark.parametrize("hw", [(64, 80), (75, 75), (33, 47)])
+def test_stem_conv_and_ceil_maxpool_vs_torch(dev, hw):
+    """7x7/2 stem on NHWC4 + BN + ReLU, then MaxPool2d(3,2,0,ceil_mode=True) (resnet.py:109-113)"""
+    ops = _ops()
+    H, W = hw
+    torch.manual_seed(2)
+    x = torch.randn(2, 3, H, W) * 64
+    w = torch.randn(64, 3, 7, 7) * 0.025
+    scale, shift = torch.rand(64) * 0.05 + 0.02, torch.randn(64) * 0.1
+    y = F.relu(F.conv2d(x, w, stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref = F.max_pool2d(y, 3, 2, 0, ceil_mode=True)
+    x4 = ops.nchw_to_nhwc(x.to(dev), cpad=4)
+    wp = ops.pack_conv_weight(w.to(dev), stem=True)
+    o, oh, ow = ops.conv2d_nhwc(x4, 2, H, W, 4, wp, 64, 7, 7, 2, 3, scale=scale.to(dev), shift=shift.to(dev),
+                                relu=True, stem=True)
+    _close(ops.nhwc_to_nchw(o, 2, 64, oh, ow).cpu(), y)
+    p, ph, pw = ops.maxpool3x3s2_ceil(o, 2, oh, ow, 64)
+    assert (ph, pw) == tuple(ref.shape[2:])
+    _close(ops.nhwc_to_nchw(p, 2, 64, ph, pw).cpu(), ref)
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 256, 1024), (2394, 1200, 256), (77, 2, 1024), (128, 1024, 3136),
+                                   (513, 1024, 1200), (49, 147, 256), (1, 4, 2048)])
+def test_gemm_nt_vs_torch(dev, m, n, k):
+    ops = _ops()
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g)
+    bias = torch.randn(n, generator=g)
+    ref = (a.double() @ b.double().t()) * 0.125 + bias.double()
+    out = ops.gemm_nt(a.to(dev), b.to(dev), m, n, k, shift=bias.to(dev), alpha=0.125)
+    _close(out.cpu(), ref, 2e-5)
+
+
+def test_gemm_nt_batched_strided(dev):
+    ops = _ops()
+    torch.manual_seed(4)
+    B, m, n, k = 3, 130, 147, 256
+    a, b = torch.randn(B, m, k), torch.randn(B, 2 * n, k)  # use the second half of each b batch
+    ref = torch.bmm(a.double(), b[:, n:].double().transpose(1, 2)) / 16
+    out = torch.zeros(B, m, 160, device=dev)
+    bd = b.to(dev)
+    ops.gemm_nt(a.to(dev), bd.view(-1)[n * k:], m, n, k, out=out, ldc=160, batch=B, batch_a=m * k, batch_b=2 * n * k,
+                batch_c=m * 160, alpha=1 / 16)
+    _close(out[:, :, :n].cpu(), ref, 2e-5)
+    assert (out[:, :, n:] == 0).all()
+
+
+def test_attention_small_kernels_vs_torch(dev):
+    ops = _ops()
+    torch.manual_seed(5)
+    G_, L, D = 6, 400, 1024
+    s = torch.randn(G_, L, D)
+    w, b = torch.randn(1, D) * 0.03, torch.randn(1) * 0.1
+    pe = torch.randn(L, D)
+    sd = ops.add_pe(s.to(dev), pe.to(dev), G_ * L, L, D).view(G_, L, D)
+    s_pe = s + pe
+    assert torch.equal(sd.cpu(), s_pe)
+    logits = ops.rowdot(sd, w.to(dev), b.to(dev), G_ * L, D)
+    ref_logits = F.linear(s_pe, w, b).squeeze(-1)
+    _close(logits.view(G_, L).cpu(), ref_logits, 2e-5)
+    sm = ops.softmax_rows_(logits.clone(), G_, L).view(G_, L)
+    ref_sm = F.softmax(ref_logits, 1)
+    assert torch.allclose(sm.cpu(), ref_sm, rtol=1e-4, atol=1e-7)
+    # BA block (dana.py:134-137)
+    g = torch.bmm(ref_sm.unsqueeze(1), s_pe)
+    ref_ba = s_pe + 0.1 * F.leaky_relu(g)
+    ba = ops.ba_apply_(sd.clone(), sm.contiguous(), G_, L, D)
+    _close(ba.cpu(), ref_ba, 1e-5)
+    # zero-mean over positions (dana.py:125)
+    q = torch.randn(2, 777, 256)
+    qd = ops.colmean_sub_(q.to(dev).clone(), 2, 777, 256)
+    _close(qd.cpu(), q - q.mean(1, keepdim=True), 1e-5)
+    # softmax + unary + 1/shot over per-shot segments (dana.py:143-146,150)
+    rows, nseg, Ls = 50, 3, 49
+    sc = torch.randn(2, rows, 160)
+    un = F.softmax(torch.randn(2, 2 * nseg, Ls), 2)  # way=2 layout: use the second `nseg` block of each batch
+    ref = torch.cat([(F.softmax(sc[:, :, i * Ls:(i + 1) * Ls], 2) + 0.1 * un[:, nseg + i].unsqueeze(1)) / nseg
+                     for i in range(nseg)], 2)
+    scd = sc.to(dev).clone()
+    ops.attn_softmax_unary_(scd, un.to(dev).view(-1)[nseg * Ls:], 2 * rows, rows, nseg, Ls, 160, 160, 0.1, 1.0 / nseg,
+                            unary_batch_stride=2 * nseg * Ls)
+    assert torch.allclose(scd[:, :, :nseg * Ls].cpu(), ref, rtol=1e-4, atol=1e-7)
+    assert (scd[:, :, nseg * Ls:] == 0).all()
+    # transpose with zero K padding, avgpool 14/1, spatial mean
+    t = ops.transpose_batched(sd[:2].contiguous(), 2, L, D, ldo=416)
+    assert torch.equal(t[:, :, :L].cpu(), s_pe[:2].transpose(1, 2)) and (t[:, :, L:] == 0).all()
+    f = torch.randn(3, 1024, 20, 20)
+    ap = ops.avgpool(ops.nchw_to_nhwc(f.to(dev)), 3, 20, 20, 1024, 14, 1)
+    _close(ap.view(3, 7, 7, 1024).permute(0, 3, 1, 2).cpu(), F.avg_pool2d(f, 14, 1), 1e-5)
+    y = torch.randn(5, 2048, 4, 4)
+    mean = ops.spatial_mean(ops.nchw_to_nhwc(y.to(dev)), 5, 16, 2048)
+    _close(mean.cpu(), y.mean(3).mean(2), 1e-5)
+    # frozen-BN fold
+    gam, bet, mu, var = torch.rand(64) + 0.5, torch.randn(64), torch.randn(64), torch.rand(64) + 0.5
+    sc_, sh_ = ops.bn_fold(gam.to(dev), bet.to(dev), mu.to(dev), var.to(dev), 1e-5)
+    x = torch.randn(10, 64)
+    _close(x * sc_.cpu() + sh_.cpu(), F.batch_norm(x, mu, var, gam, bet, False, 0., 1e-5), 1e-5)

@@ -1,0 +1,128 @@
+"""End-to-end parity of the HIP DAnARCNN forward (module API -> C ABI -> gfx950 kernels) against the
+reference's golden vectors (tests/golden/e2e_*.npz, produced by running the reference itself) and
+against the oracle on fresh inputs.
+
+Tolerances (north_star: boxes within 1e-3 IoU, scores within 1e-4 of the reference):
+  continuous maps (base_feat, attended feature, RPN heads)  rel 2e-4 of the map's max |value|
+  rois (matched by position; scores are well separated)      IoU >= 1 - 1e-3 for >= 99% of rois
+  cls_prob on matched rois                                   |d| <= 1e-4 ; bbox_pred |d| <= 1e-4
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, tag):
+    return np.load(os.path.join(golden_dir, "e2e_%s.npz" % tag))
+
+
+def _build(meta, dev):
+    import dana_amd
+    from dana_amd import synthetic as S
+    use_ba, training, B, way, shot, H, W, wseed, iseed, nseed = [int(v) for v in meta]
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=bool(use_ba), way=way, shot=shot,
+                           classes=["fg", "bg"])
+    sd = S.fill_state_dict(m.state_dict(), seed=wseed, profile="test")
+    m.load_state_dict(sd)
+    m.to(dev)
+    m.nms_inclusive = True  # the golden vectors come from the reference's CPU path (nms_cpu.cpp:60: >=)
+    m.train() if training else m.eval()
+    inputs = S.episode_inputs(B, way if training else 1, shot, H, W, seed=iseed)
+    return m, sd, [t.to(dev) for t in inputs], inputs, (use_ba, training, B, way, shot, nseed)
+
+
+def _iou(a, b):
+    x1, y1 = np.maximum(a[:, 0], b[:, 0]), np.maximum(a[:, 1], b[:, 1])
+    x2, y2 = np.minimum(a[:, 2], b[:, 2]), np.minimum(a[:, 3], b[:, 3])
+    inter = np.clip(x2 - x1 + 1, 0, None) * np.clip(y2 - y1 + 1, 0, None)
+    aa = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1)
+    ab = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    return inter / (aa + ab - inter)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("tag", ["eval_small_cisa", "eval_small_ba", "eval_full_ba"])
+def test_eval_forward_matches_reference_golden(golden_dir, dev, tag):
+    import dana_amd
+    ops = dana_amd.ops
+    g = _load(golden_dir, tag)
+    m, sd, din, _, _ = _build(g["meta"], dev)
+    m._capture = {}
+    with torch.no_grad():
+        rois, cls_prob, bbox_pred, l1, l2, l3, l4, lab = m(*din)
+    assert (l1, l2, l3, l4, lab) == (0, 0, 0, 0, None)  # dana.py:173-178,217-218
+    corr, B, fh, fw = m._capture["corr"]
+    corr_nchw = ops.nhwc_to_nchw(corr, B, 2048, fh, fw).cpu().numpy()
+    assert _rel(corr_nchw[:, :1024][:, ::16], g["base_feat_s"]) < 2e-4
+    assert _rel(corr_nchw[:, 1024:][:, ::16], g["dense_s"]) < 2e-4
+    heads = m._capture["rpn_heads"].view(B, fh, fw, 72).permute(0, 3, 1, 2).cpu().numpy()
+    assert _rel(heads[:, :24], g["rpn_cls_score"]) < 2e-4
+    assert _rel(heads[:, 24:], g["rpn_bbox_pred"]) < 2e-4
+    r, rg = rois.cpu().numpy().reshape(-1, 5), g["rois"].reshape(-1, 5)
+    assert r.shape == rg.shape and np.array_equal(r[:, 0], rg[:, 0])
+    iou = _iou(r[:, 1:], rg[:, 1:])
+    matched = iou >= 1 - 1e-3
+    assert matched.mean() >= 0.99, "only %.1f%% of rois match the reference by position" % (100 * matched.mean())
+    assert np.abs(cls_prob.cpu().numpy() - g["cls_prob"])[matched].max() <= 1e-4
+    assert np.abs(bbox_pred.cpu().numpy() - g["bbox_pred"])[matched].max() <= 1e-4
+
+
+def test_train_forward_matches_reference_golden(golden_dir, dev):
+    g = _load(golden_dir, "train_small_ba")
+    m, sd, din, _, (use_ba, training, B, way, shot, nseed) = _build(g["meta"], dev)
+    np.random.seed(nseed)
+    with torch.no_grad():
+        rois, cls_prob, bbox_pred, l1, l2, l3, l4, lab = m(*din)
+    r, rg = rois.cpu().numpy().reshape(-1, 5), g["rois"].reshape(-1, 5)
+    assert r.shape == rg.shape
+    iou = _iou(r[:, 1:], rg[:, 1:])
+    matched = iou >= 1 - 1e-3
+    assert matched.mean() >= 0.97, "sampled rois diverge from the reference: %.1f%% match" % (100 * matched.mean())
+    if matched.all():  # same sampled set -> every downstream number must agree
+        assert np.array_equal(lab.cpu().numpy(), g["rois_label"])
+        m2 = np.concatenate([matched, matched])
+        assert np.abs(cls_prob.cpu().numpy() - g["cls_prob"])[m2].max() <= 1e-4
+        assert np.abs(bbox_pred.cpu().numpy() - g["bbox_pred"]).max() <= 1e-4
+        for name, v in (("rpn_loss_cls", l1), ("rpn_loss_bbox", l2), ("RCNN_loss_cls", l3), ("RCNN_loss_bbox", l4)):
+            assert abs(float(v) - float(g[name])) <= 1e-4 * max(1.0, abs(float(g[name]))), name
+
+
+def test_eval_forward_vs_oracle_fresh_inputs_cuda_nms_rule(dev):
+    """fresh seed, B=2, the shipped `>` NMS rule; oracle switched to the same rule"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    from oracle import model_ref as O
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=2, shot=2, classes=["fg", "bg"])
+    sd = S.fill_state_dict(m.state_dict(), seed=3, profile="test")
+    m.load_state_dict(sd)
+    m.to(dev).eval()
+    inputs = S.episode_inputs(2, 1, 2, 160, 224, seed=77)
+    with torch.no_grad():
+        out = m(*[t.to(dev) for t in inputs])
+        ref = O.forward(sd, *inputs, False, 1, 2, True, nms_inclusive=False)
+    r, rg = out[0].cpu().numpy().reshape(-1, 5), ref[0].numpy().reshape(-1, 5)
+    matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
+    assert matched.mean() >= 0.99
+    assert np.abs(out[1].cpu().numpy() - ref[1].numpy())[matched].max() <= 1e-4
+    assert np.abs(out[2].cpu().numpy() - ref[2].numpy())[matched].max() <= 1e-4
+
+
+def test_model_rejects_cpu_and_bad_supports(dev):
+    import dana_amd
+    from dana_amd import synthetic as S
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=1, shot=1, classes=["fg", "bg"])
+    m.eval()
+    inputs = S.episode_inputs(1, 1, 1, 96, 128, seed=1)
+    with pytest.raises(RuntimeError):
+        m(*inputs)  # CPU: no fallback
+    m.to(dev)
+    bad = S.episode_inputs(1, 1, 1, 96, 128, seed=1, support_size=224)
+    with pytest.raises(RuntimeError, match="320x320"):
+        m(*[t.to(dev) for t in bad])
