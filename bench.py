@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py -- DAnA forward hot path on MI355X (BASELINE.json metric: query-images/sec, res50,
+way=2 shot=3 bs=4). One process per GPU; a "step" is ONE pass of the hot path -- the train-mode
+DAnARCNN forward (trunk -> BA/CISA attention -> RPN -> proposals/NMS -> RoIAlign -> attention RCNN
+head -> losses) -- over one batch of 4 synthetic episodes (600x1000 query + way*shot 320x320
+supports; 320 because the reference hard-codes the 20x20 support map) that is
+already resident in HBM. Weak scaling: every rank runs its own 4 episodes, no data-path collective
+(episodes are independent).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel family = the fp32-MFMA implicit
+GEMM, timed live with HIP events on its launch stream) and, at N=1, `cpu_baseline` (the oracle
+port timed on the host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="episodes per GPU per step")
+    ap.add_argument("--way", type=int, default=2)
+    ap.add_argument("--shot", type=int, default=3)
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--width", type=int, default=1000)
+    ap.add_argument("--ba", action="store_true", help="full BA+CISA (configs[2]); default CISA only (configs[1])")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"], help="train-mode forward (default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", default="", help="write the per-launch igemm table to this file")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, sd):
+    """The oracle port (oracle/model_ref.py) on the host cores: ONE episode of the same workload."""
+    from dana_amd import synthetic as S
+    from oracle import model_ref as O
+    cores = min(os.cpu_count() or 1, 64)  # torch-CPU convs stop scaling (and oversubscribe) beyond ~64 threads
+    torch.set_num_threads(cores)
+    way = args.way if args.mode == "train" else 1
+    inputs = S.episode_inputs(1, way, args.shot, args.height, args.width, seed=1996)
+    np.random.seed(3)
+    t0 = time.time()
+    with torch.no_grad():
+        O.forward(sd, *inputs, args.mode == "train", way, args.shot, args.ba, nms_inclusive=False)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "query-images/sec", "cores": cores, "kind": "port",
+            "sample": "1 episode (1 query %dx%d + %d supports 320x320), %s-mode forward, oracle/model_ref.py on "
+                      "torch-CPU fp32 with %d threads, %.1f s" % (args.height, args.width, way * args.shot,
+                                                                 args.mode, cores, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import dana_amd
+    from dana_amd import ops, synthetic as S
+    training = args.mode == "train"
+    way = args.way if training else 1
+    model = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=args.ba, way=args.way, shot=args.shot,
+                               classes=["fg", "bg"])
+    sd = S.fill_state_dict(model.state_dict(), seed=11, profile="test")  # random init, O(1) activations
+    model.load_state_dict(sd)
+    model.to(dev)
+    model.train() if training else model.eval()
+    # every rank gets its own episodes (weak scaling), already resident in HBM before the timed region
+    inputs = [t.to(dev) for t in S.episode_inputs(args.batch, way, args.shot, args.height, args.width,
+                                                  seed=1996 + rank)]
+
+    def step():
+        with torch.no_grad():
+            return model(*inputs)
+
+    np.random.seed(1996 + rank)
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = {
+        "metric": "query-images/sec (res50, way=%d, shot=%d, bs=%d per GPU, %s-mode forward)" % (
+            args.way, args.shot, args.batch, args.mode),
+        "value": round(world * args.batch * args.steps / dt, 3),
+        "unit": "query-images/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * dt / args.steps, 3),
+        "ms_per_episode": round(1000.0 * dt / args.steps / args.batch, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (seeded N(0,64^2) query/support pixels, 3 gt boxes/image, random-init weights)",
+        "config": {"workload": "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d 320x320 "
+                               "supports/episode, %s, %s-mode forward" % (
+                                   2 if args.ba else 1, args.way, args.shot, args.batch, args.height, args.width,
+                                   way * args.shot, "BA+CISA" if args.ba else "CISA only", args.mode),
+                   "global_batch": world * args.batch, "parallelism": "episodes sharded, %d rank(s)" % world},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel family: igemm_f32_kernel (every conv / Linear / bmm). Same K steps, each launch
+        # bracketed by HIP events recorded on the stream the kernel is launched on (torch's current stream).
+        ops.PROFILE = []
+        torch.cuda.synchronize()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        flops = sum(p[1] for p in prof)
+        ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+        launches = len(prof) // args.steps
+        achieved = flops / (ms * 1e-3) / 1e12
+        by = {}
+        for tag, f, e0, e1 in prof:
+            a = by.setdefault(tag.split(" ")[0], [0.0, 0.0, 0])
+            a[0] += f
+            a[1] += e0.elapsed_time(e1)
+            a[2] += 1
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "igemm_f32_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)",
+            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": launches,
+            "algorithmic_gflop_per_step": round(flops / args.steps / 1e9, 1),
+            "kernel_ms_per_step": round(ms / args.steps, 3),
+            "by_kind_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in by.items()},
+            "whole_step_tflops": round(flops / args.steps / (dt / args.steps) / 1e12, 2),
+        }
+        if args.dump_launches:
+            per = {}
+            for i, (tag, f, e0, e1) in enumerate(prof):
+                a = per.setdefault((i % launches, tag), [f, 0.0])
+                a[1] += e0.elapsed_time(e1) / args.steps
+            with open(args.dump_launches, "w") as fh:
+                for (i, tag), (f, t) in sorted(per.items()):
+                    fh.write("%3d %-40s %9.2f GF %9.1f us %7.2f TF/s\n" % (i, tag, f / 1e9, t * 1e3, f / t / 1e9))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, sd)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,23 +11,32 @@
 // Data layout in HBM: activations NHWC (pixel-major, channel-minor; `lda` floats between pixels so
 // a tensor can live inside a wider concat buffer), weights [N][K] with k = (kh, kw, cin) cin-minor.
 // Both MFMA operands are therefore "rows with K contiguous": A rows are gathered pixels (implicit
-// im2col with zero fill for padding), B rows are filters. Epilogue fuses frozen-BN scale/shift or
-// bias, residual add and ReLU (resnet.py:84-100), and writes with row stride `ldc` so producers can
-// write straight into concat buffers (dana.py:153-154 torch.cat eliminated).
+// im2col), B rows are filters. Epilogue fuses frozen-BN scale/shift or bias, residual add and ReLU
+// (resnet.py:84-100) and writes with row stride `ldc` so producers can write straight into concat
+// buffers (dana.py:153-154 torch.cat eliminated).
 //
-// Tiling (wave64, 4 waves as 2x2): block BMxBNx32, wave tile (BM/2)x(BN/2) made of 32x32 MFMA tiles.
-// LDS rows are padded to 36 dwords: the ds_read_b128 fragment reads (16-lane groups, distinct rows)
-// and the 8-lane ds_write_b128 staging writes are both bank-conflict-free. K is consumed 8 at a
-// time per lane-half: lane (i, h) holds k = 8c+4h .. 8c+4h+3 of row i for BOTH operands, so MFMA
-// step s multiplies the k-pair {8c+s, 8c+4+s}; any pairing is valid because A and B agree.
-// Pipeline: global->register prefetch of tile t+1 is issued before the MFMAs of tile t, written
-// to the other LDS buffer after them; one barrier per K-step. The 64-cycle f32 MFMA hides the rest.
+// Kernel structure (wave64, 4 waves as 2x2; block BM x BN x 32; wave tile = 32x32 MFMA tiles):
+//  * staging loads are BRANCH-FREE buffer loads (buffer_load_dwordx4 with a raw SRD): padding taps,
+//    rows >= M, filters >= N and the K tail all become an out-of-range offset, which the hardware
+//    returns as zeros. Per row the thread keeps one 32-bit byte offset and a 64-bit tap-validity
+//    mask computed once; a K-step adds a wave-uniform tap delta. No exec-mask branches, no 64-bit
+//    address math in the loop, so hipcc can interleave the loads with the MFMAs.
+//  * LDS rows are padded to 36 dwords: the ds_read_b128 fragment reads (16-lane groups, distinct
+//    rows) and the 8-lane ds_write_b128 staging writes are bank-conflict-free. Lane (i, h) holds
+//    k = 8c+4h..8c+4h+3 of row i for BOTH operands, so MFMA step s multiplies the k-pair
+//    {8c+s, 8c+4+s}; any pairing is valid because A and B agree.
+//  * pipeline: global->register prefetch of tile t+1 is issued before the MFMAs of tile t and
+//    written to the other LDS buffer after them; one barrier per K-step.
+//  * epilogue: accumulators go through LDS (the staging buffers are dead by then) so that each
+//    thread finishes 4 consecutive channels of one pixel: float4 scale/shift, float4 residual
+//    load, float4 store -- whole 256/512-byte rows per wave instead of 4-byte scattered stores.
 #include "common.h"
 #include "../../include/dana_hip.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmParams {
   const float* A;
@@ -38,15 +47,19 @@ struct IgemmParams {
   const float* residual;  // [M][ldr] or null
   int M, N, K;
   int IH, IW, OH, OW, Cin, KH, KW, stride, pad;
-  long lda, ldb, ldc, ldr;
+  int lda, ldb;           // floats
+  long ldc, ldr;
   long batch_a, batch_b, batch_c;  // blockIdx.z strides (floats)
+  unsigned a_bytes, b_bytes;       // addressable span of one batch slice (buffer descriptor range)
   float alpha;
   int relu;
+  int vec_io;  // C / residual rows are 16-byte aligned -> float4 epilogue
   int tiles_m, tiles_n;
 };
 
 constexpr int BK = 32;
-constexpr int LDS_LD = 36;  // padded row, dwords
+constexpr int LDS_LD = 36;             // padded staging row, dwords
+constexpr unsigned OOB = 0x80000000u;  // > any descriptor range: the load returns zeros
 
 // bijective XCD-aware remap: consecutive tile ids land on the same XCD's L2 (guide T1)
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -55,13 +68,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
+__device__ __forceinline__ float4 ldg_b128(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return *(float4*)&v;
+}
+
 template <int BM, int BN, int STEM>
 __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
   constexpr int RA = BM / 32, RB = BN / 32;  // float4 loads per thread per K-step
+  constexpr int CLD = BN + 4;                // epilogue C-tile row, dwords
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                       // [2][BM][LDS_LD]
-  float* Bs = smem + 2 * BM * LDS_LD;     // [2][BN][LDS_LD]
+  float* As = smem;                    // [2][BM][LDS_LD]
+  float* Bs = smem + 2 * BM * LDS_LD;  // [2][BN][LDS_LD]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -74,60 +93,70 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   const float* Ab = p.A + (long)blockIdx.z * p.batch_a;
   const float* Bb = p.Bw + (long)blockIdx.z * p.batch_b;
   float* Cb = p.C + (long)blockIdx.z * p.batch_c;
+  const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)p.b_bytes, 0x00020000);
 
-  // ---- per-thread staging coordinates --------------------------------------------------------
-  const int c4 = tid & 7;    // which float4 of the 32-wide k chunk
-  const int r0 = tid >> 3;   // row within a 32-row slab
-  long a_pix[RA];            // pixel index of (img, 0, 0) for this row
-  int a_ih0[RA], a_iw0[RA];
-  bool a_ok[RA];
+  // ---- per-thread staging coordinates (computed once) -----------------------------------------
+  const int c4 = tid & 7;   // which float4 of the 32-wide k chunk
+  const int r0 = tid >> 3;  // row within a 32-row slab
+  unsigned a_off[RA];       // byte offset of (pixel at tap (0,0), channel c4*4)
+  unsigned long long a_mask[RA];  // bit t: tap t reads inside the image (and the row exists)
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int m = m0 + r0 + 32 * j;
-    a_ok[j] = m < p.M;
-    const int mm = a_ok[j] ? m : 0;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
     const int ohw = p.OH * p.OW;
-    const int img = mm / ohw, rem = mm % ohw;
-    const int oh = rem / p.OW, ow = rem % p.OW;
-    a_pix[j] = (long)img * p.IH * p.IW;
-    a_ih0[j] = oh * p.stride - p.pad;
-    a_iw0[j] = ow * p.stride - p.pad;
+    const int img = mm / ohw, rem = mm - img * ohw;
+    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+    const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+    unsigned long long mask = 0;
+    if (STEM) {
+      // chunk = filter row kh; this thread's float4 is tap kw = c4 (8th tap / 4th channel: zero weights)
+      const int iw = iw0 + c4;
+      if (ok && c4 < 7 && iw >= 0 && iw < p.IW)
+        for (int kh = 0; kh < 7; ++kh)
+          if (ih0 + kh >= 0 && ih0 + kh < p.IH) mask |= 1ull << kh;
+      a_off[j] = (unsigned)(((img * p.IH + ih0) * p.IW + iw) * 16);
+    } else {
+      if (ok)
+        for (int kh = 0; kh < p.KH; ++kh)
+          for (int kw = 0; kw < p.KW; ++kw)
+            if (ih0 + kh >= 0 && ih0 + kh < p.IH && iw0 + kw >= 0 && iw0 + kw < p.IW)
+              mask |= 1ull << (kh * p.KW + kw);
+      a_off[j] = (unsigned)((((img * p.IH + ih0) * p.IW + iw0) * p.lda + c4 * 4) * 4);
+    }
+    a_mask[j] = mask;
   }
-  const float* b_ptr[RB];
-  bool b_ok[RB];
+  unsigned b_off[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     const int n = n0 + r0 + 32 * j;
-    b_ok[j] = n < p.N;
-    b_ptr[j] = Bb + (long)(b_ok[j] ? n : 0) * p.ldb + c4 * 4;
+    b_off[j] = n < p.N ? (unsigned)((n * p.ldb + c4 * 4) * 4) : OOB;
   }
 
   float4 ra[RA], rb[RB];
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
     const bool kok = (k0 + c4 * 4) < p.K;
+    int tap;
+    unsigned delta;
     if (STEM) {
-      // chunk kt = filter row kh; float4 c4 = tap kw (8th tap and 4th channel are zero weights)
-#pragma unroll
-      for (int j = 0; j < RA; ++j) {
-        const int ih = a_ih0[j] + kt, iw = a_iw0[j] + c4;
-        const bool ok = a_ok[j] && c4 < 7 && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
-        ra[j] = ok ? *(const float4*)(Ab + (a_pix[j] + (long)ih * p.IW + iw) * 4) : make_float4(0, 0, 0, 0);
-      }
+      tap = kt;
+      delta = (unsigned)(kt * p.IW * 16);
     } else {
-      const int tap = k0 / p.Cin, cin0 = k0 - tap * p.Cin;
+      tap = k0 / p.Cin;
+      const int cin0 = k0 - tap * p.Cin;
       const int kh = tap / p.KW, kw = tap - kh * p.KW;
-#pragma unroll
-      for (int j = 0; j < RA; ++j) {
-        const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
-        const bool ok = a_ok[j] && kok && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
-        ra[j] = ok ? *(const float4*)(Ab + (a_pix[j] + (long)ih * p.IW + iw) * p.lda + cin0 + c4 * 4)
-                   : make_float4(0, 0, 0, 0);
-      }
+      delta = (unsigned)(((kh * p.IW + kw) * p.lda + cin0) * 4);
     }
 #pragma unroll
-    for (int j = 0; j < RB; ++j)
-      rb[j] = (b_ok[j] && kok) ? *(const float4*)(b_ptr[j] + k0) : make_float4(0, 0, 0, 0);
+    for (int j = 0; j < RA; ++j) {
+      const bool ok = kok && ((a_mask[j] >> tap) & 1ull);
+      ra[j] = ldg_b128(ra_src, ok ? a_off[j] + delta : OOB);
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) rb[j] = ldg_b128(rb_src, (kok && b_off[j] != OOB) ? b_off[j] + k0 * 4 : OOB);
   };
   auto store_tile = [&](int buf) {
     float* as = As + buf * BM * LDS_LD;
@@ -153,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight across the MFMAs below
+    if (kt + 1 < nk) load_tile(kt + 1);  // buffer loads in flight across the MFMAs below
     const float* as = As + buf * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + lh * 4;
     const float* bs = Bs + buf * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + lh * 4;
 #pragma unroll
@@ -177,29 +206,99 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------------
+  // ---- epilogue through LDS: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------
+  float* Cs = smem;  // [BM][CLD]; staging buffers are dead after the loop's last barrier
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / 2) + j * 32 + li;
-    const bool nok = n < p.N;
-    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
-    const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
+    for (int j = 0; j < TN; ++j) {
+      float* cw = Cs + (wm * (BM / 2) + i * 32 + 4 * lh) * CLD + wn * (BN / 2) + j * 32 + li;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (nok && m < p.M) {
-          float v = acc[i][j][r] * p.alpha;
-          v = v * sc + sh;
-          if (p.residual) v += p.residual[(long)m * p.ldr + n];
-          if (p.relu) v = fmaxf(v, 0.f);
-          Cb[(long)m * p.ldc + n] = v;
-        }
+      for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * CLD] = acc[i][j][r];
+    }
+  __syncthreads();
+  constexpr int TPR = BN / 4;        // threads per output row
+  constexpr int RPP = 256 / TPR;     // rows per pass
+  const int ec = (tid % TPR) * 4;    // this thread's 4 columns within the tile
+  const int er = tid / TPR;
+  const int n = n0 + ec;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool nok = (n + q) < p.N;
+    sc[q] = (nok && p.scale) ? p.scale[n + q] : 1.f;
+    sh[q] = (nok && p.shift) ? p.shift[n + q] : 0.f;
+  }
+  const bool full4 = p.vec_io && (n + 3) < p.N;
+#pragma unroll 4
+  for (int rr = er; rr < BM; rr += RPP) {
+    const int m = m0 + rr;
+    if (m >= p.M) break;
+    const float4 a4 = *(const float4*)(Cs + rr * CLD + ec);
+    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = v[q] * p.alpha * sc[q] + sh[q];
+    float* cp = Cb + (long)m * p.ldc + n;
+    if (full4) {
+      if (p.residual) {
+        const float4 r4 = *(const float4*)(p.residual + (long)m * p.ldr + n);
+        v[0] += r4.x;
+        v[1] += r4.y;
+        v[2] += r4.z;
+        v[3] += r4.w;
       }
+      if (p.relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+      }
+      *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if ((n + q) < p.N) {
+          float x = v[q];
+          if (p.residual) x += p.residual[(long)m * p.ldr + n + q];
+          if (p.relu) x = fmaxf(x, 0.f);
+          cp[q] = x;
+        }
     }
   }
+}
+
+// ---- skinny GEMM (N <= 8): one wave per output row, lanes split K (RCNN_bbox_pred 2048->4,
+// output_score_layer.linear2 1024->2: dana.py:246,304). HBM-bound on reading A once. ------------
+template <int NMAX>
+__global__ void __launch_bounds__(256)
+gemm_skinny_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c,
+                   const float* __restrict__ scale, const float* __restrict__ shift, int M, int N, int K, long lda,
+                   long ldb, long ldc, float alpha, int relu) {
+  const int lane = threadIdx.x & 63;
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float acc[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+  const float4* ar = (const float4*)(a + m * lda);
+  for (int k4 = lane; k4 < K / 4; k4 += 64) {
+    const float4 x = ar[k4];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+      if (n < N) {
+        const float4 w = ((const float4*)(b + n * ldb))[k4];
+        acc[n] += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+      }
+  }
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o);
+  }
+  if (lane == 0)
+    for (int n = 0; n < N; ++n) {
+      float v = acc[n] * alpha * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
+      if (relu) v = fmaxf(v, 0.f);
+      c[m * ldc + n] = v;
+    }
 }
 
 template <int BM, int BN, int STEM>
@@ -207,11 +306,13 @@ int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+  size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+  const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+  if (lds_c > lds) lds = lds_c;
   static bool attr_set = false;  // >64 KiB of dynamic LDS needs the opt-in once per process
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_f32_kernel<BM, BN, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
+    (void)hipFuncSetAttribute((const void*)igemm_f32_kernel<BM, BN, STEM>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
@@ -219,17 +320,29 @@ int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   return 0;
 }
 
+// Tile choice. The 64-cycle f32 MFMA hides staging for every tile shape (measured intrinsic rate of a
+// perfectly balanced launch: ~100 / 93 / 92 TF/s for 128x128 / 128x64 / 64x64), so what decides is
+// the TAIL: a CU finishes ceil(tiles/256) tiles while the average is tiles/256. Pick the shape that
+// maximises intrinsic * balance.
 int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   if (stem) return launch<128, 64, 1>(p, batch, s);
-  // tile choice: keep >= ~2 waves of workgroups over the 256 CUs when the problem allows it
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-  if (p.N <= 64) {
-    return launch<128, 64, 0>(p, batch, s);
-  }
-  if (t128 >= 384) return launch<128, 128, 0>(p, batch, s);
-  const long t12864 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64) * batch;
-  if (t12864 >= 384) return launch<128, 64, 0>(p, batch, s);
+  auto eff = [&](int bm, int bn, double intrinsic) {
+    if (bn == 128 && p.N <= 64) return 0.0;
+    const double tiles = (double)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch;
+    const double rounds = (double)((long)((tiles + 255) / 256));
+    const double useful = ((double)p.M / (((p.M + bm - 1) / bm) * bm)) * ((double)p.N / (((p.N + bn - 1) / bn) * bn));
+    return intrinsic * useful * tiles / (rounds * 256.0);
+  };
+  const double e128 = eff(128, 128, 1.00), e12864 = eff(128, 64, 0.94), e64 = eff(64, 64, 0.90);
+  if (e128 >= e12864 && e128 >= e64) return launch<128, 128, 0>(p, batch, s);
+  if (e12864 >= e64) return launch<128, 64, 0>(p, batch, s);
   return launch<64, 64, 0>(p, batch, s);
+}
+
+int run(IgemmParams& p, int batch, int stem, hipStream_t s) {
+  p.vec_io = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (p.batch_c % 4 == 0) &&
+             (!p.residual || ((p.ldr % 4 == 0) && (((uintptr_t)p.residual & 15) == 0)));
+  return dispatch(p, batch, stem, s);
 }
 
 }  // namespace
@@ -245,6 +358,7 @@ int dana_conv2d_nhwc(const float* input, const float* weight, float* output, con
                  "dana_conv2d_nhwc: bad shape");
   if (batch == 0) return DANA_OK;
   DANA_CHECK_ARG(input && weight && output, "dana_conv2d_nhwc: null pointer");
+  DANA_CHECK_ARG(kh * kw <= 64, "dana_conv2d_nhwc: at most 64 filter taps");
   const bool stem = (flags & DANA_CONV_STEM7) != 0;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -267,25 +381,32 @@ int dana_conv2d_nhwc(const float* input, const float* weight, float* output, con
   p.pad = pad;
   p.alpha = 1.f;
   p.relu = (flags & DANA_EPI_RELU) ? 1 : 0;
+  long lda;
   if (stem) {
     // input is NHWC4 (3 channels + zero pad), weight packed [cout][7][8][4] (K = 224)
     DANA_CHECK_ARG(kh == 7 && kw == 7 && cin == 4, "dana_conv2d_nhwc: STEM7 needs 7x7 over NHWC4");
     p.Cin = 4;
     p.K = 7 * 32;
-    p.lda = 4;
+    lda = 4;
   } else {
     DANA_CHECK_ARG(cin % BK == 0, "dana_conv2d_nhwc: cin=%d must be a multiple of %d", cin, BK);
     p.Cin = cin;
     p.K = kh * kw * cin;
-    p.lda = in_pix_stride > 0 ? in_pix_stride : cin;
-    DANA_CHECK_ARG(p.lda % 4 == 0, "dana_conv2d_nhwc: in_pix_stride %% 4 != 0");
+    lda = in_pix_stride > 0 ? in_pix_stride : cin;
+    DANA_CHECK_ARG(lda % 4 == 0 && lda >= cin, "dana_conv2d_nhwc: bad in_pix_stride");
   }
+  const long a_bytes = (long)batch * in_h * in_w * lda * 4, b_bytes = (long)cout * p.K * 4;
+  DANA_CHECK_ARG(a_bytes < (long)OOB && b_bytes < (long)OOB,
+                 "dana_conv2d_nhwc: operand spans >= 2 GiB are not addressable by one buffer descriptor; split the batch");
+  p.lda = (int)lda;
   p.ldb = p.K;
+  p.a_bytes = (unsigned)a_bytes;
+  p.b_bytes = (unsigned)b_bytes;
   p.ldc = out_pix_stride > 0 ? out_pix_stride : cout;
   p.ldr = res_pix_stride > 0 ? res_pix_stride : cout;
   DANA_CHECK_ARG(((uintptr_t)input & 15) == 0 && ((uintptr_t)weight & 15) == 0,
                  "dana_conv2d_nhwc: input/weight must be 16-byte aligned");
-  dispatch(p, 1, stem, (hipStream_t)stream);
+  run(p, 1, stem, (hipStream_t)stream);
   DANA_CHECK_LAUNCH("dana_conv2d_nhwc");
   return DANA_OK;
 }
@@ -298,8 +419,18 @@ int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, c
   DANA_CHECK_ARG(a && b && c, "dana_gemm_nt: null pointer");
   DANA_CHECK_ARG(k % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && batch_a % 4 == 0 && batch_b % 4 == 0,
                  "dana_gemm_nt: k, lda, ldb and batch strides must be multiples of 4 (16-byte rows)");
+  DANA_CHECK_ARG(lda >= k && ldb >= k && ldc >= n, "dana_gemm_nt: leading dimension smaller than the row");
   DANA_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "dana_gemm_nt: a/b must be 16-byte aligned");
   DANA_CHECK_ARG(!residual || batch == 1, "dana_gemm_nt: residual only with batch == 1");
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 8 && batch == 1 && !residual) {
+    gemm_skinny_kernel<8><<<dana_ceil_div(m, 4), 256, 0, s>>>(a, b, c, scale, shift, m, n, k, lda, ldb, ldc, alpha,
+                                                              (flags & DANA_EPI_RELU) ? 1 : 0);
+    DANA_CHECK_LAUNCH("dana_gemm_nt(skinny)");
+    return DANA_OK;
+  }
+  const long a_bytes = ((long)(m - 1) * lda + k) * 4, b_bytes = ((long)(n - 1) * ldb + k) * 4;
+  DANA_CHECK_ARG(a_bytes < (long)OOB && b_bytes < (long)OOB, "dana_gemm_nt: operand slice >= 2 GiB; split it");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.A = a;
@@ -320,8 +451,10 @@ int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, c
   p.KH = p.KW = 1;
   p.stride = 1;
   p.pad = 0;
-  p.lda = lda;
-  p.ldb = ldb;
+  p.lda = (int)lda;
+  p.ldb = (int)ldb;
+  p.a_bytes = (unsigned)a_bytes;
+  p.b_bytes = (unsigned)b_bytes;
   p.ldc = ldc;
   p.ldr = ldr > 0 ? ldr : ldc;
   p.batch_a = batch_a;
@@ -329,7 +462,7 @@ int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, c
   p.batch_c = batch_c;
   p.alpha = alpha;
   p.relu = (flags & DANA_EPI_RELU) ? 1 : 0;
-  dispatch(p, batch, 0, (hipStream_t)stream);
+  run(p, batch, 0, s);
   DANA_CHECK_LAUNCH("dana_gemm_nt");
   return DANA_OK;
 }

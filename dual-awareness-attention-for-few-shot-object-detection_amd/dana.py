@@ -438,7 +438,7 @@ class DAnARCNN(nn.Module):
                                     unary_batch_stride=way * shot * P2)
             st2 = ops.transpose_batched(sb, B, K2, 1024, ldi=1024, ldo=K2p, in_batch=way * shot * P2 * 1024)
             ops.gemm_nt(sc2, st2, R * P2, 1024, K2p, lda=K2p, ldb=K2p, out=cat.view(-1)[1024:], ldc=2048, batch=B,
-                        batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 2048)
+                        batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 2048, k_true=K2)
             tr = ops.gemm_nt(cat, wt, n_roi * P2, self.rcnn_dim, 2048, shift=bt_)  # [n*49][64] == [n][3136]
             hid = ops.gemm_nt(tr, w1, n_roi, w1.size(0), P2 * self.rcnn_dim, shift=b1, relu=True)
             score = ops.gemm_nt(hid, w2, n_roi, 2, w1.size(0), shift=b2)

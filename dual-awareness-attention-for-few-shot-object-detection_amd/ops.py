@@ -11,6 +11,25 @@ from ._lib import lib, DanaError  # noqa: F401
 NCHW, NHWC = 0, 1
 EPI_RELU, CONV_STEM7 = 1, 2
 
+# bench.py sets this to a list to time every MFMA contraction launch with HIP events recorded on the
+# stream the kernel is launched on; entries are (tag, algorithmic_flops, start_event, end_event).
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, tag, flops):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((tag, flops, e0, e1))
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -189,13 +208,17 @@ def conv2d_nhwc(x, batch, in_h, in_w, cin, weight, cout, kh, kw, stride, pad, sc
         out = torch.empty((batch * oh * ow, cout), dtype=torch.float32, device=x.device)
         out_stride = cout
     flags = (EPI_RELU if relu else 0) | (CONV_STEM7 if stem else 0)
+    e0 = _prof_begin()
     lib().call("dana_conv2d_nhwc", _p(x), _p(weight), _p(out), _p(scale), _p(shift), _p(residual), batch, in_h,
                in_w, cin, cout, kh, kw, stride, pad, in_stride, out_stride, res_stride, flags, _stream())
+    # algorithmic flops: the stem counts its 3 real channels x 49 real taps, not the padded K=224
+    _prof_end(e0, "conv%dx%d M=%d N=%d K=%d s%d" % (kh, kw, batch * oh * ow, cout, kh * kw * cin, stride),
+              2.0 * batch * oh * ow * cout * kh * kw * (3 if stem else cin))
     return out, oh, ow
 
 
 def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None, residual=None, ldr=0, batch=1,
-            batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False):
+            batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False, k_true=0):
     """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous."""
     _chk(a, "a")
     _chk(b, "b")
@@ -205,8 +228,10 @@ def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None
         out = torch.empty((batch, m, n) if batch > 1 else (m, n), dtype=torch.float32, device=a.device)
         ldc = n
         batch_c = m * n
+    e0 = _prof_begin()
     lib().call("dana_gemm_nt", _p(a), _p(b), _p(out), _p(scale), _p(shift), _p(residual), m, n, k, lda, ldb, ldc,
                ldr, batch, batch_a, batch_b, batch_c, float(alpha), EPI_RELU if relu else 0, _stream())
+    _prof_end(e0, "gemm M=%d N=%d K=%d b%d" % (m, n, k, batch), 2.0 * batch * m * n * (k_true or k))
     return out
 
 
