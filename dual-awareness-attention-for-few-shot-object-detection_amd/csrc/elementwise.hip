@@ -125,23 +125,37 @@ add_pe_kernel(const float4* __restrict__ in, const float4* __restrict__ pe, floa
   }
 }
 
-// x[g][l][d] -= mean_l x[g][l][d]; grid = (D/64 column slabs, G); block = 64 columns x 4 row lanes
+// x[g][l][d] -= mean_l x[g][l][d] in two passes over row chunks (fixed summation order, no atomics):
+// (1) partial[g][chunk][d] = sum of the chunk's rows; (2) every chunk re-adds the partials in chunk
+// order, divides by L and subtracts. grid = (D/64 column slabs, chunks, G); block = 64 cols x 4 row lanes.
+constexpr int CM_ROWS = 64;
 __global__ void __launch_bounds__(256)
-colmean_sub_kernel(float* __restrict__ x, int L, int D, long ld) {
+colmean_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int L, int D, long ld) {
   __shared__ float part[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
-  float* base = x + (long)blockIdx.y * L * ld;
+  const float* base = x + (long)blockIdx.z * L * ld;
+  const int l0 = blockIdx.y * CM_ROWS, l1 = min(L, l0 + CM_ROWS);
   float s = 0.f;
   if (col < D)
-    for (int l = rl; l < L; l += 4) s += base[(long)l * ld + col];
+    for (int l = l0 + rl; l < l1; l += 4) s += base[(long)l * ld + col];
   part[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  const float mean = (part[0][threadIdx.x & 63] + part[1][threadIdx.x & 63] + part[2][threadIdx.x & 63] +
-                      part[3][threadIdx.x & 63]) /
-                     (float)L;
-  if (col < D)
-    for (int l = rl; l < L; l += 4) base[(long)l * ld + col] -= mean;
+  if (rl == 0 && col < D)
+    partial[((long)blockIdx.z * gridDim.y + blockIdx.y) * D + col] =
+        (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(256)
+colmean_apply_kernel(float* __restrict__ x, const float* __restrict__ partial, int L, int D, long ld) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  if (col >= D) return;
+  float s = 0.f;
+  for (int c = 0; c < (int)gridDim.y; ++c) s += partial[((long)blockIdx.z * gridDim.y + c) * D + col];
+  const float mean = s / (float)L;
+  float* base = x + (long)blockIdx.z * L * ld;
+  const int l0 = blockIdx.y * CM_ROWS, l1 = min(L, l0 + CM_ROWS);
+  for (int l = l0 + rl; l < l1; l += 4) base[(long)l * ld + col] -= mean;
 }
 
 // batched transpose in[g][R][C] -> out[g][C][ldo] (32x32 LDS tiles); columns R..ldo-1 are left untouched
@@ -289,14 +303,28 @@ int dana_add_pe(const float* in, const float* pe, float* out, long rows, int len
   return DANA_OK;
 }
 
-int dana_colmean_sub(float* x, int groups, int length, int dim, long ld, dana_stream_t stream) {
+size_t dana_colmean_sub_workspace_bytes(int groups, int length, int dim) {
+  if (groups <= 0 || length <= 0 || dim <= 0) return 0;
+  return (size_t)groups * ((length + CM_ROWS - 1) / CM_ROWS) * dim * sizeof(float);
+}
+
+int dana_colmean_sub(float* x, int groups, int length, int dim, long ld, void* workspace, size_t workspace_bytes,
+                     dana_stream_t stream) {
   DANA_CHECK_ARG(groups >= 0 && length > 0 && dim > 0, "dana_colmean_sub: bad shape");
   if (groups == 0) return DANA_OK;
   DANA_CHECK_ARG(x, "dana_colmean_sub: null pointer");
   if (ld <= 0) ld = dim;
-  dim3 grid(dana_ceil_div(dim, 64), groups);
-  colmean_sub_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, length, dim, ld);
-  DANA_CHECK_LAUNCH("dana_colmean_sub");
+  const size_t need = dana_colmean_sub_workspace_bytes(groups, length, dim);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("dana_colmean_sub: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  dim3 grid(dana_ceil_div(dim, 64), dana_ceil_div(length, CM_ROWS), groups);
+  DANA_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "dana_colmean_sub: too many chunks/groups");
+  colmean_partial_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (float*)workspace, length, dim, ld);
+  DANA_CHECK_LAUNCH("dana_colmean_sub(partial)");
+  colmean_apply_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (const float*)workspace, length, dim, ld);
+  DANA_CHECK_LAUNCH("dana_colmean_sub(apply)");
   return DANA_OK;
 }
 

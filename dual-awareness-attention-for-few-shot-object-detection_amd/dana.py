@@ -307,6 +307,9 @@ class DAnARCNN(nn.Module):
         shot = self.n_shot
         way = self.n_way if training else 1  # eval reshapes supports as [*, n_shot] (dana.py:111)
         inter = getattr(self, "_capture", None)
+        if training:
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record()
 
         # -- feature extraction (dana.py:98-115) --
         corr, fh, fw = self._rcnn_base(im_data, plan, out_stride=2048)  # base_feat = corr[:, :1024]
@@ -368,17 +371,44 @@ class DAnARCNN(nn.Module):
             inter["rpn_heads"] = heads
             inter["rpn_rois"] = rois
 
+        # -- support-side half of the RoI-level CISA (dana.py:105-108,258,271-277): K / unary projections
+        #    once per support (the reference recomputes them for every RoI). Independent of the rois, so
+        #    they are queued here to keep the GPU busy while the host samples the training targets. --
+        P = cfg.POOLING_SIZE
+        P2 = P * P
+        dq = self.rcnn_reduce_dim
+        sp = ops.avgpool(sup, Ns, 20, 20, 1024, 14, 1)  # [Ns][49][1024]
+        sp_pe = ops.add_pe(sp, plan["pe49"], Ns * P2, P2, 1024)
+        wk2, bk2 = self._w(self.rcnn_adapt_k_layer)
+        k2 = ops.gemm_nt(sp_pe, wk2, Ns * P2, dq, 1024, shift=bk2)
+        ops.colmean_sub_(k2, Ns, P2, dq)
+        wu2, bu2 = self._w(self.rcnn_unary_layer)
+        un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
+        ops.softmax_rows_(un2, Ns, P2)
+
         rpn_loss_cls = rpn_loss_bbox = 0
         rois_label = None
         if training:
+            # anchor targets depend on the inputs only: they are computed on a side stream so that their
+            # host syncs (np.random needs the counts) never drain the main stream's kernel queue
+            main = torch.cuda.current_stream()
+            side = self._consts.get("side_stream")
+            if side is None:
+                side = self._consts["side_stream"] = torch.cuda.Stream(device=dev)
+            side.wait_event(inputs_ready)  # NOT wait_stream(main): the trunk is already queued there
+            with torch.cuda.stream(side):
+                labels, bt, biw, bow = T.anchor_target_layer(fh, fw, gt_boxes, im_info, plan["anchors"])
+                lab = labels.view(-1)
+                keep = lab.ne(-1).nonzero().view(-1)
+                lab_keep = lab[keep].long()
+            for t_ in (bt, biw, bow, keep, lab_keep):
+                t_.record_stream(main)
+            main.wait_stream(side)
             heads4 = heads.view(B, fh, fw, nh)
             rpn_cls_score = heads4[..., :rpn.nc_score_out].permute(0, 3, 1, 2)  # [B,2A,H,W] view
             rpn_bbox_pred = heads4[..., rpn.nc_score_out:].permute(0, 3, 1, 2)
-            labels, bt, biw, bow = T.anchor_target_layer(fh, fw, gt_boxes, im_info, plan["anchors"])
             sc = rpn_cls_score.reshape(B, 2, A * fh, fw).permute(0, 2, 3, 1).reshape(-1, 2)
-            lab = labels.view(-1)
-            keep = lab.ne(-1).nonzero().view(-1)
-            rpn_loss_cls = F.cross_entropy(sc[keep], lab[keep].long())
+            rpn_loss_cls = F.cross_entropy(sc[keep], lab_keep)
             rpn_loss_bbox = T._smooth_l1_loss(rpn_bbox_pred, bt, biw, bow, sigma=3, dim=[1, 2, 3])
             rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = T.proposal_target_layer(rois, gt_boxes)
             rois_label = rois_label.view(-1).long()
@@ -392,8 +422,6 @@ class DAnARCNN(nn.Module):
         if cfg.POOLING_MODE != "align":
             raise NotImplementedError("POOLING_MODE '%s': the DAnA recipe uses 'align' (cfgs/res50.yml:35)"
                                       % cfg.POOLING_MODE)
-        P = cfg.POOLING_SIZE
-        P2 = P * P
         cat = torch.empty((n_roi * P2, 2048), dtype=torch.float32, device=dev)  # [q+PE | attended] (dana.py:284)
         pooled, _ = ops.roi_align_forward_nhwc(corr, B, fh, fw, 1024, 2048, rois.view(-1, 5), 1.0 / 16.0, P, 0,
                                                pe=plan["pe49"], out_pe=cat, out_pe_stride=2048)
@@ -409,18 +437,9 @@ class DAnARCNN(nn.Module):
         bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
 
         # -- RoI-level CISA (dana.py:248-292); K / unary projections once per support (not per RoI) --
-        dq = self.rcnn_reduce_dim
         wq2, bq2 = self._w(self.rcnn_adapt_q_layer)
         q2 = ops.gemm_nt(cat, wq2, n_roi * P2, dq, 1024, lda=2048, shift=bq2)
         ops.colmean_sub_(q2, n_roi, P2, dq)
-        sp = ops.avgpool(sup, Ns, 20, 20, 1024, 14, 1)  # [Ns][49][1024]  (dana.py:105-108)
-        sp_pe = ops.add_pe(sp, plan["pe49"], Ns * P2, P2, 1024)
-        wk2, bk2 = self._w(self.rcnn_adapt_k_layer)
-        k2 = ops.gemm_nt(sp_pe, wk2, Ns * P2, dq, 1024, shift=bk2)
-        ops.colmean_sub_(k2, Ns, P2, dq)
-        wu2, bu2 = self._w(self.rcnn_unary_layer)
-        un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
-        ops.softmax_rows_(un2, Ns, P2)
         K2 = shot * P2
         K2p = (K2 + 31) // 32 * 32
         wt, bt_ = self._w(self.rcnn_transform_layer)

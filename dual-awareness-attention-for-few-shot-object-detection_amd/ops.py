@@ -294,7 +294,8 @@ def add_pe(x, pe, rows, length, channels, in_stride=0, out=None, out_stride=0):
 
 def colmean_sub_(x, groups, length, dim, ld=0):
     _chk(x, "x")
-    lib().call("dana_colmean_sub", _p(x), groups, length, dim, ld, _stream())
+    ws = _ws(lib().query("dana_colmean_sub_workspace_bytes", groups, length, dim), x.device)
+    lib().call("dana_colmean_sub", _p(x), groups, length, dim, ld, _p(ws), ws.numel(), _stream())
     return x
 
 

@@ -137,7 +137,9 @@ int dana_spatial_mean_nhwc(const float* in, float* out, int groups, int position
 int dana_add_pe(const float* in, const float* pe, float* out, long rows, int length, int channels,
                 long in_stride, long out_stride, dana_stream_t stream);
 /* x - x.mean(1, keepdim=True): dana.py:125,141,267,272; x[groups][length][ld], in place */
-int dana_colmean_sub(float* x, int groups, int length, int dim, long ld, dana_stream_t stream);
+size_t dana_colmean_sub_workspace_bytes(int groups, int length, int dim);
+int dana_colmean_sub(float* x, int groups, int length, int dim, long ld, void* workspace, size_t workspace_bytes,
+                     dana_stream_t stream);
 /* .transpose(1, 2).contiguous() of [groups][rows][cols] -> [groups][cols][ldo] */
 int dana_transpose_batched(const float* in, float* out, int groups, int rows, int cols, long ldi, long ldo,
                            long in_batch, long out_batch, dana_stream_t stream);
