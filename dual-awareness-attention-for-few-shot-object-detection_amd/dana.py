@@ -252,6 +252,13 @@ class DAnARCNN(nn.Module):
         self._plan = p
         return p
 
+    def _stream(self, name, dev):
+        key = ("stream", name, str(dev))
+        st = self._consts.get(key)
+        if st is None:
+            st = self._consts[key] = torch.cuda.Stream(device=dev)
+        return st
+
     @staticmethod
     def _w(layer):
         return layer.weight.detach().contiguous(), layer.bias.detach().contiguous()
@@ -307,49 +314,74 @@ class DAnARCNN(nn.Module):
         shot = self.n_shot
         way = self.n_way if training else 1  # eval reshapes supports as [*, n_shot] (dana.py:111)
         inter = getattr(self, "_capture", None)
-        if training:
-            inputs_ready = torch.cuda.Event()
-            inputs_ready.record()
+        main = torch.cuda.current_stream()
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record()
+        sup_stream = self._stream("support", dev)
 
-        # -- feature extraction (dana.py:98-115) --
-        corr, fh, fw = self._rcnn_base(im_data, plan, out_stride=2048)  # base_feat = corr[:, :1024]
-        hw = fh * fw
+        # -- feature extraction (dana.py:98-115). The support trunk and everything that depends only on
+        #    the supports run on their own stream, concurrently with the query trunk: each conv launch has
+        #    a tail (tiles/256 is rarely an integer) and the two streams fill each other's idle CUs. --
         sup_ims = support_ims.reshape(-1, support_ims.size(2), support_ims.size(3), support_ims.size(4))
-        sup, sh_, sw_ = self._rcnn_base(sup_ims, plan)  # [Ns*400][1024]
-        if (sh_, sw_) != (20, 20):
-            raise RuntimeError("support images must be 320x320 (20x20 stride-16 map), as the reference hard-codes "
-                               "(dana.py:105); got a %dx%d map" % (sh_, sw_))
         Ns = sup_ims.size(0)
         if Ns != B * way * shot:
             raise RuntimeError("support_ims must hold batch*way*shot = %d images, got %d" % (B * way * shot, Ns))
         L = 400
-
-        # -- RPN-level dual-awareness attention (dana.py:118-154) --
-        wq, bq = self._w(self.rpn_adapt_q_layer)
-        qp = ops.gemm_nt(corr, wq, B * hw, self.rpn_reduce_dim, 1024, lda=2048, shift=bq)
-        ops.colmean_sub_(qp, B, hw, self.rpn_reduce_dim)
-        s_pe = torch.empty((B, shot * L, 1024), dtype=torch.float32, device=dev)
-        sup3 = sup.view(Ns, L * 1024)
-        for b in range(B):  # positives = the first `shot` supports of each image (dana.py:103)
-            ops.add_pe(sup3[b * way * shot], plan["pe400"], shot * L, L, 1024, out=s_pe[b])
-        if self.semantic_enhance:  # BA block (dana.py:133-137)
-            wc, bc = self._w(self.rpn_channel_k_layer)
-            wgt = ops.rowdot(s_pe, wc, bc, B * shot * L, 1024)
-            ops.softmax_rows_(wgt, B * shot, L)
-            ops.ba_apply_(s_pe, wgt, B * shot, L, 1024, gamma=self.channel_gamma, slope=0.01)
-        wk, bk = self._w(self.rpn_adapt_k_layer)
-        kp = ops.gemm_nt(s_pe, wk, B * shot * L, self.rpn_reduce_dim, 1024, shift=bk)
-        ops.colmean_sub_(kp, B * shot, L, self.rpn_reduce_dim)
-        wu, bu = self._w(self.rpn_unary_layer)
-        unary = ops.rowdot(s_pe, wu, bu, B * shot * L, 1024)
-        ops.softmax_rows_(unary, B * shot, L)
-        K1 = shot * L
-        scores = torch.empty((B, hw, K1), dtype=torch.float32, device=dev)
         d = self.rpn_reduce_dim
+        P = cfg.POOLING_SIZE
+        P2 = P * P
+        dq = self.rcnn_reduce_dim
+        K1 = shot * L
+        sup_stream.wait_event(inputs_ready)
+        with torch.cuda.stream(sup_stream):
+            sup, sh_, sw_ = self._rcnn_base(sup_ims, plan)  # [Ns*400][1024]
+            if (sh_, sw_) != (20, 20):
+                raise RuntimeError("support images must be 320x320 (20x20 stride-16 map), as the reference "
+                                   "hard-codes (dana.py:105); got a %dx%d map" % (sh_, sw_))
+            # RPN-level support side (dana.py:126-145): PE, BA block, K projection, unary term, S^T
+            s_pe = torch.empty((B, shot * L, 1024), dtype=torch.float32, device=dev)
+            sup3 = sup.view(Ns, L * 1024)
+            for b in range(B):  # positives = the first `shot` supports of each image (dana.py:103)
+                ops.add_pe(sup3[b * way * shot], plan["pe400"], shot * L, L, 1024, out=s_pe[b])
+            if self.semantic_enhance:  # BA block (dana.py:133-137)
+                wc, bc = self._w(self.rpn_channel_k_layer)
+                wgt = ops.rowdot(s_pe, wc, bc, B * shot * L, 1024)
+                ops.softmax_rows_(wgt, B * shot, L)
+                ops.ba_apply_(s_pe, wgt, B * shot, L, 1024, gamma=self.channel_gamma, slope=0.01)
+            wk, bk = self._w(self.rpn_adapt_k_layer)
+            kp = ops.gemm_nt(s_pe, wk, B * shot * L, d, 1024, shift=bk)
+            ops.colmean_sub_(kp, B * shot, L, d)
+            wu, bu = self._w(self.rpn_unary_layer)
+            unary = ops.rowdot(s_pe, wu, bu, B * shot * L, 1024)
+            ops.softmax_rows_(unary, B * shot, L)
+            s_t = ops.transpose_batched(s_pe, B, K1, 1024)  # [B][1024][K1]
+            # RoI-level support side (dana.py:105-108,258,271-277): K / unary projections once per support
+            # (the reference recomputes them for every RoI)
+            sp = ops.avgpool(sup, Ns, 20, 20, 1024, 14, 1)  # [Ns][49][1024]
+            sp_pe = ops.add_pe(sp, plan["pe49"], Ns * P2, P2, 1024)
+            wk2, bk2 = self._w(self.rcnn_adapt_k_layer)
+            k2 = ops.gemm_nt(sp_pe, wk2, Ns * P2, dq, 1024, shift=bk2)
+            ops.colmean_sub_(k2, Ns, P2, dq)
+            wu2, bu2 = self._w(self.rcnn_unary_layer)
+            un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
+            ops.softmax_rows_(un2, Ns, P2)
+            for t_ in (kp, unary, s_t, sp_pe, k2, un2):
+                t_.record_stream(main)
+            support_done = torch.cuda.Event()
+            support_done.record()
+
+        corr, fh, fw = self._rcnn_base(im_data, plan, out_stride=2048)  # base_feat = corr[:, :1024]
+        hw = fh * fw
+
+        # -- RPN-level dual-awareness attention, query side (dana.py:118-154) --
+        wq, bq = self._w(self.rpn_adapt_q_layer)
+        qp = ops.gemm_nt(corr, wq, B * hw, d, 1024, lda=2048, shift=bq)
+        ops.colmean_sub_(qp, B, hw, d)
+        main.wait_event(support_done)
+        scores = torch.empty((B, hw, K1), dtype=torch.float32, device=dev)
         ops.gemm_nt(qp, kp, hw, K1, d, out=scores, ldc=K1, batch=B, batch_a=hw * d, batch_b=K1 * d, batch_c=hw * K1,
                     alpha=1.0 / math.sqrt(d))
         ops.attn_softmax_unary_(scores, unary, B * hw, hw, shot, L, K1, K1, self.unary_gamma, 1.0 / shot)
-        s_t = ops.transpose_batched(s_pe, B, K1, 1024)  # [B][1024][K1]
         ops.gemm_nt(scores, s_t, hw, 1024, K1, lda=K1, ldb=K1, out=corr.view(-1)[1024:], ldc=2048, batch=B,
                     batch_a=hw * K1, batch_b=1024 * K1, batch_c=hw * 2048)
         if inter is not None:
@@ -371,30 +403,12 @@ class DAnARCNN(nn.Module):
             inter["rpn_heads"] = heads
             inter["rpn_rois"] = rois
 
-        # -- support-side half of the RoI-level CISA (dana.py:105-108,258,271-277): K / unary projections
-        #    once per support (the reference recomputes them for every RoI). Independent of the rois, so
-        #    they are queued here to keep the GPU busy while the host samples the training targets. --
-        P = cfg.POOLING_SIZE
-        P2 = P * P
-        dq = self.rcnn_reduce_dim
-        sp = ops.avgpool(sup, Ns, 20, 20, 1024, 14, 1)  # [Ns][49][1024]
-        sp_pe = ops.add_pe(sp, plan["pe49"], Ns * P2, P2, 1024)
-        wk2, bk2 = self._w(self.rcnn_adapt_k_layer)
-        k2 = ops.gemm_nt(sp_pe, wk2, Ns * P2, dq, 1024, shift=bk2)
-        ops.colmean_sub_(k2, Ns, P2, dq)
-        wu2, bu2 = self._w(self.rcnn_unary_layer)
-        un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
-        ops.softmax_rows_(un2, Ns, P2)
-
         rpn_loss_cls = rpn_loss_bbox = 0
         rois_label = None
         if training:
             # anchor targets depend on the inputs only: they are computed on a side stream so that their
             # host syncs (np.random needs the counts) never drain the main stream's kernel queue
-            main = torch.cuda.current_stream()
-            side = self._consts.get("side_stream")
-            if side is None:
-                side = self._consts["side_stream"] = torch.cuda.Stream(device=dev)
+            side = self._stream("targets", dev)
             side.wait_event(inputs_ready)  # NOT wait_stream(main): the trunk is already queued there
             with torch.cuda.stream(side):
                 labels, bt, biw, bow = T.anchor_target_layer(fh, fw, gt_boxes, im_info, plan["anchors"])
