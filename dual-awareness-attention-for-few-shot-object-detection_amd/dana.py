@@ -424,7 +424,12 @@ class DAnARCNN(nn.Module):
             sc = rpn_cls_score.reshape(B, 2, A * fh, fw).permute(0, 2, 3, 1).reshape(-1, 2)
             rpn_loss_cls = F.cross_entropy(sc[keep], lab_keep)
             rpn_loss_bbox = T._smooth_l1_loss(rpn_bbox_pred, bt, biw, bow, sigma=3, dim=[1, 2, 3])
-            rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = T.proposal_target_layer(rois, gt_boxes)
+            tr_ = cfg.TRAIN
+            fg_per = int(np.round(tr_.FG_FRACTION * tr_.BATCH_SIZE)) or 1
+            rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_layer(
+                rois, gt_boxes.float(), int(tr_.BATCH_SIZE), fg_per, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
+                tr_.BBOX_NORMALIZE_MEANS, tr_.BBOX_NORMALIZE_STDS, tr_.BBOX_INSIDE_WEIGHTS,
+                tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)
             rois_label = rois_label.view(-1).long()
             rois_target = rois_target.view(-1, 4)
             rois_inside_ws = rois_inside_ws.view(-1, 4)

@@ -194,6 +194,59 @@ def rpn_decode(cls, cls_strides, cls_is_prob, bbox, bbox_strides, im_info, base_
     return proposals, scores
 
 
+def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_thresh, bg_hi, bg_lo, means, stds,
+                          inside_w, normalize=True):
+    """_ProposalTargetLayer.forward (proposal_target_layer_cascade.py:33-213): two HIP launches around one
+    D2H read of the fg/bg counts; the sampling draws np.random exactly like the reference (:143-175)."""
+    import ctypes
+    import numpy as np
+    rois = _chk(rois.contiguous(), "rois")
+    gt_boxes = _chk(gt_boxes.contiguous(), "gt_boxes")
+    B, n_rois, _ = rois.shape
+    n_gt = gt_boxes.shape[1]
+    n_all = n_rois + n_gt
+    dev = rois.device
+    max_ov = torch.empty((B, n_all), dtype=torch.float32, device=dev)
+    ibuf = torch.empty((3, B, n_all), dtype=torch.int32, device=dev)  # assign, fg_list, bg_list
+    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    lib().call("dana_proposal_target_prepare", _p(rois), _p(gt_boxes), B, n_rois, n_gt, float(fg_thresh), float(bg_hi),
+               float(bg_lo), _p(max_ov), _p(ibuf[0]), _p(ibuf[1]), _p(ibuf[2]), _p(counts), _stream())
+    cnt = counts.cpu().numpy()  # the one host sync: np.random needs the counts
+    R = rois_per_image
+    picks = np.zeros((B, R), dtype=np.int32)
+    taken = np.zeros((B,), dtype=np.int32)
+    for i in range(B):
+        nf, nb = int(cnt[i, 0]), int(cnt[i, 1])
+        if nf > 0 and nb > 0:
+            fg_n = min(fg_rois_per_image, nf)
+            picks[i, :fg_n] = np.random.permutation(nf)[:fg_n]
+            picks[i, fg_n:] = np.floor(np.random.rand(R - fg_n) * nb)
+        elif nf > 0:
+            fg_n = R
+            picks[i] = np.floor(np.random.rand(R) * nf)
+        elif nb > 0:
+            fg_n = 0
+            picks[i] = np.floor(np.random.rand(R) * nb)
+        else:
+            raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
+        taken[i] = fg_n
+    host = torch.from_numpy(np.concatenate([picks.reshape(-1), taken])).to(dev, non_blocking=True)
+    out = torch.empty((B, R, 18), dtype=torch.float32, device=dev)  # rois 5 | label 1 | tgt 4 | w_in 4 | w_out 4
+    rois_out = torch.empty((B, R, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, R), dtype=torch.float32, device=dev)
+    tgt = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
+    w_in = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
+    w_out = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
+    f4 = ctypes.c_float * 4
+    lib().call("dana_proposal_target_gather", _p(rois), _p(gt_boxes), B, n_rois, n_gt, _p(ibuf[0]), _p(ibuf[1]),
+               _p(ibuf[2]), _p(host), host.data_ptr() + B * R * 4, R,
+               ctypes.cast(f4(*means), ctypes.c_void_p), ctypes.cast(f4(*stds), ctypes.c_void_p),
+               ctypes.cast(f4(*inside_w), ctypes.c_void_p), int(bool(normalize)), _p(rois_out), _p(labels), _p(tgt),
+               _p(w_in), _p(w_out), _stream())
+    del out
+    return rois_out, labels, tgt, w_in, w_out
+
+
 # ------------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------------

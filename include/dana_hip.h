@@ -166,6 +166,25 @@ int dana_attn_softmax_unary(float* scores, const float* unary, long rows, long r
                             int nseg, int length, long ld, int kpad, float unary_gamma, float out_scale,
                             dana_stream_t stream);
 
+/* ---- training targets for the sampled RoIs: lib/model/rpn/proposal_target_layer_cascade.py:33-213 ---- */
+
+/* candidates = rois[B][n_rois][5] (cols 1..4) followed by gt_boxes[B][n_gt][5] (cols 0..3) (:43-47).
+ * max_overlaps / gt_assignment [B][n_rois+n_gt] (bbox_overlaps_batch + torch.max, :122-124),
+ * fg_list / bg_list: ascending candidate indices with max_overlap >= fg_thresh / in [bg_lo, bg_hi)
+ * (:128-133), counts[B][2] = their lengths -- the only values the host RNG needs. */
+int dana_proposal_target_prepare(const float* rois, const float* gt_boxes, int B, int n_rois, int n_gt,
+                                 float fg_thresh, float bg_thresh_hi, float bg_thresh_lo, float* max_overlaps,
+                                 int* gt_assignment, int* fg_list, int* bg_list, int* counts, dana_stream_t stream);
+/* picks[B][rois_per_image]: position in fg_list for slot r < fg_taken[b], in bg_list otherwise (the
+ * host draws them with np.random exactly as :143-175). means4/stds4/inside_w4 are HOST float[4].
+ * -> rois_out[B][R][5], labels_out[B][R], bbox_targets / inside / outside weights [B][R][4] (:83-91,:183-204). */
+int dana_proposal_target_gather(const float* rois, const float* gt_boxes, int B, int n_rois, int n_gt,
+                                const int* gt_assignment, const int* fg_list, const int* bg_list, const int* picks,
+                                const int* fg_taken, int rois_per_image, const float* means4, const float* stds4,
+                                const float* inside_w4, int normalize, float* rois_out, float* labels_out,
+                                float* bbox_targets, float* inside_weights, float* outside_weights,
+                                dana_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,23 @@
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+import dana_amd
+from dana_amd import synthetic as S, ops
+dev = torch.device('cuda:0')
+for mode in ('train', 'eval'):
+    training = mode == 'train'
+    way = 2 if training else 1
+    m = dana_amd.get_model('DAnA', pretrained=False, use_BA_block=False, way=2, shot=3, classes=['fg','bg'])
+    m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=11, profile='test')); m.to(dev)
+    m.train() if training else m.eval()
+    inputs = [t.to(dev) for t in S.episode_inputs(4, way, 3, 600, 1000, seed=1996)]
+    np.random.seed(0)
+    with torch.no_grad():
+        for _ in range(3): m(*inputs)
+        torch.cuda.synchronize()
+        hs, ts = [], []
+        for _ in range(8):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            m(*inputs); t1 = time.perf_counter()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            hs.append(t1 - t0); ts.append(t2 - t0)
+    print(mode, 'host enqueue ms %.2f  total ms %.2f' % (1e3*np.median(hs), 1e3*np.median(ts)))
