@@ -143,11 +143,15 @@ def main():
     if rank == 0 and not args.no_roofline:
         # dominant kernel family: igemm_f32_kernel (every conv / Linear / bmm). Same K steps, each launch
         # bracketed by HIP events recorded on the stream the kernel is launched on (torch's current stream).
+        # The product overlaps independent branches on several streams; for a per-kernel duration the
+        # timing pass runs them on ONE stream so that every launch is measured alone on the chip.
         ops.PROFILE = []
+        model._single_stream = True
         torch.cuda.synchronize()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+        model._single_stream = False
         prof, ops.PROFILE = ops.PROFILE, None
         flops = sum(p[1] for p in prof)
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)

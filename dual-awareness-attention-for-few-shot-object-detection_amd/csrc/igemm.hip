@@ -32,6 +32,7 @@
 //    load, float4 store -- whole 256/512-byte rows per wave instead of 4-byte scattered stores.
 #include "common.h"
 #include "../../include/dana_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -320,22 +321,16 @@ int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   return 0;
 }
 
-// Tile choice. The 64-cycle f32 MFMA hides staging for every tile shape (measured intrinsic rate of a
-// perfectly balanced launch: ~100 / 93 / 92 TF/s for 128x128 / 128x64 / 64x64), so what decides is
-// the TAIL: a CU finishes ceil(tiles/256) tiles while the average is tiles/256. Pick the shape that
-// maximises intrinsic * balance.
+// Tile choice (measured on MI355X, tools/conv_sweep.py): the 64x64 block wins or ties on every layer of
+// the path -- 36.9 KB of LDS and 68 VGPRs let 4 blocks (16 waves) share a CU, which hides the
+// barrier/staging bubbles of the 64-cycle f32 MFMA better than 2 blocks of 128x128, and its finer
+// granularity shortens the tail (a CU finishes ceil(tiles/256) tiles while the average is tiles/256).
+// DANA_IGEMM_TILE=1|2|3 forces 128x128 | 128x64 | 64x64 for tuning.
 int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   if (stem) return launch<128, 64, 1>(p, batch, s);
-  auto eff = [&](int bm, int bn, double intrinsic) {
-    if (bn == 128 && p.N <= 64) return 0.0;
-    const double tiles = (double)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch;
-    const double rounds = (double)((long)((tiles + 255) / 256));
-    const double useful = ((double)p.M / (((p.M + bm - 1) / bm) * bm)) * ((double)p.N / (((p.N + bn - 1) / bn) * bn));
-    return intrinsic * useful * tiles / (rounds * 256.0);
-  };
-  const double e128 = eff(128, 128, 1.00), e12864 = eff(128, 64, 0.94), e64 = eff(64, 64, 0.90);
-  if (e128 >= e12864 && e128 >= e64) return launch<128, 128, 0>(p, batch, s);
-  if (e12864 >= e64) return launch<128, 64, 0>(p, batch, s);
+  static const int force = getenv("DANA_IGEMM_TILE") ? atoi(getenv("DANA_IGEMM_TILE")) : 0;
+  if (force == 1 && p.N > 64) return launch<128, 128, 0>(p, batch, s);
+  if (force == 2) return launch<128, 64, 0>(p, batch, s);
   return launch<64, 64, 0>(p, batch, s);
 }
 

@@ -253,6 +253,8 @@ class DAnARCNN(nn.Module):
         return p
 
     def _stream(self, name, dev):
+        if getattr(self, "_single_stream", False):  # bench.py's per-launch timing pass: no overlap
+            return torch.cuda.current_stream()
         key = ("stream", name, str(dev))
         st = self._consts.get(key)
         if st is None:
@@ -314,7 +316,20 @@ class DAnARCNN(nn.Module):
         shot = self.n_shot
         way = self.n_way if training else 1  # eval reshapes supports as [*, n_shot] (dana.py:111)
         inter = getattr(self, "_capture", None)
+        tl = getattr(self, "_timeline", None)  # optional host-side phase clock (tools/hosttime.py)
+        if tl is not None:
+            import time as _time
+            tl.append(("begin", _time.perf_counter()))
         main = torch.cuda.current_stream()
+        gev = getattr(self, "_gpu_events", None)
+
+        def mark(name):
+            if gev is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                gev.append((name, e))
+
+        mark("begin")
         inputs_ready = torch.cuda.Event()
         inputs_ready.record()
         sup_stream = self._stream("support", dev)
@@ -373,6 +388,7 @@ class DAnARCNN(nn.Module):
         corr, fh, fw = self._rcnn_base(im_data, plan, out_stride=2048)  # base_feat = corr[:, :1024]
         hw = fh * fw
 
+        mark("query trunk")
         # -- RPN-level dual-awareness attention, query side (dana.py:118-154) --
         wq, bq = self._w(self.rpn_adapt_q_layer)
         qp = ops.gemm_nt(corr, wq, B * hw, d, 1024, lda=2048, shift=bq)
@@ -387,22 +403,27 @@ class DAnARCNN(nn.Module):
         if inter is not None:
             inter["corr"] = (corr, B, fh, fw)
 
+        mark("rpn-level attention (incl. wait for support stream)")
         # -- RPN head + proposals (rpn.py:58-78, proposal_layer.py:49-190) --
         rpn = self.RCNN_rpn
         x, _, _ = ops.conv2d_nhwc(corr, B, fh, fw, 2048, plan["rpn_conv_w"], 512, 3, 3, 1, 1, shift=plan["rpn_conv_b"],
                                   relu=True)
         nh = rpn.nc_score_out + rpn.nc_bbox_out
         heads = ops.gemm_nt(x, plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])  # [B*hw][2A | 4A]
+        mark("rpn conv + heads")
         A = plan["anchors"].size(0)
         key = "TRAIN" if training else "TEST"
         rois = ops.proposal_layer(heads, (hw * nh, 1, nh), False, heads.view(-1)[rpn.nc_score_out:], (hw * nh, 1, nh),
                                   im_info, plan["anchors"], B, A, fh, fw, rpn.feat_stride,
                                   cfg[key].RPN_PRE_NMS_TOP_N, cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH,
                                   self.nms_inclusive)
+        mark("proposal layer (decode, sort, nms)")
         if inter is not None:
             inter["rpn_heads"] = heads
             inter["rpn_rois"] = rois
 
+        if tl is not None:
+            tl.append(("enqueued trunk..proposals", _time.perf_counter()))
         rpn_loss_cls = rpn_loss_bbox = 0
         rois_label = None
         if training:
@@ -418,6 +439,8 @@ class DAnARCNN(nn.Module):
             for t_ in (bt, biw, bow, keep, lab_keep):
                 t_.record_stream(main)
             main.wait_stream(side)
+            if tl is not None:
+                tl.append(("anchor targets (host)", _time.perf_counter()))
             heads4 = heads.view(B, fh, fw, nh)
             rpn_cls_score = heads4[..., :rpn.nc_score_out].permute(0, 3, 1, 2)  # [B,2A,H,W] view
             rpn_bbox_pred = heads4[..., rpn.nc_score_out:].permute(0, 3, 1, 2)
@@ -430,10 +453,13 @@ class DAnARCNN(nn.Module):
                 rois, gt_boxes.float(), int(tr_.BATCH_SIZE), fg_per, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
                 tr_.BBOX_NORMALIZE_MEANS, tr_.BBOX_NORMALIZE_STDS, tr_.BBOX_INSIDE_WEIGHTS,
                 tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)
+            if tl is not None:
+                tl.append(("rpn losses + proposal targets (waits for rois)", _time.perf_counter()))
             rois_label = rois_label.view(-1).long()
             rois_target = rois_target.view(-1, 4)
             rois_inside_ws = rois_inside_ws.view(-1, 4)
             rois_outside_ws = rois_outside_ws.view(-1, 4)
+        mark("rpn losses + proposal targets")
         R = rois.size(1)
         n_roi = B * R
 
@@ -441,29 +467,44 @@ class DAnARCNN(nn.Module):
         if cfg.POOLING_MODE != "align":
             raise NotImplementedError("POOLING_MODE '%s': the DAnA recipe uses 'align' (cfgs/res50.yml:35)"
                                       % cfg.POOLING_MODE)
-        cat = torch.empty((n_roi * P2, 2048), dtype=torch.float32, device=dev)  # [q+PE | attended] (dana.py:284)
-        pooled, _ = ops.roi_align_forward_nhwc(corr, B, fh, fw, 1024, 2048, rois.view(-1, 5), 1.0 / 16.0, P, 0,
-                                               pe=plan["pe49"], out_pe=cat, out_pe_stride=2048)
+        pooled, q_pe = ops.roi_align_forward_nhwc(corr, B, fh, fw, 1024, 2048, rois.view(-1, 5), 1.0 / 16.0, P, 0,
+                                                  pe=plan["pe49"])  # pooled [n,49,1024] and pooled + PE (dana.py:259)
         if inter is not None:
             inter["pooled"] = pooled
+        pooled_ready = torch.cuda.Event()
+        pooled_ready.record()
+        mark("roi align")
 
-        # -- box regression branch: layer4 + mean + Linear (dana.py:246,387-389); shared by pos/neg heads --
-        y, h4, w4 = pooled, P, P
-        for bp in plan["layer4"]:
-            y, h4, w4 = self._bottleneck(y, n_roi, h4, w4, bp)
-        fc7 = ops.spatial_mean(y, n_roi, h4 * w4, 2048)
-        wb, bb = self._w(self.RCNN_bbox_pred)
-        bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
+        # -- box regression branch: layer4 + mean + Linear (dana.py:246,387-389), shared by the pos/neg heads.
+        #    It is independent of the attention head below, so it runs on its own stream (tails overlap). --
+        l4_stream = self._stream("layer4", dev)
+        l4_stream.wait_event(pooled_ready)
+        with torch.cuda.stream(l4_stream):
+            y, h4, w4 = pooled, P, P
+            for bp in plan["layer4"]:
+                y, h4, w4 = self._bottleneck(y, n_roi, h4, w4, bp)
+            fc7 = ops.spatial_mean(y, n_roi, h4 * w4, 2048)
+            wb, bb = self._w(self.RCNN_bbox_pred)
+            bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
+            bbox_pred.record_stream(main)
+            pooled.record_stream(l4_stream)
+            l4_done = torch.cuda.Event()
+            l4_done.record()
 
-        # -- RoI-level CISA (dana.py:248-292); K / unary projections once per support (not per RoI) --
+        # -- RoI-level CISA (dana.py:248-292). Query side once: Q projection and the q half of
+        #    rcnn_transform_layer (cat([q, attended]) @ Wt^T = q @ Wt[:, :1024]^T + attended @ Wt[:, 1024:]^T,
+        #    so the [n*49][2048] concat of dana.py:284 is never materialised). --
         wq2, bq2 = self._w(self.rcnn_adapt_q_layer)
-        q2 = ops.gemm_nt(cat, wq2, n_roi * P2, dq, 1024, lda=2048, shift=bq2)
+        q2 = ops.gemm_nt(q_pe, wq2, n_roi * P2, dq, 1024, shift=bq2)
         ops.colmean_sub_(q2, n_roi, P2, dq)
         K2 = shot * P2
         K2p = (K2 + 31) // 32 * 32
         wt, bt_ = self._w(self.rcnn_transform_layer)
         w1, b1 = self._w(self.output_score_layer.linear1)
         w2, b2 = self._w(self.output_score_layer.linear2)
+        tr_q = ops.gemm_nt(q_pe, wt, n_roi * P2, self.rcnn_dim, 1024, ldb=2048, shift=bt_)  # [n*49][64]
+        q_ready = torch.cuda.Event()
+        q_ready.record()
 
         def head(offset):  # offset 0: positive supports, `shot`: negatives (dana.py:189-190)
             kb = k2.view(-1)[offset * P2 * dq:]
@@ -475,18 +516,37 @@ class DAnARCNN(nn.Module):
             ops.attn_softmax_unary_(sc2, ub, n_roi * P2, R * P2, shot, P2, K2p, K2p, self.unary_gamma, 1.0 / shot,
                                     unary_batch_stride=way * shot * P2)
             st2 = ops.transpose_batched(sb, B, K2, 1024, ldi=1024, ldo=K2p, in_batch=way * shot * P2 * 1024)
-            ops.gemm_nt(sc2, st2, R * P2, 1024, K2p, lda=K2p, ldb=K2p, out=cat.view(-1)[1024:], ldc=2048, batch=B,
-                        batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 2048, k_true=K2)
-            tr = ops.gemm_nt(cat, wt, n_roi * P2, self.rcnn_dim, 2048, shift=bt_)  # [n*49][64] == [n][3136]
+            dense = torch.empty((n_roi * P2, 1024), dtype=torch.float32, device=dev)
+            ops.gemm_nt(sc2, st2, R * P2, 1024, K2p, lda=K2p, ldb=K2p, out=dense, ldc=1024, batch=B,
+                        batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 1024, k_true=K2)
+            tr = ops.gemm_nt(dense, wt.view(-1)[1024:], n_roi * P2, self.rcnn_dim, 1024, ldb=2048,
+                             residual=tr_q, ldr=self.rcnn_dim)  # [n*49][64] == [n][3136]
             hid = ops.gemm_nt(tr, w1, n_roi, w1.size(0), P2 * self.rcnn_dim, shift=b1, relu=True)
             score = ops.gemm_nt(hid, w2, n_roi, 2, w1.size(0), shift=b2)
             prob = ops.softmax_rows_(score.clone(), n_roi, 2)
             return prob, score
 
+        if training:  # the negative-support head (dana.py:190) on its own stream, concurrent with the positive one
+            neg_stream = self._stream("neg_head", dev)
+            neg_stream.wait_event(q_ready)
+            with torch.cuda.stream(neg_stream):
+                neg_prob, neg_score = head(shot)
+                for t_ in (neg_prob, neg_score):
+                    t_.record_stream(main)
+                for t_ in (q2, tr_q, q_pe):
+                    t_.record_stream(neg_stream)
+                neg_done = torch.cuda.Event()
+                neg_done.record()
         cls_prob, cls_score_all = head(0)
+        mark("pos head")
+        main.wait_event(l4_done)
+        if training:
+            main.wait_event(neg_done)
+        mark("join layer4 / neg head")
+        if tl is not None:
+            tl.append(("enqueued roialign..head", _time.perf_counter()))
         RCNN_loss_cls = RCNN_loss_bbox = 0
         if training:
-            neg_prob, neg_score = head(shot)
             cls_prob = torch.cat([cls_prob, neg_prob], 0)
             cls_score_all = torch.cat([cls_score_all, neg_score], 0)
             rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
@@ -504,4 +564,7 @@ class DAnARCNN(nn.Module):
             top1 = real_bg[real_bg >= int(n_all * 0.5)][:bg_num_1]
             topk = torch.cat([fg_inds, top0, top1], dim=0)
             RCNN_loss_cls = F.cross_entropy(cls_score_all[topk], rois_label[topk])
+        mark("rcnn losses")
+        if tl is not None:
+            tl.append(("rcnn losses", _time.perf_counter()))
         return rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox, rois_label

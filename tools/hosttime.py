@@ -21,3 +21,15 @@ for mode in ('train', 'eval'):
             torch.cuda.synchronize(); t2 = time.perf_counter()
             hs.append(t1 - t0); ts.append(t2 - t0)
     print(mode, 'host enqueue ms %.2f  total ms %.2f' % (1e3*np.median(hs), 1e3*np.median(ts)))
+    m._timeline = []
+    m._gpu_events = []
+    with torch.no_grad():
+        m(*inputs)
+    torch.cuda.synchronize()
+    e0 = m._gpu_events[0][1]
+    for name, e in m._gpu_events:
+        print('   GPU %-55s @%.2f ms' % (name, e0.elapsed_time(e)))
+    m._gpu_events = None
+    t0 = m._timeline[0][1]
+    for name, t in m._timeline:
+        print('   %-55s +%.2f ms' % (name, 1e3 * (t - t0)))
