@@ -48,6 +48,12 @@ struct IgemmParams {
   const float* residual;  // [M][ldr] or null
   int M, N, K;
   int IH, IW, OH, OW, Cin, KH, KW, stride, pad;
+  // optional second geometry segment: rows m >= M0 are pixels of images IH1 x IW1 that start `pix1`
+  // pixels into A (query and support images share every trunk launch: twice the tiles, half the tail)
+  int M0, IH1, IW1, OH1, OW1, pix1;
+  float* C1;              // segment-1 output (row m - M0), row stride ldc1
+  const float* residual1;
+  long ldc1, ldr1;
   int lda, ldb;           // floats
   long ldc, ldr;
   long batch_a, batch_b, batch_c;  // blockIdx.z strides (floats)
@@ -102,30 +108,35 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   const int r0 = tid >> 3;  // row within a 32-row slab
   unsigned a_off[RA];       // byte offset of (pixel at tap (0,0), channel c4*4)
   unsigned long long a_mask[RA];  // bit t: tap t reads inside the image (and the row exists)
+  bool a_seg1[RA];                // row belongs to the second geometry segment
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int m = m0 + r0 + 32 * j;
     const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    const int ohw = p.OH * p.OW;
+    const bool s1 = ok && m >= p.M0;
+    a_seg1[j] = s1;
+    const int mm = ok ? (s1 ? m - p.M0 : m) : 0;
+    const int IH = s1 ? p.IH1 : p.IH, IW = s1 ? p.IW1 : p.IW, OW = s1 ? p.OW1 : p.OW;
+    const int ohw = (s1 ? p.OH1 : p.OH) * OW;
     const int img = mm / ohw, rem = mm - img * ohw;
-    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+    const int oh = rem / OW, ow = rem - oh * OW;
     const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+    const int pix = (s1 ? p.pix1 : 0) + (img * IH + ih0) * IW;
     unsigned long long mask = 0;
     if (STEM) {
       // chunk = filter row kh; this thread's float4 is tap kw = c4 (8th tap / 4th channel: zero weights)
       const int iw = iw0 + c4;
-      if (ok && c4 < 7 && iw >= 0 && iw < p.IW)
+      if (ok && c4 < 7 && iw >= 0 && iw < IW)
         for (int kh = 0; kh < 7; ++kh)
-          if (ih0 + kh >= 0 && ih0 + kh < p.IH) mask |= 1ull << kh;
-      a_off[j] = (unsigned)(((img * p.IH + ih0) * p.IW + iw) * 16);
+          if (ih0 + kh >= 0 && ih0 + kh < IH) mask |= 1ull << kh;
+      a_off[j] = (unsigned)((pix + iw) * 16);
     } else {
       if (ok)
         for (int kh = 0; kh < p.KH; ++kh)
           for (int kw = 0; kw < p.KW; ++kw)
-            if (ih0 + kh >= 0 && ih0 + kh < p.IH && iw0 + kw >= 0 && iw0 + kw < p.IW)
+            if (ih0 + kh >= 0 && ih0 + kh < IH && iw0 + kw >= 0 && iw0 + kw < IW)
               mask |= 1ull << (kh * p.KW + kw);
-      a_off[j] = (unsigned)((((img * p.IH + ih0) * p.IW + iw0) * p.lda + c4 * 4) * 4);
+      a_off[j] = (unsigned)(((pix + iw0) * p.lda + c4 * 4) * 4);
     }
     a_mask[j] = mask;
   }
@@ -141,20 +152,22 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     const int k0 = kt * BK;
     const bool kok = (k0 + c4 * 4) < p.K;
     int tap;
-    unsigned delta;
+    unsigned delta, delta1;  // wave-uniform tap offsets for segment 0 / 1 (they differ in image width only)
     if (STEM) {
       tap = kt;
       delta = (unsigned)(kt * p.IW * 16);
+      delta1 = (unsigned)(kt * p.IW1 * 16);
     } else {
       tap = k0 / p.Cin;
       const int cin0 = k0 - tap * p.Cin;
       const int kh = tap / p.KW, kw = tap - kh * p.KW;
       delta = (unsigned)(((kh * p.IW + kw) * p.lda + cin0) * 4);
+      delta1 = (unsigned)(((kh * p.IW1 + kw) * p.lda + cin0) * 4);
     }
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
       const bool ok = kok && ((a_mask[j] >> tap) & 1ull);
-      ra[j] = ldg_b128(ra_src, ok ? a_off[j] + delta : OOB);
+      ra[j] = ldg_b128(ra_src, ok ? a_off[j] + (a_seg1[j] ? delta1 : delta) : OOB);
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) rb[j] = ldg_b128(rb_src, (kok && b_off[j] != OOB) ? b_off[j] + k0 * 4 : OOB);
@@ -175,6 +188,28 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Residual prefetch (64x64 tiles): the 1x1 expand convs of a bottleneck have K = 64..512, i.e. 2-16
+  // K-steps, and are HBM-bound on their [M][N] residual + output. Issuing the residual tile's loads
+  // here puts them in flight under the whole K loop instead of serialising them in the epilogue.
+  constexpr int TPR = BN / 4;     // threads per output row (epilogue mapping)
+  constexpr int RPP = 256 / TPR;  // rows per pass
+  constexpr bool PREFETCH_RES = (BM / RPP) <= 4;
+  const int ec = (tid % TPR) * 4;  // this thread's 4 columns within the tile
+  const int er = tid / TPR;
+  float4 rpre[PREFETCH_RES ? BM / RPP : 1];
+  if (PREFETCH_RES && p.residual && p.vec_io) {
+#pragma unroll
+    for (int q = 0; q < BM / RPP; ++q) {
+      const int m = m0 + er + q * RPP;
+      const int n = n0 + ec;
+      rpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p.M && n + 3 < p.N) {
+        const bool s1 = m >= p.M0;
+        rpre[q] = *(const float4*)(s1 ? p.residual1 + (long)(m - p.M0) * p.ldr1 + n : p.residual + (long)m * p.ldr + n);
+      }
+    }
+  }
 
   const int nk = (p.K + BK - 1) / BK;
   load_tile(0);
@@ -218,10 +253,6 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * CLD] = acc[i][j][r];
     }
   __syncthreads();
-  constexpr int TPR = BN / 4;        // threads per output row
-  constexpr int RPP = 256 / TPR;     // rows per pass
-  const int ec = (tid % TPR) * 4;    // this thread's 4 columns within the tile
-  const int er = tid / TPR;
   const int n = n0 + ec;
   float sc[4], sh[4];
 #pragma unroll
@@ -231,18 +262,21 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     sh[q] = (nok && p.shift) ? p.shift[n + q] : 0.f;
   }
   const bool full4 = p.vec_io && (n + 3) < p.N;
-#pragma unroll 4
-  for (int rr = er; rr < BM; rr += RPP) {
+#pragma unroll
+  for (int q = 0; q < BM / RPP; ++q) {
+    const int rr = er + q * RPP;
     const int m = m0 + rr;
     if (m >= p.M) break;
     const float4 a4 = *(const float4*)(Cs + rr * CLD + ec);
     float v[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = v[q] * p.alpha * sc[q] + sh[q];
-    float* cp = Cb + (long)m * p.ldc + n;
+    const bool s1 = m >= p.M0;
+    float* cp = s1 ? p.C1 + (long)(m - p.M0) * p.ldc1 + n : Cb + (long)m * p.ldc + n;
+    const float* rp = s1 ? p.residual1 + (long)(m - p.M0) * p.ldr1 + n : p.residual + (long)m * p.ldr + n;
     if (full4) {
       if (p.residual) {
-        const float4 r4 = *(const float4*)(p.residual + (long)m * p.ldr + n);
+        const float4 r4 = PREFETCH_RES ? rpre[q] : *(const float4*)rp;
         v[0] += r4.x;
         v[1] += r4.y;
         v[2] += r4.z;
@@ -258,7 +292,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       for (int q = 0; q < 4; ++q)
         if ((n + q) < p.N) {
           float x = v[q];
-          if (p.residual) x += p.residual[(long)m * p.ldr + n + q];
+          if (p.residual) x += rp[q];
           if (p.relu) x = fmaxf(x, 0.f);
           cp[q] = x;
         }
@@ -335,8 +369,15 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
 }
 
 int run(IgemmParams& p, int batch, int stem, hipStream_t s) {
+  if (p.M0 <= 0 || p.M0 > p.M) p.M0 = p.M;  // single segment
+  if (p.M0 == p.M) {
+    p.IH1 = p.IH; p.IW1 = p.IW; p.OH1 = p.OH; p.OW1 = p.OW; p.pix1 = 0;
+    p.C1 = p.C; p.ldc1 = p.ldc; p.residual1 = p.residual; p.ldr1 = p.ldr;
+  }
   p.vec_io = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (p.batch_c % 4 == 0) &&
-             (!p.residual || ((p.ldr % 4 == 0) && (((uintptr_t)p.residual & 15) == 0)));
+             (!p.residual || ((p.ldr % 4 == 0) && (((uintptr_t)p.residual & 15) == 0))) &&
+             (p.ldc1 % 4 == 0) && (((uintptr_t)p.C1 & 15) == 0) &&
+             (!p.residual1 || ((p.ldr1 % 4 == 0) && (((uintptr_t)p.residual1 & 15) == 0)));
   return dispatch(p, batch, stem, s);
 }
 
@@ -344,31 +385,49 @@ int run(IgemmParams& p, int batch, int stem, hipStream_t s) {
 
 extern "C" {
 
-int dana_conv2d_nhwc(const float* input, const float* weight, float* output, const float* scale,
-                     const float* shift, const float* residual, int batch, int in_h, int in_w, int cin,
-                     int cout, int kh, int kw, int stride, int pad, long in_pix_stride, long out_pix_stride,
-                     long res_pix_stride, int flags, dana_stream_t stream) {
-  DANA_CHECK_ARG(batch >= 0 && in_h > 0 && in_w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 &&
-                     pad >= 0,
-                 "dana_conv2d_nhwc: bad shape");
-  if (batch == 0) return DANA_OK;
-  DANA_CHECK_ARG(input && weight && output, "dana_conv2d_nhwc: null pointer");
-  DANA_CHECK_ARG(kh * kw <= 64, "dana_conv2d_nhwc: at most 64 filter taps");
+static int conv2d_impl(const char* who, const float* input, const float* weight, float* out0, float* out1,
+                       const float* scale, const float* shift, const float* res0, const float* res1, int batch0,
+                       int h0, int w0, int batch1, int h1, int w1, int cin, int cout, int kh, int kw, int stride,
+                       int pad, long in_pix_stride, long out0_stride, long out1_stride, long res0_stride,
+                       long res1_stride, int flags, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch0 >= 0 && batch1 >= 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+                 "%s: bad shape", who);
+  DANA_CHECK_ARG((batch0 == 0 || (h0 > 0 && w0 > 0)) && (batch1 == 0 || (h1 > 0 && w1 > 0)), "%s: bad image size", who);
+  if (batch0 + batch1 == 0) return DANA_OK;
+  if (batch0 == 0) {  // only the second segment is populated: make it the first
+    return conv2d_impl(who, input, weight, out1, nullptr, scale, shift, res1, nullptr, batch1, h1, w1, 0, 0, 0, cin,
+                       cout, kh, kw, stride, pad, in_pix_stride, out1_stride, 0, res1_stride, 0, flags, stream);
+  }
+  DANA_CHECK_ARG(input && weight && out0 && (batch1 == 0 || out1), "%s: null pointer", who);
+  DANA_CHECK_ARG(kh * kw <= 64, "%s: at most 64 filter taps", who);
+  DANA_CHECK_ARG(!res0 == !(batch1 ? res1 : res0), "%s: residual must be given for both segments or none", who);
   const bool stem = (flags & DANA_CONV_STEM7) != 0;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.A = input;
   p.Bw = weight;
-  p.C = output;
+  p.C = out0;
   p.scale = scale;
   p.shift = shift;
-  p.residual = residual;
-  p.IH = in_h;
-  p.IW = in_w;
-  p.OH = (in_h + 2 * pad - kh) / stride + 1;
-  p.OW = (in_w + 2 * pad - kw) / stride + 1;
-  DANA_CHECK_ARG(p.OH > 0 && p.OW > 0, "dana_conv2d_nhwc: empty output");
-  p.M = batch * p.OH * p.OW;
+  p.residual = res0;
+  p.IH = h0;
+  p.IW = w0;
+  p.OH = (h0 + 2 * pad - kh) / stride + 1;
+  p.OW = (w0 + 2 * pad - kw) / stride + 1;
+  DANA_CHECK_ARG(p.OH > 0 && p.OW > 0, "%s: empty output", who);
+  p.M0 = batch0 * p.OH * p.OW;
+  p.M = p.M0;
+  if (batch1 > 0) {
+    p.IH1 = h1;
+    p.IW1 = w1;
+    p.OH1 = (h1 + 2 * pad - kh) / stride + 1;
+    p.OW1 = (w1 + 2 * pad - kw) / stride + 1;
+    DANA_CHECK_ARG(p.OH1 > 0 && p.OW1 > 0, "%s: empty output (segment 1)", who);
+    p.pix1 = batch0 * h0 * w0;
+    p.M += batch1 * p.OH1 * p.OW1;
+    p.C1 = out1;
+    p.residual1 = res1;
+  }
   p.N = cout;
   p.KH = kh;
   p.KW = kw;
@@ -379,31 +438,52 @@ int dana_conv2d_nhwc(const float* input, const float* weight, float* output, con
   long lda;
   if (stem) {
     // input is NHWC4 (3 channels + zero pad), weight packed [cout][7][8][4] (K = 224)
-    DANA_CHECK_ARG(kh == 7 && kw == 7 && cin == 4, "dana_conv2d_nhwc: STEM7 needs 7x7 over NHWC4");
+    DANA_CHECK_ARG(kh == 7 && kw == 7 && cin == 4, "%s: STEM7 needs 7x7 over NHWC4", who);
     p.Cin = 4;
     p.K = 7 * 32;
     lda = 4;
   } else {
-    DANA_CHECK_ARG(cin % BK == 0, "dana_conv2d_nhwc: cin=%d must be a multiple of %d", cin, BK);
+    DANA_CHECK_ARG(cin % BK == 0, "%s: cin=%d must be a multiple of %d", who, cin, BK);
     p.Cin = cin;
     p.K = kh * kw * cin;
     lda = in_pix_stride > 0 ? in_pix_stride : cin;
-    DANA_CHECK_ARG(lda % 4 == 0 && lda >= cin, "dana_conv2d_nhwc: bad in_pix_stride");
+    DANA_CHECK_ARG(lda % 4 == 0 && lda >= cin, "%s: bad in_pix_stride", who);
   }
-  const long a_bytes = (long)batch * in_h * in_w * lda * 4, b_bytes = (long)cout * p.K * 4;
+  const long a_bytes = ((long)batch0 * h0 * w0 + (long)batch1 * h1 * w1) * lda * 4, b_bytes = (long)cout * p.K * 4;
   DANA_CHECK_ARG(a_bytes < (long)OOB && b_bytes < (long)OOB,
-                 "dana_conv2d_nhwc: operand spans >= 2 GiB are not addressable by one buffer descriptor; split the batch");
+                 "%s: operand spans >= 2 GiB are not addressable by one buffer descriptor; split the batch", who);
   p.lda = (int)lda;
   p.ldb = p.K;
   p.a_bytes = (unsigned)a_bytes;
   p.b_bytes = (unsigned)b_bytes;
-  p.ldc = out_pix_stride > 0 ? out_pix_stride : cout;
-  p.ldr = res_pix_stride > 0 ? res_pix_stride : cout;
+  p.ldc = out0_stride > 0 ? out0_stride : cout;
+  p.ldr = res0_stride > 0 ? res0_stride : cout;
+  p.ldc1 = out1_stride > 0 ? out1_stride : cout;
+  p.ldr1 = res1_stride > 0 ? res1_stride : cout;
   DANA_CHECK_ARG(((uintptr_t)input & 15) == 0 && ((uintptr_t)weight & 15) == 0,
-                 "dana_conv2d_nhwc: input/weight must be 16-byte aligned");
+                 "%s: input/weight must be 16-byte aligned", who);
   run(p, 1, stem, (hipStream_t)stream);
-  DANA_CHECK_LAUNCH("dana_conv2d_nhwc");
+  DANA_CHECK_LAUNCH(who);
   return DANA_OK;
+}
+
+int dana_conv2d_nhwc(const float* input, const float* weight, float* output, const float* scale,
+                     const float* shift, const float* residual, int batch, int in_h, int in_w, int cin,
+                     int cout, int kh, int kw, int stride, int pad, long in_pix_stride, long out_pix_stride,
+                     long res_pix_stride, int flags, dana_stream_t stream) {
+  return conv2d_impl("dana_conv2d_nhwc", input, weight, output, nullptr, scale, shift, residual, nullptr, batch, in_h,
+                     in_w, 0, 0, 0, cin, cout, kh, kw, stride, pad, in_pix_stride, out_pix_stride, 0, res_pix_stride,
+                     0, flags, stream);
+}
+
+int dana_conv2d_nhwc_dual(const float* input, const float* weight, float* out0, float* out1, const float* scale,
+                          const float* shift, const float* res0, const float* res1, int batch0, int h0, int w0,
+                          int batch1, int h1, int w1, int cin, int cout, int kh, int kw, int stride, int pad,
+                          long in_pix_stride, long out0_stride, long out1_stride, long res0_stride,
+                          long res1_stride, int flags, dana_stream_t stream) {
+  return conv2d_impl("dana_conv2d_nhwc_dual", input, weight, out0, out1, scale, shift, res0, res1, batch0, h0, w0,
+                     batch1, h1, w1, cin, cout, kh, kw, stride, pad, in_pix_stride, out0_stride, out1_stride,
+                     res0_stride, res1_stride, flags, stream);
 }
 
 int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, const float* shift,

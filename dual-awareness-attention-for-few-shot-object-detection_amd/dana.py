@@ -137,6 +137,10 @@ class DAnARCNN(nn.Module):
         self.pos_encoding = pos_encoding
         self.pool_feat_dim = 1024
         self.rcnn_dim = 64
+        self.query_streams = 1
+        # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
+        # True: query + support batches share every trunk launch (dana_conv2d_nhwc_dual)
+        self.merge_trunk = False
         self.nms_inclusive = False  # False: IoU > thr as the reference CUDA op (nms.cu:60); True: CPU op (>=)
         dim_in = self.pool_feat_dim
 
@@ -284,8 +288,9 @@ class DAnARCNN(nn.Module):
                               out_stride=out_stride)
         return o3, h1, w1
 
-    def _rcnn_base(self, im, plan, out_stride=0):
-        """RCNN_base (dana.py:344-345) on NCHW input -> (NHWC flat buffer [n*h*w][out_stride or 1024], h, w)."""
+    def _rcnn_base(self, im, plan, out_stride=0, out_buf=None):
+        """RCNN_base (dana.py:344-345) on NCHW input -> (NHWC flat buffer [n*h*w][out_stride or 1024], h, w).
+        out_buf: write the result there (row stride out_stride) instead of allocating."""
         n, _, H, W = im.shape
         x4 = ops.nchw_to_nhwc(im, cpad=4)
         st = plan["stem"]
@@ -300,9 +305,67 @@ class DAnARCNN(nn.Module):
                 if last and out_stride:
                     hh = (h - 1) // bp["c1"]["stride"] + 1
                     ww = (w - 1) // bp["c1"]["stride"] + 1
-                    out = torch.empty((n * hh * ww, out_stride), dtype=torch.float32, device=im.device)
+                    out = out_buf if out_buf is not None else torch.empty((n * hh * ww, out_stride),
+                                                                          dtype=torch.float32, device=im.device)
                 x, h, w = self._bottleneck(x, n, h, w, bp, out=out, out_stride=out_stride if last else 0)
         return x, h, w
+
+    @staticmethod
+    def _feat_size(H, W):
+        """spatial size of RCNN_base's output: 7x7/2 pad 3, ceil-mode 3x3/2 maxpool, two stride-2 1x1 convs"""
+        h, w = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        h, w = ops.maxpool_out_size(h, w)
+        for _ in range(2):
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        return h, w
+
+    def _rcnn_base_dual(self, im, sup_ims, plan, dev):
+        """RCNN_base on the query batch AND the support batch with one launch per layer (dana.py:98,100):
+        -> (corr [B*h*w][2048] with base_feat in channels 0..1023, (h, w), sup [Ns*sh*sw][1024], (sh, sw))."""
+        n0, _, H0, W0 = im.shape
+        n1, _, H1, W1 = sup_ims.shape
+        x4 = torch.empty(((n0 * H0 * W0 + n1 * H1 * W1), 4), dtype=torch.float32, device=dev)
+        ops.nchw_to_nhwc(im, cpad=4, out=x4)
+        ops.nchw_to_nhwc(sup_ims, cpad=4, out=x4[n0 * H0 * W0:])
+        st = plan["stem"]
+        x, _, g0, g1 = ops.conv2d_nhwc_dual(x4, n0, H0, W0, n1, H1, W1, 4, st["w"], 64, 7, 7, 2, 3, scale=st["scale"],
+                                            shift=st["shift"], relu=True, stem=True)
+        p0, p1 = ops.maxpool_out_size(*g0), ops.maxpool_out_size(*g1)
+        m0 = n0 * p0[0] * p0[1]
+        xp = torch.empty((m0 + n1 * p1[0] * p1[1], 64), dtype=torch.float32, device=dev)
+        ops.maxpool3x3s2_ceil(x, n0, g0[0], g0[1], 64, out=xp)
+        ops.maxpool3x3s2_ceil(x[n0 * g0[0] * g0[1]:], n1, g1[0], g1[1], 64, out=xp[m0:])
+        x, g0, g1 = xp, p0, p1
+
+        def conv(xin, gin0, gin1, c, relu, res=None, out0=None, out1=None, s0=0, s1=0):
+            mi0 = n0 * gin0[0] * gin0[1]
+            r0, r1 = (res, res[mi0_res[0]:]) if res is not None else (None, None)
+            return ops.conv2d_nhwc_dual(xin, n0, gin0[0], gin0[1], n1, gin1[0], gin1[1], c["cin"], c["w"], c["cout"],
+                                        c["k"], c["k"], c["stride"], c["pad"], scale=c["scale"], shift=c["shift"],
+                                        res0=r0, res1=r1, relu=relu, out0=out0, out1=out1, out0_stride=s0,
+                                        out1_stride=s1)
+
+        mi0_res = [0]
+        corr = sup = None
+        nl = len(plan["layers"])
+        for li, layer in enumerate(plan["layers"]):
+            for bi, bp in enumerate(layer):
+                last = (li == nl - 1) and (bi == len(layer) - 1)
+                o1, _, h0, h1 = conv(x, g0, g1, bp["c1"], True)
+                o2, _, _, _ = conv(o1, h0, h1, bp["c2"], True)
+                if bp["ds"] is not None:
+                    res, _, _, _ = conv(x, g0, g1, bp["ds"], False)
+                else:
+                    res = x
+                mi0_res[0] = n0 * h0[0] * h0[1]
+                if last:
+                    corr = torch.empty((n0 * h0[0] * h0[1], 2048), dtype=torch.float32, device=dev)
+                    sup = torch.empty((n1 * h1[0] * h1[1], 1024), dtype=torch.float32, device=dev)
+                    conv(o2, h0, h1, bp["c3"], True, res=res, out0=corr, out1=sup, s0=2048, s1=1024)
+                else:
+                    x, _, _, _ = conv(o2, h0, h1, bp["c3"], True, res=res)
+                g0, g1 = h0, h1
+        return corr, g0, sup, g1
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, im_data, im_info, gt_boxes, num_boxes, support_ims, all_cls_gt_boxes=None):
@@ -334,9 +397,9 @@ class DAnARCNN(nn.Module):
         inputs_ready.record()
         sup_stream = self._stream("support", dev)
 
-        # -- feature extraction (dana.py:98-115). The support trunk and everything that depends only on
-        #    the supports run on their own stream, concurrently with the query trunk: each conv launch has
-        #    a tail (tiles/256 is rarely an integer) and the two streams fill each other's idle CUs. --
+        # -- feature extraction (dana.py:98-115): query and support batches share every trunk launch
+        #    (twice the tiles -> half the tail on the 256 CUs); everything that depends only on the
+        #    supports then runs on its own stream, concurrently with the query side. --
         sup_ims = support_ims.reshape(-1, support_ims.size(2), support_ims.size(3), support_ims.size(4))
         Ns = sup_ims.size(0)
         if Ns != B * way * shot:
@@ -347,12 +410,38 @@ class DAnARCNN(nn.Module):
         P2 = P * P
         dq = self.rcnn_reduce_dim
         K1 = shot * L
-        sup_stream.wait_event(inputs_ready)
+        if self.merge_trunk:
+            corr, (fh, fw), sup, (sh_, sw_) = self._rcnn_base_dual(im_data, sup_ims, plan, dev)
+            trunk_done = torch.cuda.Event()
+            trunk_done.record()
+            sup_stream.wait_event(trunk_done)
+        else:
+            sup_stream.wait_event(inputs_ready)
+            with torch.cuda.stream(sup_stream):
+                sup, sh_, sw_ = self._rcnn_base(sup_ims, plan)  # [Ns*400][1024]
+            # the query batch itself is split over `query_streams` streams: kernels of different images
+            # overlap each other's prologue / epilogue / tail phases on the CUs
+            qs = max(1, min(int(self.query_streams), B))
+            fh, fw = self._feat_size(im_data.size(2), im_data.size(3))
+            corr = torch.empty((B * fh * fw, 2048), dtype=torch.float32, device=dev)
+            bounds = [B * i // qs for i in range(qs + 1)]
+            for i in range(qs):
+                b0, b1 = bounds[i], bounds[i + 1]
+                if i == 0:
+                    self._rcnn_base(im_data[b0:b1], plan, out_stride=2048, out_buf=corr)
+                else:
+                    st_i = self._stream("query%d" % i, dev)
+                    st_i.wait_event(inputs_ready)
+                    with torch.cuda.stream(st_i):
+                        self._rcnn_base(im_data[b0:b1], plan, out_stride=2048, out_buf=corr[b0 * fh * fw:])
+                    main.wait_stream(st_i)
+        hw = fh * fw
+        if (sh_, sw_) != (20, 20):
+            raise RuntimeError("support images must be 320x320 (20x20 stride-16 map), as the reference "
+                               "hard-codes (dana.py:105); got a %dx%d map" % (sh_, sw_))
+        mark("trunk (query + support)")
         with torch.cuda.stream(sup_stream):
-            sup, sh_, sw_ = self._rcnn_base(sup_ims, plan)  # [Ns*400][1024]
-            if (sh_, sw_) != (20, 20):
-                raise RuntimeError("support images must be 320x320 (20x20 stride-16 map), as the reference "
-                                   "hard-codes (dana.py:105); got a %dx%d map" % (sh_, sw_))
+            sup.record_stream(sup_stream)
             # RPN-level support side (dana.py:126-145): PE, BA block, K projection, unary term, S^T
             s_pe = torch.empty((B, shot * L, 1024), dtype=torch.float32, device=dev)
             sup3 = sup.view(Ns, L * 1024)
@@ -385,10 +474,6 @@ class DAnARCNN(nn.Module):
             support_done = torch.cuda.Event()
             support_done.record()
 
-        corr, fh, fw = self._rcnn_base(im_data, plan, out_stride=2048)  # base_feat = corr[:, :1024]
-        hw = fh * fw
-
-        mark("query trunk")
         # -- RPN-level dual-awareness attention, query side (dana.py:118-154) --
         wq, bq = self._w(self.rpn_adapt_q_layer)
         qp = ops.gemm_nt(corr, wq, B * hw, d, 1024, lda=2048, shift=bq)

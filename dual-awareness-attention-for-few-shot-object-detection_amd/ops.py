@@ -270,6 +270,30 @@ def conv2d_nhwc(x, batch, in_h, in_w, cin, weight, cout, kh, kw, stride, pad, sc
     return out, oh, ow
 
 
+def conv2d_nhwc_dual(x, n0, h0, w0, n1, h1, w1, cin, weight, cout, kh, kw, stride, pad, scale=None, shift=None,
+                     res0=None, res1=None, relu=False, in_stride=0, out0=None, out1=None, out0_stride=0,
+                     out1_stride=0, res0_stride=0, res1_stride=0, stem=False):
+    """One launch over two image groups (query batch + support batch); x holds group 0's pixels then group 1's.
+    Without out0/out1 the result is ONE merged buffer [M0 + M1][cout]. Returns (out0, out1, (oh0, ow0), (oh1, ow1))."""
+    _chk(x, "x")
+    _chk(weight, "weight")
+    oh0, ow0 = (h0 + 2 * pad - kh) // stride + 1, (w0 + 2 * pad - kw) // stride + 1
+    oh1, ow1 = (h1 + 2 * pad - kh) // stride + 1, (w1 + 2 * pad - kw) // stride + 1
+    m0, m1 = n0 * oh0 * ow0, n1 * oh1 * ow1
+    if out0 is None:
+        merged = torch.empty((m0 + m1, cout), dtype=torch.float32, device=x.device)
+        out0, out1 = merged, merged[m0:]
+        out0_stride = out1_stride = cout
+    flags = (EPI_RELU if relu else 0) | (CONV_STEM7 if stem else 0)
+    e0 = _prof_begin()
+    lib().call("dana_conv2d_nhwc_dual", _p(x), _p(weight), _p(out0), _p(out1), _p(scale), _p(shift), _p(res0),
+               _p(res1), n0, h0, w0, n1, h1, w1, cin, cout, kh, kw, stride, pad, in_stride, out0_stride, out1_stride,
+               res0_stride, res1_stride, flags, _stream())
+    _prof_end(e0, "conv%dx%d M=%d N=%d K=%d s%d" % (kh, kw, m0 + m1, cout, kh * kw * cin, stride),
+              2.0 * (m0 + m1) * cout * kh * kw * (3 if stem else cin))
+    return out0, out1, (oh0, ow0), (oh1, ow1)
+
+
 def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None, residual=None, ldr=0, batch=1,
             batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False, k_true=0):
     """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous."""
@@ -308,15 +332,21 @@ def nhwc_to_nchw(x, B, C, H, W, in_stride=0):
     return out
 
 
-def maxpool3x3s2_ceil(x, B, H, W, C):
-    _chk(x, "x")
+def maxpool_out_size(H, W):
     oh = (H - 3 + 1) // 2 + 1
     ow = (W - 3 + 1) // 2 + 1
     if (oh - 1) * 2 >= H:
         oh -= 1
     if (ow - 1) * 2 >= W:
         ow -= 1
-    out = torch.empty((B * oh * ow, C), dtype=torch.float32, device=x.device)
+    return oh, ow
+
+
+def maxpool3x3s2_ceil(x, B, H, W, C, out=None):
+    _chk(x, "x")
+    oh, ow = maxpool_out_size(H, W)
+    if out is None:
+        out = torch.empty((B * oh * ow, C), dtype=torch.float32, device=x.device)
     lib().call("dana_maxpool3x3s2_ceil_nhwc", _p(x), _p(out), B, H, W, C, _stream())
     return out, oh, ow
 

@@ -111,6 +111,16 @@ int dana_conv2d_nhwc(const float* input, const float* weight, float* output, con
                      int cout, int kh, int kw, int stride, int pad, long in_pix_stride, long out_pix_stride,
                      long res_pix_stride, int flags, dana_stream_t stream);
 
+/* The same conv over TWO image groups in one launch: input rows = batch0 images of h0 x w0 followed by
+ * batch1 images of h1 x w1 (same channels / pixel stride); outputs go to out0 / out1 with their own row
+ * strides. RCNN_base is applied to the query batch and to the support batch (dana.py:98,100): sharing
+ * each layer's launch doubles the tile count and halves the tail on the 256 CUs. */
+int dana_conv2d_nhwc_dual(const float* input, const float* weight, float* out0, float* out1, const float* scale,
+                          const float* shift, const float* res0, const float* res1, int batch0, int h0, int w0,
+                          int batch1, int h1, int w1, int cin, int cout, int kh, int kw, int stride, int pad,
+                          long in_pix_stride, long out0_stride, long out1_stride, long res0_stride,
+                          long res1_stride, int flags, dana_stream_t stream);
+
 /* nn.Linear / torch.bmm (dana.py:124,140,142,147,266-290): c[z][m][n] = epi(alpha * sum_k a[z][m][k]*b[z][n][k]).
  * Both operands K-contiguous ("NT"); nn.Linear weights [out][in] are used as stored. k % 4 == 0. */
 int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, const float* shift,

@@ -1,0 +1,128 @@
+"""CPU suite, part 2: the C-ABI library loads and exports every symbol include/dana_hip.h declares
+(no compute without a GPU), argument errors surface as DanaError with a message, and the host-side
+logic of the product package (module API, state_dict contract, config, target assignment, synthetic
+generator) behaves like the reference / the oracle."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dana_amd
+from dana_amd import _lib, ops, synthetic as S, targets as T
+from dana_amd.config import cfg, cfg_from_list
+from oracle import model_ref as O
+
+
+def test_library_exports_every_declared_symbol():
+    protos = _lib.parse_header()
+    assert len(protos) >= 35
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(cdll, name), "libdana_hip.so does not export %s" % name
+    # and nothing torch-typed leaks into the boundary: only C scalars and raw pointers
+    allowed = {"int", "long", "float", "size_t", "dana_stream_t", "const float*", "float*", "const int*", "int*",
+               "void*"}
+    for name, (ret, args) in protos.items():
+        assert ret in ("int", "size_t", "const char*"), (name, ret)
+        for ty, _ in args:
+            assert ty in allowed, "%s: parameter type %r is not a plain C scalar / raw pointer" % (name, ty)
+    assert _lib.lib().query("dana_abi_version") == 1
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    L = _lib.lib()
+    with pytest.raises(_lib.DanaError, match="bad shape"):
+        L.call("dana_roi_align_forward", None, None, None, 1, 0, 8, 8, 1, 1.0, 7, 7, 0, 0, 0, 0, None, None, 0, None)
+    with pytest.raises(_lib.DanaError, match="multiples of 4"):
+        L.call("dana_gemm_nt", 16, 16, 16, None, None, None, 8, 8, 6, 6, 6, 8, 0, 1, 0, 0, 0, 1.0, 0, None)
+    with pytest.raises(_lib.DanaError, match="workspace"):
+        L.call("dana_nms", 16, 100, 1, 0.7, 0, 0, 16, 100, 16, None, 0, None)
+    assert L.query("dana_nms_workspace_bytes", 12000, 4) == 4 * 12000 * 188 * 8
+    # empty inputs are a no-op, like the reference (nms.h:17-18, ROIAlign_cuda.cu:278-281)
+    L.call("dana_roi_align_forward", None, None, None, 1, 8, 8, 8, 0, 1.0, 7, 7, 0, 0, 0, 0, None, None, 0, None)
+
+
+def test_ops_refuse_cpu_tensors():
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ops.roi_align_forward(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 1.0, 7, 7, 0)
+    with pytest.raises(RuntimeError):
+        dana_amd._C.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
+
+
+def test_module_api_and_state_dict_contract():
+    """346 entries (344 without the BA layer), 70 trainable tensors / 37 113 489 params."""
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=2, shot=3, classes=["fg", "bg"])
+    sd = m.state_dict()
+    assert len(sd) == 346
+    assert sum(k.startswith("RCNN_base.") for k in sd) == 258 and sum(k.startswith("RCNN_top.") for k in sd) == 60
+    for k in ("rpn_unary_layer.weight", "rcnn_adapt_q_layer.bias", "rpn_channel_k_layer.weight",
+              "RCNN_rpn.RPN_Conv.weight", "RCNN_rpn.RPN_cls_score.bias", "rcnn_transform_layer.weight",
+              "output_score_layer.linear1.weight", "RCNN_bbox_pred.bias", "RCNN_base.6.5.bn3.running_var",
+              "RCNN_top.0.0.downsample.0.weight"):
+        assert k in sd, k
+    assert tuple(sd["RCNN_rpn.RPN_Conv.weight"].shape) == (512, 2048, 3, 3)
+    assert tuple(sd["RCNN_rpn.RPN_cls_score.weight"].shape) == (24, 512, 1, 1)
+    assert tuple(sd["output_score_layer.linear1.weight"].shape) == (1024, 3136)
+    trainable = [p for p in m.parameters() if p.requires_grad]
+    assert len(trainable) == 70 and sum(p.numel() for p in trainable) == 37113489
+    assert sum(p.numel() for p in m.parameters()) == 37389009
+    assert "bias" in "".join(n for n, _ in m.named_parameters())  # train.py:79-85 keys off 'bias' in name
+    m.train()
+    assert not m.RCNN_base[4].training and m.RCNN_base[5].training  # dana.py:370-385
+    assert all(not mod.training for mod in m.RCNN_base.modules() if isinstance(mod, torch.nn.BatchNorm2d))
+    assert len(dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False).state_dict()) == 344
+    with pytest.raises(Exception):
+        dana_amd.get_model("cisa")  # undefined in the reference too (utils.py:117-118)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.eval()(*S.episode_inputs(1, 1, 3, 64, 64))
+
+
+def test_config_overrides():
+    assert cfg.ANCHOR_SCALES == [4, 8, 16, 32] and cfg.MAX_NUM_GT_BOXES == 50 and cfg.TRAIN.BATCH_SIZE == 128
+    cfg_from_list(["TRAIN.RPN_POST_NMS_TOP_N", "1000"])
+    assert cfg.TRAIN.RPN_POST_NMS_TOP_N == 1000
+    cfg_from_list(["TRAIN.RPN_POST_NMS_TOP_N", "2000"])
+    with pytest.raises(AssertionError):
+        cfg_from_list(["NOT_A_KEY", "1"])
+
+
+def test_synthetic_generator_is_portable_and_seeded():
+    a, b = S.normal("x", (4, 5), 2.0, 1.0, seed=3), S.normal("x", (4, 5), 2.0, 1.0, seed=3)
+    assert torch.equal(a, b) and not torch.equal(a, S.normal("y", (4, 5), 2.0, 1.0, seed=3))
+    big = S.normal("z", (200000,), 1.0, 0.0, seed=1)
+    assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01
+    im, info, gt, nb, sup = S.episode_inputs(2, 2, 3, 64, 96)
+    assert sup.shape == (2, 6, 3, 320, 320) and gt.shape == (2, 50, 5) and (gt[:, :3, 4] == 1).all()
+
+
+def test_host_target_layers_match_the_oracle_on_cpu():
+    """the product's torch target layers (targets.py) vs the oracle restatement, same np.random stream"""
+    torch.manual_seed(0)
+    B, H, W = 2, 12, 16
+    _, im_info, gt, _, _ = S.episode_inputs(B, 1, 1, 192, 256, seed=5)
+    base = torch.from_numpy(T.generate_anchors(scales=np.array(cfg.ANCHOR_SCALES), ratios=np.array(cfg.ANCHOR_RATIOS))).float()
+    assert np.array_equal(T.generate_anchors(scales=np.array([4, 8, 16, 32])), O.generate_anchors(scales=[4, 8, 16, 32]))
+    assert torch.equal(T.shifted_anchors(base, H, W, 16, "cpu"), O.anchor_grid(base.numpy(), H, W, 16))
+    np.random.seed(11)
+    mine = T.anchor_target_layer(H, W, gt, im_info, base)
+    np.random.seed(11)
+    ref = O.anchor_target_layer((H, W), gt, im_info)
+    for a, b in zip(mine, ref):
+        assert torch.equal(a, b.contiguous())
+    rois = torch.zeros(B, 300, 5)
+    rng = np.random.default_rng(0)
+    xy = rng.uniform(0, 150, size=(B, 300, 2))
+    wh = rng.uniform(8, 100, size=(B, 300, 2))
+    rois[:, :, 1:3] = torch.from_numpy(xy).float()
+    rois[:, :, 3:5] = torch.from_numpy(xy + wh).float()
+    rois[:, 250:] = 0  # zero-padded proposals (proposal_layer.py:186-188)
+    np.random.seed(12)
+    mine = T.proposal_target_layer(rois, gt)
+    np.random.seed(12)
+    ref = O.proposal_target_layer(rois, gt)
+    for a, b in zip(mine, ref):
+        assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
+    ov = T.bbox_overlaps_batch(rois, gt)
+    assert torch.equal(ov, O.bbox_overlaps_batch(rois, gt))

@@ -180,3 +180,51 @@ def test_decode_clip_golden(G, dev):
                                    B, A, H, W, 16)
     assert np.allclose(props.cpu().numpy(), G["dec_out"], rtol=1e-5, atol=1e-3)  # expf vs torch.exp: few ulp
     assert torch.allclose(scores, torch.full_like(scores, 0.5))
+
+
+def test_proposal_target_hip_matches_host_logic_same_rng(dev):
+    """HIP _ProposalTargetLayer (2 launches + 1 count read) vs the torch restatement, same np.random stream"""
+    import dana_amd
+    from dana_amd import ops, synthetic as S, targets as T
+    from dana_amd.config import cfg
+    B = 3
+    _, _, gt, _, _ = S.episode_inputs(B, 1, 1, 600, 1000, seed=21)
+    rng = np.random.default_rng(4)
+    rois = torch.zeros(B, 2000, 5)
+    xy = rng.uniform(0, 800, size=(B, 2000, 2)); wh = rng.uniform(8, 300, size=(B, 2000, 2))
+    rois[:, :, 1:3] = torch.from_numpy(xy).float()
+    rois[:, :, 3] = torch.from_numpy(np.minimum(xy[..., 0] + wh[..., 0], 999)).float()
+    rois[:, :, 4] = torch.from_numpy(np.minimum(xy[..., 1] + wh[..., 1], 599)).float()
+    rois[:, :40, 1:] = gt[:, :1, :4] + torch.from_numpy(rng.uniform(-6, 6, size=(B, 40, 4))).float()  # some fg
+    rois[:, 1900:] = 0  # zero padding
+    for b in range(B):
+        rois[b, :, 0] = b
+    tr = cfg.TRAIN
+    np.random.seed(5)
+    ref = T.proposal_target_layer(rois, gt)
+    np.random.seed(5)
+    got = ops.proposal_target_layer(rois.to(dev), gt.to(dev), 128, 32, tr.FG_THRESH, tr.BG_THRESH_HI, tr.BG_THRESH_LO,
+                                    tr.BBOX_NORMALIZE_MEANS, tr.BBOX_NORMALIZE_STDS, tr.BBOX_INSIDE_WEIGHTS, True)
+    assert torch.equal(got[0].cpu(), ref[0])            # sampled rois: identical picks
+    assert torch.equal(got[1].cpu(), ref[1])            # labels
+    assert torch.allclose(got[2].cpu(), ref[2], atol=2e-6)  # logf vs torch.log
+    assert torch.equal(got[3].cpu(), ref[3]) and torch.equal(got[4].cpu(), ref[4])
+
+
+def test_conv_dual_segment_matches_two_single_launches(dev):
+    """query batch + support batch in one launch (dana_conv2d_nhwc_dual) == two separate launches, bitwise"""
+    import dana_amd
+    from dana_amd import ops
+    torch.manual_seed(8)
+    n0, h0, w0, n1, h1, w1, cin, cout = 2, 19, 32, 5, 20, 20, 64, 96
+    x0, x1 = torch.randn(n0 * h0 * w0, cin, device=dev), torch.randn(n1 * h1 * w1, cin, device=dev)
+    x = torch.cat([x0, x1], 0).contiguous()
+    for k, stride in ((3, 1), (1, 2), (1, 1)):
+        w = torch.randn(cout, k * k * cin, device=dev) * 0.05
+        sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+        a, oh0, ow0 = ops.conv2d_nhwc(x0, n0, h0, w0, cin, w, cout, k, k, stride, k // 2, scale=sc, shift=sh, relu=True)
+        b, oh1, ow1 = ops.conv2d_nhwc(x1, n1, h1, w1, cin, w, cout, k, k, stride, k // 2, scale=sc, shift=sh, relu=True)
+        m, _, g0, g1 = ops.conv2d_nhwc_dual(x, n0, h0, w0, n1, h1, w1, cin, w, cout, k, k, stride, k // 2, scale=sc,
+                                            shift=sh, relu=True)
+        assert g0 == (oh0, ow0) and g1 == (oh1, ow1)
+        assert torch.equal(m[:a.size(0)], a) and torch.equal(m[a.size(0):], b)
