@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "eval"], help="train-mode forward (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="collapse the model's streams to one (kernels run alone: for rocprof per-kernel averages)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch igemm table to this file")
     return ap.parse_args()
 
@@ -57,14 +59,21 @@ def cpu_baseline(args, sd):
     way = args.way if args.mode == "train" else 1
     inputs = S.episode_inputs(1, way, args.shot, args.height, args.width, seed=1996)
     np.random.seed(3)
-    t0 = time.time()
-    with torch.no_grad():
-        O.forward(sd, *inputs, args.mode == "train", way, args.shot, args.ba, nms_inclusive=False)
-    dt = time.time() - t0
+
+    def one():
+        with torch.no_grad():
+            O.forward(sd, *inputs, args.mode == "train", way, args.shot, args.ba, nms_inclusive=False)
+
+    one()  # warm-up (thread pools, oneDNN primitive caches)
+    reps, t0 = 0, time.time()
+    while reps < 20 and (time.time() - t0) < 12.0:  # bounded sample: ~10-15 s of CPU work
+        one()
+        reps += 1
+    dt = (time.time() - t0) / reps
     return {"value": round(1.0 / dt, 4), "unit": "query-images/sec", "cores": cores, "kind": "port",
-            "sample": "1 episode (1 query %dx%d + %d supports 320x320), %s-mode forward, oracle/model_ref.py on "
-                      "torch-CPU fp32 with %d threads, %.1f s" % (args.height, args.width, way * args.shot,
-                                                                 args.mode, cores, dt)}
+            "sample": "%d x 1 episode (1 query %dx%d + %d supports 320x320), %s-mode forward, oracle/model_ref.py on "
+                      "torch-CPU fp32 with %d threads, %.2f s/episode" % (reps, args.height, args.width,
+                                                                          way * args.shot, args.mode, cores, dt)}
 
 
 def main():
@@ -89,6 +98,7 @@ def main():
     model.load_state_dict(sd)
     model.to(dev)
     model.train() if training else model.eval()
+    model._single_stream = bool(args.single_stream)
     # every rank gets its own episodes (weak scaling), already resident in HBM before the timed region
     inputs = [t.to(dev) for t in S.episode_inputs(args.batch, way, args.shot, args.height, args.width,
                                                   seed=1996 + rank)]
@@ -151,7 +161,7 @@ def main():
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        model._single_stream = False
+        model._single_stream = bool(args.single_stream)
         prof, ops.PROFILE = ops.PROFILE, None
         flops = sum(p[1] for p in prof)
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)
