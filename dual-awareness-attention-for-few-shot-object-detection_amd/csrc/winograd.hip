@@ -1,0 +1,215 @@
+// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions with many channels (layer3 / layer4 conv2 of
+// the Bottlenecks, resnet.py:73-74, and RPN_Conv, rpn.py:28): 2.25x fewer multiplies than the direct
+// implicit GEMM, still exact-fp32 MFMA arithmetic (the transforms only add / halve).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        d = 4x4 input patch, g = 3x3 filter, Y = 2x2 outputs
+//
+//   wino_filter_kernel   U[xi][cout][cin]  = G g G^T            once per weight version
+//   wino_input_kernel    V[xi][tile][cin]  = B^T d B            HBM-bound, float4 lanes over channels,
+//                                                               branch-free buffer loads (padding -> 0)
+//   dana_gemm_nt(batch = 16)  M[xi][tile][cout] = V[xi] . U[xi]^T   the MFMA kernel of igemm.hip
+//   wino_output_kernel   out = relu?( (A^T M A) * scale + shift )   HBM-bound, writes NHWC with a row stride
+//
+// Planes are [16][tiles][C]: every plane is a plain K-contiguous GEMM operand, so the 16 products are
+// ONE batched launch with 16x the tiles of a single GEMM (good for the 256 CUs).
+#include "common.h"
+#include "../../include/dana_hip.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// packed weight [cout][3][3][cin] -> U[16][cout][cin]
+__global__ void __launch_bounds__(256)
+wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int cout, int cin) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)cout * cin) return;
+  const int ci = (int)(i % cin);
+  const long co = i / cin;
+  float g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[r][c] = w[((co * 3 + r) * 3 + c) * cin + ci];
+  float t[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    t[0][c] = g[0][c];
+    t[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+    t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+    t[3][c] = g[2][c];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float u0 = t[r][0], u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]), u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]),
+                u3 = t[r][2];
+    const long plane = (long)cout * cin;
+    U[(r * 4 + 0) * plane + i] = u0;
+    U[(r * 4 + 1) * plane + i] = u1;
+    U[(r * 4 + 2) * plane + i] = u2;
+    U[(r * 4 + 3) * plane + i] = u3;
+  }
+}
+
+// one lane = (tile, 4 channels)
+__global__ void __launch_bounds__(256)
+wino_input_kernel(const float* __restrict__ in, float* __restrict__ V, int H, int W, int C4, int th, int tw,
+                  long tiles, int lda, unsigned in_bytes) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tiles * C4) return;
+  const int c4 = (int)(idx % C4);
+  const long t = idx / C4;
+  const int j = (int)(t % tw);
+  const int i = (int)((t / tw) % th);
+  const int img = (int)(t / ((long)tw * th));
+  const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
+  float4 d[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = 2 * i - 1 + r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int x = 2 * j - 1 + c;
+      const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+      const unsigned off = ok ? (unsigned)((((img * H + y) * W + x) * lda + c4 * 4) * 4) : OOB;
+      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(src, (int)off, 0, 0);
+      d[r][c] = *(float4*)&v;
+    }
+  }
+  float4 tm[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {  // B^T d
+    tm[0][c] = f4sub(d[0][c], d[2][c]);
+    tm[1][c] = f4add(d[1][c], d[2][c]);
+    tm[2][c] = f4sub(d[2][c], d[1][c]);
+    tm[3][c] = f4sub(d[1][c], d[3][c]);
+  }
+  const long plane = tiles * (long)C4;  // in float4 units
+  float4* out = (float4*)V + t * C4 + c4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // (.) B
+    out[(r * 4 + 0) * plane] = f4sub(tm[r][0], tm[r][2]);
+    out[(r * 4 + 1) * plane] = f4add(tm[r][1], tm[r][2]);
+    out[(r * 4 + 2) * plane] = f4sub(tm[r][2], tm[r][1]);
+    out[(r * 4 + 3) * plane] = f4sub(tm[r][1], tm[r][3]);
+  }
+}
+
+// one lane = (tile, 4 output channels)
+__global__ void __launch_bounds__(256)
+wino_output_kernel(const float* __restrict__ M, float* __restrict__ out, const float* __restrict__ scale,
+                   const float* __restrict__ shift, int H, int W, int N4, int th, int tw, long tiles, long ldc,
+                   int relu) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tiles * N4) return;
+  const int n4 = (int)(idx % N4);
+  const long t = idx / N4;
+  const int j = (int)(t % tw);
+  const int i = (int)((t / tw) % th);
+  const long img = t / ((long)tw * th);
+  const long plane = tiles * (long)N4;
+  const float4* mp = (const float4*)M + t * N4 + n4;
+  float4 m[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m[r][c] = mp[(r * 4 + c) * plane];
+  float4 s[2][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {  // A^T m
+    s[0][c] = f4add(f4add(m[0][c], m[1][c]), m[2][c]);
+    s[1][c] = f4sub(f4sub(m[1][c], m[2][c]), m[3][c]);
+  }
+  const float4 sc = scale ? ((const float4*)scale)[n4] : make_float4(1, 1, 1, 1);
+  const float4 sh = shift ? ((const float4*)shift)[n4] : make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int y = 2 * i + r;
+    if (y >= H) break;
+    float4 y0 = f4add(f4add(s[r][0], s[r][1]), s[r][2]);
+    float4 y1 = f4sub(f4sub(s[r][1], s[r][2]), s[r][3]);
+    float4 o[2] = {y0, y1};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int x = 2 * j + c;
+      if (x >= W) break;
+      float4 v = make_float4(o[c].x * sc.x + sh.x, o[c].y * sc.y + sh.y, o[c].z * sc.z + sh.z, o[c].w * sc.w + sh.w);
+      if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      *(float4*)(out + ((img * H + y) * W + x) * ldc + n4 * 4) = v;
+    }
+  }
+}
+
+struct WinoPlan {
+  int th, tw;
+  long tiles;
+  size_t v_bytes, m_bytes, total;
+};
+WinoPlan wino_plan(int batch, int h, int w, int cin, int cout) {
+  WinoPlan p;
+  p.th = (h + 1) / 2;
+  p.tw = (w + 1) / 2;
+  p.tiles = (long)batch * p.th * p.tw;
+  p.v_bytes = dana_align_up((size_t)16 * p.tiles * cin * 4, 256);
+  p.m_bytes = dana_align_up((size_t)16 * p.tiles * cout * 4, 256);
+  p.total = p.v_bytes + p.m_bytes;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dana_winograd_filter_transform(const float* w_packed, float* u, int cout, int cin, dana_stream_t stream) {
+  DANA_CHECK_ARG(w_packed && u && cout > 0 && cin > 0, "dana_winograd_filter_transform: bad args");
+  const long total = (long)cout * cin;
+  wino_filter_kernel<<<dana_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(w_packed, u, cout, cin);
+  DANA_CHECK_LAUNCH("dana_winograd_filter_transform");
+  return DANA_OK;
+}
+
+size_t dana_conv3x3_winograd_workspace_bytes(int batch, int h, int w, int cin, int cout) {
+  if (batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+  return wino_plan(batch, h, w, cin, cout).total;
+}
+
+int dana_conv3x3_winograd_nhwc(const float* input, const float* u, float* output, const float* scale,
+                               const float* shift, int batch, int h, int w, int cin, int cout, long in_pix_stride,
+                               long out_pix_stride, int flags, void* workspace, size_t workspace_bytes,
+                               dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 4 == 0 && cout % 4 == 0,
+                 "dana_conv3x3_winograd_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(input && u && output, "dana_conv3x3_winograd_nhwc: null pointer");
+  const long lda = in_pix_stride > 0 ? in_pix_stride : cin;
+  const long ldc = out_pix_stride > 0 ? out_pix_stride : cout;
+  DANA_CHECK_ARG(lda % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)input & 15) == 0 && ((uintptr_t)output & 15) == 0,
+                 "dana_conv3x3_winograd_nhwc: strides / pointers must be 16-byte aligned");
+  const long in_bytes = (long)batch * h * w * lda * 4;
+  DANA_CHECK_ARG(in_bytes < (long)OOB, "dana_conv3x3_winograd_nhwc: input span >= 2 GiB; split the batch");
+  const WinoPlan p = wino_plan(batch, h, w, cin, cout);
+  if (!workspace || workspace_bytes < p.total) {
+    dana_set_error("dana_conv3x3_winograd_nhwc: workspace %zu < %zu", workspace_bytes, p.total);
+    return DANA_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* V = (float*)workspace;
+  float* M = (float*)((char*)workspace + p.v_bytes);
+  const int C4 = cin / 4, N4 = cout / 4;
+  wino_input_kernel<<<dana_ceil_div(p.tiles * C4, 256), 256, 0, s>>>(input, V, h, w, C4, p.th, p.tw, p.tiles, (int)lda,
+                                                                    (unsigned)in_bytes);
+  DANA_CHECK_LAUNCH("dana_conv3x3_winograd_nhwc(input transform)");
+  int rc = dana_gemm_nt(V, u, M, nullptr, nullptr, nullptr, (int)p.tiles, cout, cin, cin, cin, cout, 0, 16,
+                        p.tiles * cin, (long)cout * cin, p.tiles * cout, 1.f, 0, stream);
+  if (rc) return rc;
+  wino_output_kernel<<<dana_ceil_div(p.tiles * N4, 256), 256, 0, s>>>(M, output, scale, shift, h, w, N4, p.th, p.tw,
+                                                                     p.tiles, ldc, (flags & DANA_EPI_RELU) ? 1 : 0);
+  DANA_CHECK_LAUNCH("dana_conv3x3_winograd_nhwc(output transform)");
+  return DANA_OK;
+}
+
+}  // extern "C"

@@ -137,6 +137,8 @@ class DAnARCNN(nn.Module):
         self.pos_encoding = pos_encoding
         self.pool_feat_dim = 1024
         self.rcnn_dim = 64
+        self.use_winograd = True   # F(2x2,3x3) for the stride-1 3x3 convs with >= winograd_min_cin channels
+        self.winograd_min_cin = 256
         self.query_streams = 1
         # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
         # True: query + support batches share every trunk launch (dana_conv2d_nhwc_dual)
@@ -217,13 +219,17 @@ class DAnARCNN(nn.Module):
         if cached is None or cached[0] != dev:  # module.to(device) swaps buffers: re-collect the tensor list
             cached = (dev, list(self.state_dict(keep_vars=True).values()))
             self._consts["sig_tensors"] = cached
-        return (dev,) + tuple(t._version for t in cached[1])
+        return (dev, self.use_winograd, self.winograd_min_cin) + tuple(t._version for t in cached[1])
 
     def _conv_bn(self, conv, bn, stem=False):
         w = ops.pack_conv_weight(conv.weight, stem=stem)
         scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-        return dict(w=w, scale=scale, shift=shift, cin=conv.in_channels, cout=conv.out_channels,
-                    k=conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0])
+        d = dict(w=w, scale=scale, shift=shift, cin=conv.in_channels, cout=conv.out_channels,
+                 k=conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0], u=None)
+        if (self.use_winograd and d["k"] == 3 and d["stride"] == 1 and d["pad"] == 1 and not stem
+                and d["cin"] >= self.winograd_min_cin):
+            d["u"] = ops.winograd_filter_transform(w, d["cout"], d["cin"])
+        return d
 
     def _block_plan(self, blk):
         d = dict(c1=self._conv_bn(blk.conv1, blk.bn1), c2=self._conv_bn(blk.conv2, blk.bn2),
@@ -245,6 +251,8 @@ class DAnARCNN(nn.Module):
         p["layer4"] = [self._block_plan(b) for b in self.RCNN_top[0]]
         rpn = self.RCNN_rpn
         p["rpn_conv_w"] = ops.pack_conv_weight(rpn.RPN_Conv.weight)
+        p["rpn_conv_u"] = (ops.winograd_filter_transform(p["rpn_conv_w"], 512, rpn.din)
+                           if self.use_winograd and rpn.din >= self.winograd_min_cin else None)
         p["rpn_conv_b"] = rpn.RPN_Conv.bias.detach().contiguous()
         p["rpn_head_w"] = torch.cat([rpn.RPN_cls_score.weight.detach().view(rpn.nc_score_out, -1),
                                      rpn.RPN_bbox_pred.weight.detach().view(rpn.nc_bbox_out, -1)], 0).contiguous()
@@ -272,6 +280,9 @@ class DAnARCNN(nn.Module):
     # ---- trunk -----------------------------------------------------------------------------------
     @staticmethod
     def _conv(x, n, h, w, c, relu, residual=None, res_stride=0, out=None, out_stride=0, in_stride=0):
+        if c.get("u") is not None and residual is None:
+            return ops.conv3x3_winograd(x, n, h, w, c["cin"], c["u"], c["cout"], scale=c["scale"], shift=c["shift"],
+                                        relu=relu, in_stride=in_stride, out=out, out_stride=out_stride)
         return ops.conv2d_nhwc(x, n, h, w, c["cin"], c["w"], c["cout"], c["k"], c["k"], c["stride"], c["pad"],
                                scale=c["scale"], shift=c["shift"], residual=residual, relu=relu,
                                in_stride=in_stride, out=out, out_stride=out_stride, res_stride=res_stride)
@@ -491,8 +502,12 @@ class DAnARCNN(nn.Module):
         mark("rpn-level attention (incl. wait for support stream)")
         # -- RPN head + proposals (rpn.py:58-78, proposal_layer.py:49-190) --
         rpn = self.RCNN_rpn
-        x, _, _ = ops.conv2d_nhwc(corr, B, fh, fw, 2048, plan["rpn_conv_w"], 512, 3, 3, 1, 1, shift=plan["rpn_conv_b"],
-                                  relu=True)
+        if plan["rpn_conv_u"] is not None:
+            x, _, _ = ops.conv3x3_winograd(corr, B, fh, fw, 2048, plan["rpn_conv_u"], 512, shift=plan["rpn_conv_b"],
+                                           relu=True)
+        else:
+            x, _, _ = ops.conv2d_nhwc(corr, B, fh, fw, 2048, plan["rpn_conv_w"], 512, 3, 3, 1, 1,
+                                      shift=plan["rpn_conv_b"], relu=True)
         nh = rpn.nc_score_out + rpn.nc_bbox_out
         heads = ops.gemm_nt(x, plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])  # [B*hw][2A | 4A]
         mark("rpn conv + heads")

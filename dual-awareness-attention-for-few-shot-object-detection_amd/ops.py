@@ -294,6 +294,29 @@ def conv2d_nhwc_dual(x, n0, h0, w0, n1, h1, w1, cin, weight, cout, kh, kw, strid
     return out0, out1, (oh0, ow0), (oh1, ow1)
 
 
+def winograd_filter_transform(w_packed, cout, cin):
+    _chk(w_packed, "w_packed")
+    u = torch.empty((16, cout, cin), dtype=torch.float32, device=w_packed.device)
+    lib().call("dana_winograd_filter_transform", _p(w_packed), _p(u), cout, cin, _stream())
+    return u
+
+
+def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=False, in_stride=0, out=None,
+                     out_stride=0):
+    """stride-1 pad-1 3x3 conv through Winograd F(2x2,3x3) (u from winograd_filter_transform)."""
+    _chk(x, "x")
+    _chk(u, "u")
+    if out is None:
+        out = torch.empty((batch * h * w, cout), dtype=torch.float32, device=x.device)
+        out_stride = cout
+    ws = _ws(lib().query("dana_conv3x3_winograd_workspace_bytes", batch, h, w, cin, cout), x.device)
+    e0 = _prof_begin()
+    lib().call("dana_conv3x3_winograd_nhwc", _p(x), _p(u), _p(out), _p(scale), _p(shift), batch, h, w, cin, cout,
+               in_stride, out_stride, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
+    _prof_end(e0, "wino3x3 M=%d N=%d K=%d s1" % (batch * h * w, cout, 9 * cin), 2.0 * batch * h * w * cout * 9 * cin)
+    return out, h, w
+
+
 def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None, residual=None, ldr=0, batch=1,
             batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False, k_true=0):
     """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous."""

@@ -121,6 +121,16 @@ int dana_conv2d_nhwc_dual(const float* input, const float* weight, float* out0, 
                           long in_pix_stride, long out0_stride, long out1_stride, long res0_stride,
                           long res1_stride, int flags, dana_stream_t stream);
 
+/* Winograd F(2x2,3x3) path for the stride-1 pad-1 3x3 convs with many channels (layer3/layer4 conv2,
+ * RPN_Conv): u = dana_winograd_filter_transform(packed weight [cout][3][3][cin]) -> [16][cout][cin], then
+ * out = relu?(conv3x3(input) * scale + shift) with 2.25x fewer multiplies (exact-fp32 MFMA GEMMs). */
+int dana_winograd_filter_transform(const float* w_packed, float* u, int cout, int cin, dana_stream_t stream);
+size_t dana_conv3x3_winograd_workspace_bytes(int batch, int h, int w, int cin, int cout);
+int dana_conv3x3_winograd_nhwc(const float* input, const float* u, float* output, const float* scale,
+                               const float* shift, int batch, int h, int w, int cin, int cout, long in_pix_stride,
+                               long out_pix_stride, int flags, void* workspace, size_t workspace_bytes,
+                               dana_stream_t stream);
+
 /* nn.Linear / torch.bmm (dana.py:124,140,142,147,266-290): c[z][m][n] = epi(alpha * sum_k a[z][m][k]*b[z][n][k]).
  * Both operands K-contiguous ("NT"); nn.Linear weights [out][in] are used as stored. k % 4 == 0. */
 int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, const float* shift,
