@@ -140,6 +140,7 @@ class DAnARCNN(nn.Module):
         self.use_winograd = True   # F(2x2,3x3) for the stride-1 3x3 convs with >= winograd_min_cin channels
         self.winograd_min_cin = 256
         self.query_streams = 1
+        self.query_sequential = False  # chunks of the query batch one after the other on the main stream
         # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
         # True: query + support batches share every trunk launch (dana_conv2d_nhwc_dual)
         self.merge_trunk = False
@@ -438,8 +439,8 @@ class DAnARCNN(nn.Module):
             bounds = [B * i // qs for i in range(qs + 1)]
             for i in range(qs):
                 b0, b1 = bounds[i], bounds[i + 1]
-                if i == 0:
-                    self._rcnn_base(im_data[b0:b1], plan, out_stride=2048, out_buf=corr)
+                if i == 0 or self.query_sequential:
+                    self._rcnn_base(im_data[b0:b1], plan, out_stride=2048, out_buf=corr[b0 * fh * fw:])
                 else:
                     st_i = self._stream("query%d" % i, dev)
                     st_i.wait_event(inputs_ready)

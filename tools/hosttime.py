@@ -4,14 +4,15 @@ import dana_amd
 from dana_amd import synthetic as S, ops
 dev = torch.device('cuda:0')
 import os
-for mode in ('train', 'train-split', 'train-split2', 'train-split4'):
+for mode in ('train-split', 'train-seq2', 'train-seq4'):
     training = mode.startswith('train')
     way = 2 if training else 1
     m = dana_amd.get_model('DAnA', pretrained=False, use_BA_block=False, way=2, shot=3, classes=['fg','bg'])
     m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=11, profile='test')); m.to(dev)
     m.train() if training else m.eval()
     m.merge_trunk = (mode == 'train')
-    m.query_streams = {'train-split2': 2, 'train-split4': 4}.get(mode, 1)
+    m.query_streams = {'train-seq2': 2, 'train-seq4': 4}.get(mode, 1)
+    m.query_sequential = mode.startswith('train-seq')
     inputs = [t.to(dev) for t in S.episode_inputs(4, way, 3, 600, 1000, seed=1996)]
     np.random.seed(0)
     with torch.no_grad():
