@@ -171,6 +171,266 @@ proposal_target_gather_kernel(const float* __restrict__ rois, const float* __res
   wo[3] = (pos && inside_w.w > 0.f) ? 1.f : 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Anchor targets (lib/model/rpn/anchor_target_layer.py:48-193) and the RPN losses (rpn.py:97-115).
+// anchor_target_prepare : per image, all H*W*A anchors in (h, w, a) order: inside-image test against
+//     image 0's size (:85-86), IoU with the gt boxes, max / first-argmax over gt, per-gt max over the
+//     inside anchors (LDS atomicMax on the float bits, IoU >= 0), labels before subsampling
+//     (:109-124), ascending fg / bg index lists + counts.
+// [host: np.random.permutation draws exactly as :137-156, needs only the counts]
+// anchor_target_disable : labels[list[pos]] = -1 for the subsampled-away anchors.
+// anchor_target_outputs : materialise labels / targets / weights in the reference's layouts
+//     (only for callers that want `_AnchorTargetLayer`'s outputs; the model uses rpn_loss below).
+// rpn_loss_kernel       : fused cross-entropy over labels >= 0 and smooth-L1 (sigma 3) over fg anchors,
+//     straight from (label, argmax, anchor, gt): the four [B,4A,H,W] target tensors never exist.
+struct AnchorGeom {
+  int A, H, W, stride, n_gt;
+};
+
+__device__ __forceinline__ float4 anchor_box(const float* __restrict__ base, const AnchorGeom& g, int i) {
+  const int a = i % g.A, k = i / g.A;
+  const float sx = (float)((k % g.W) * g.stride), sy = (float)((k / g.W) * g.stride);
+  return make_float4(base[a * 4 + 0] + sx, base[a * 4 + 1] + sy, base[a * 4 + 2] + sx, base[a * 4 + 3] + sy);
+}
+
+__device__ __forceinline__ float gt_iou(float4 a, float a_area, const float* __restrict__ sg) {
+  if (sg[5] != 0.f) return 0.f;  // zero-area gt row (padding): masked to 0 (bbox_transform.py:212,216)
+  float iw = fminf(a.z, sg[2]) - fmaxf(a.x, sg[0]) + 1.f;
+  float ih = fminf(a.w, sg[3]) - fmaxf(a.y, sg[1]) + 1.f;
+  iw = iw < 0.f ? 0.f : iw;
+  ih = ih < 0.f ? 0.f : ih;
+  const float inter = iw * ih;
+  return inter / (a_area + sg[4] - inter);
+}
+
+// grid = B, block = 1024; dynamic LDS: sgt[n_gt][6] | gt_max bits[n_gt]
+__global__ void __launch_bounds__(1024)
+anchor_target_prepare_kernel(const float* __restrict__ gt, const float* __restrict__ im_info,
+                             const float* __restrict__ base, AnchorGeom g, float neg_ov, float pos_ov,
+                             float* __restrict__ labels, float* __restrict__ max_ov_out, int* __restrict__ assign,
+                             int* __restrict__ fg_list, int* __restrict__ bg_list, int* __restrict__ counts) {
+  extern __shared__ float sm[];
+  float* sgt = sm;
+  int* gmax = (int*)(sm + g.n_gt * 6);
+  __shared__ int wsum_fg[16], wsum_bg[16];
+  __shared__ int run_fg, run_bg;
+  const int b = blockIdx.x;
+  const int total = g.H * g.W * g.A;
+  for (int k = threadIdx.x; k < g.n_gt; k += blockDim.x) {
+    const float* q = gt + ((long)b * g.n_gt + k) * 5;
+    const float gw = q[2] - q[0] + 1.f, gh = q[3] - q[1] + 1.f;
+    sgt[k * 6 + 0] = q[0];
+    sgt[k * 6 + 1] = q[1];
+    sgt[k * 6 + 2] = q[2];
+    sgt[k * 6 + 3] = q[3];
+    sgt[k * 6 + 4] = gw * gh;
+    sgt[k * 6 + 5] = (gw == 1.f && gh == 1.f) ? 1.f : 0.f;
+    gmax[k] = 0;  // bits of +0.0f: overlaps are >= 0 for real anchors
+  }
+  if (threadIdx.x == 0) run_fg = run_bg = 0;
+  __syncthreads();
+  const float im_h = (float)(long)im_info[0], im_w = (float)(long)im_info[1];  // long(im_info[0][..]) of IMAGE 0
+  // pass 1: per-anchor max over gt, per-gt max over inside anchors
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const float4 a = anchor_box(base, g, i);
+    const bool inside = a.x >= 0.f && a.y >= 0.f && a.z < im_w && a.w < im_h;
+    float best = -3.4e38f;
+    int arg = 0;
+    if (inside) {
+      const float area = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+      for (int k = 0; k < g.n_gt; ++k) {
+        const float ov = gt_iou(a, area, sgt + k * 6);
+        if (ov > best) {
+          best = ov;
+          arg = k;
+        }
+        atomicMax(&gmax[k], __float_as_int(ov));
+      }
+    }
+    max_ov_out[(long)b * total + i] = inside ? best : -2.f;  // -2 marks "outside the image"
+    assign[(long)b * total + i] = arg;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < g.n_gt; k += blockDim.x)
+    if (__int_as_float(gmax[k]) == 0.f) gmax[k] = __float_as_int(1e-5f);  // :116
+  __syncthreads();
+  // pass 2: labels + ordered fg / bg lists
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i0 = 0; i0 < total; i0 += blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    bool fg = false, bg = false;
+    if (i < total) {
+      const float best = max_ov_out[(long)b * total + i];
+      float label = -1.f;
+      if (best > -1.5f) {  // inside
+        const float4 a = anchor_box(base, g, i);
+        const float area = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+        if (best < neg_ov) label = 0.f;
+        bool is_best = false;
+        for (int k = 0; k < g.n_gt; ++k)
+          is_best |= (gt_iou(a, area, sgt + k * 6) == __int_as_float(gmax[k]));
+        if (is_best) label = 1.f;
+        if (best >= pos_ov) label = 1.f;
+      }
+      labels[(long)b * total + i] = label;
+      fg = label == 1.f;
+      bg = label == 0.f;
+    }
+    const unsigned long long mf = __ballot(fg), mb = __ballot(bg);
+    if (lane == 0) {
+      wsum_fg[wave] = __builtin_popcountll(mf);
+      wsum_bg[wave] = __builtin_popcountll(mb);
+    }
+    __syncthreads();
+    int off_fg = run_fg, off_bg = run_bg;
+    for (int w = 0; w < wave; ++w) {
+      off_fg += wsum_fg[w];
+      off_bg += wsum_bg[w];
+    }
+    const unsigned long long below = (1ULL << lane) - 1;
+    if (fg) fg_list[(long)b * total + off_fg + __builtin_popcountll(mf & below)] = i;
+    if (bg) bg_list[(long)b * total + off_bg + __builtin_popcountll(mb & below)] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tf = 0, tb = 0;
+      for (int w = 0; w < 16; ++w) {
+        tf += wsum_fg[w];
+        tb += wsum_bg[w];
+      }
+      run_fg += tf;
+      run_bg += tb;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counts[b * 2 + 0] = run_fg;
+    counts[b * 2 + 1] = run_bg;
+  }
+}
+
+// disable[e] = (image << 1 | is_bg) packed in `which`, position in that image's list in `pos`
+__global__ void __launch_bounds__(256)
+anchor_target_disable_kernel(float* __restrict__ labels, const int* __restrict__ fg_list,
+                             const int* __restrict__ bg_list, const int* __restrict__ which,
+                             const int* __restrict__ pos, int n, int total) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int b = which[e] >> 1;
+  const int* list = (which[e] & 1) ? bg_list : fg_list;
+  labels[(long)b * total + list[(long)b * total + pos[e]]] = -1.f;
+}
+
+// bbox_transform_batch of (anchor, matched gt) (bbox_transform.py:36-75)
+__device__ __forceinline__ void anchor_targets4(float4 a, const float* __restrict__ q, float t[4]) {
+  const float ew = a.z - a.x + 1.0f, eh = a.w - a.y + 1.0f;
+  const float ecx = a.x + 0.5f * ew, ecy = a.y + 0.5f * eh;
+  const float gw = q[2] - q[0] + 1.0f, gh = q[3] - q[1] + 1.0f;
+  const float gcx = q[0] + 0.5f * gw, gcy = q[1] + 0.5f * gh;
+  t[0] = (gcx - ecx) / ew;
+  t[1] = (gcy - ecy) / eh;
+  t[2] = logf(gw / ew);
+  t[3] = logf(gh / eh);
+}
+
+// outputs in the reference's layouts: labels [B][A*H*W] (a-major), targets / weights [B][4A][H*W]
+__global__ void __launch_bounds__(256)
+anchor_target_outputs_kernel(const float* __restrict__ labels, const float* __restrict__ max_ov,
+                             const int* __restrict__ assign, const float* __restrict__ gt,
+                             const float* __restrict__ base, AnchorGeom g, float inside_w, float outside_w,
+                             float* __restrict__ labels_out, float* __restrict__ targets, float* __restrict__ w_in,
+                             float* __restrict__ w_out) {
+  const int b = blockIdx.y;
+  const int total = g.H * g.W * g.A, hw = g.H * g.W;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int a = i % g.A, k = i / g.A;
+  const float label = labels[(long)b * total + i];
+  labels_out[(long)b * total + a * hw + k] = label;
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  if (max_ov[(long)b * total + i] > -1.5f)
+    anchor_targets4(anchor_box(base, g, i), gt + ((long)b * g.n_gt + assign[(long)b * total + i]) * 5, t);
+  const float wi = label == 1.f ? inside_w : 0.f, wo = label >= 0.f ? outside_w : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long o = ((long)b * 4 * g.A + a * 4 + j) * hw + k;
+    targets[o] = t[j];
+    w_in[o] = wi;
+    w_out[o] = wo;
+  }
+}
+
+// partial[block] = (sum of CE over labels >= 0, count, sum of weighted smooth-L1 over fg anchors)
+__global__ void __launch_bounds__(256)
+rpn_loss_kernel(const float* __restrict__ heads, long head_row_stride, const float* __restrict__ labels,
+                const int* __restrict__ assign, const float* __restrict__ gt, const float* __restrict__ base,
+                AnchorGeom g, int B, float sigma, float inside_w, float outside_w, float* __restrict__ partial) {
+  __shared__ float red[3][4];
+  const int total = g.H * g.W * g.A;
+  const long n = (long)B * total;
+  float ce = 0.f, cnt = 0.f, sl1 = 0.f;
+  const float s2 = sigma * sigma;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)blockDim.x * gridDim.x) {
+    const int b = (int)(e / total), i = (int)(e % total);
+    const float label = labels[e];
+    if (label < 0.f) continue;
+    const int a = i % g.A, k = i / g.A;
+    const float* row = heads + ((long)b * g.H * g.W + k) * head_row_stride;
+    const float s0 = row[a], s1 = row[g.A + a];  // (bg, fg) scores of this anchor (rpn.py:47-56,98)
+    const float m = fmaxf(s0, s1);
+    const float lse = m + logf(expf(s0 - m) + expf(s1 - m));
+    ce += lse - (label == 1.f ? s1 : s0);
+    cnt += 1.f;
+    if (label == 1.f) {
+      float t[4];
+      anchor_targets4(anchor_box(base, g, i), gt + ((long)b * g.n_gt + assign[e]) * 5, t);
+      const float* bp = row + 2 * g.A + 4 * a;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // net_utils.py:71-85
+        const float d = inside_w * (bp[j] - t[j]);
+        const float ad = fabsf(d);
+        const float l = ad < 1.f / s2 ? d * d * (s2 / 2.f) : ad - 0.5f / s2;
+        sl1 += outside_w * l;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ce += __shfl_xor(ce, o);
+    cnt += __shfl_xor(cnt, o);
+    sl1 += __shfl_xor(sl1, o);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = ce;
+    red[1][wave] = cnt;
+    red[2][wave] = sl1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    partial[blockIdx.x * 3 + threadIdx.x] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void __launch_bounds__(64)
+rpn_loss_reduce_kernel(const float* __restrict__ partial, int nblocks, int B, float* __restrict__ out) {
+  float ce = 0.f, cnt = 0.f, sl1 = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 64) {
+    ce += partial[i * 3];
+    cnt += partial[i * 3 + 1];
+    sl1 += partial[i * 3 + 2];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ce += __shfl_xor(ce, o);
+    cnt += __shfl_xor(cnt, o);
+    sl1 += __shfl_xor(sl1, o);
+  }
+  if (threadIdx.x == 0) {
+    out[0] = ce / cnt;        // F.cross_entropy mean over the kept anchors (rpn.py:104)
+    out[1] = sl1 / (float)B;  // sum over dims [1,2,3], mean over the batch (rpn.py:114, net_utils.py:82-84)
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -210,6 +470,80 @@ int dana_proposal_target_gather(const float* rois, const float* gt_boxes, int B,
       rois, gt_boxes, n_rois, n_gt, gt_assignment, fg_list, bg_list, picks, fg_taken, rois_per_image, m, sd, iw,
       normalize, rois_out, labels_out, bbox_targets, inside_weights, outside_weights);
   DANA_CHECK_LAUNCH("dana_proposal_target_gather");
+  return DANA_OK;
+}
+
+int dana_anchor_target_prepare(const float* gt_boxes, const float* im_info, const float* base_anchors, int B,
+                               int A, int H, int W, int feat_stride, int n_gt, float negative_overlap,
+                               float positive_overlap, float* labels, float* max_overlaps, int* argmax,
+                               int* fg_list, int* bg_list, int* counts, dana_stream_t stream) {
+  DANA_CHECK_ARG(B >= 0 && A > 0 && H > 0 && W > 0 && n_gt > 0, "dana_anchor_target_prepare: bad shape");
+  if (B == 0) return DANA_OK;
+  DANA_CHECK_ARG(gt_boxes && im_info && base_anchors && labels && max_overlaps && argmax && fg_list && bg_list &&
+                     counts,
+                 "dana_anchor_target_prepare: null pointer");
+  DANA_CHECK_ARG((size_t)n_gt * 28 <= 48 * 1024, "dana_anchor_target_prepare: too many gt boxes");
+  AnchorGeom g = {A, H, W, feat_stride, n_gt};
+  anchor_target_prepare_kernel<<<B, 1024, (size_t)n_gt * 7 * sizeof(float), (hipStream_t)stream>>>(
+      gt_boxes, im_info, base_anchors, g, negative_overlap, positive_overlap, labels, max_overlaps, argmax, fg_list,
+      bg_list, counts);
+  DANA_CHECK_LAUNCH("dana_anchor_target_prepare");
+  return DANA_OK;
+}
+
+int dana_anchor_target_disable(float* labels, const int* fg_list, const int* bg_list, const int* which,
+                               const int* pos, int n, int anchors_per_image, dana_stream_t stream) {
+  DANA_CHECK_ARG(n >= 0 && anchors_per_image > 0, "dana_anchor_target_disable: bad shape");
+  if (n == 0) return DANA_OK;
+  DANA_CHECK_ARG(labels && fg_list && bg_list && which && pos, "dana_anchor_target_disable: null pointer");
+  anchor_target_disable_kernel<<<dana_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(labels, fg_list, bg_list,
+                                                                                    which, pos, n, anchors_per_image);
+  DANA_CHECK_LAUNCH("dana_anchor_target_disable");
+  return DANA_OK;
+}
+
+int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, const int* argmax,
+                               const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
+                               int feat_stride, int n_gt, float inside_weight, float outside_weight,
+                               float* labels_out, float* bbox_targets, float* inside_weights,
+                               float* outside_weights, dana_stream_t stream) {
+  DANA_CHECK_ARG(B >= 0 && A > 0 && H > 0 && W > 0 && n_gt > 0, "dana_anchor_target_outputs: bad shape");
+  if (B == 0) return DANA_OK;
+  DANA_CHECK_ARG(labels && max_overlaps && argmax && gt_boxes && base_anchors && labels_out && bbox_targets &&
+                     inside_weights && outside_weights,
+                 "dana_anchor_target_outputs: null pointer");
+  AnchorGeom g = {A, H, W, feat_stride, n_gt};
+  dim3 grid(dana_ceil_div((long)H * W * A, 256), B);
+  anchor_target_outputs_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(labels, max_overlaps, argmax, gt_boxes,
+                                                                      base_anchors, g, inside_weight, outside_weight,
+                                                                      labels_out, bbox_targets, inside_weights,
+                                                                      outside_weights);
+  DANA_CHECK_LAUNCH("dana_anchor_target_outputs");
+  return DANA_OK;
+}
+
+size_t dana_rpn_loss_workspace_bytes(void) { return 512 * 3 * sizeof(float); }
+
+int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels, const int* argmax,
+                  const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W, int feat_stride,
+                  int n_gt, float sigma, float inside_weight, float outside_weight, float* losses2, void* workspace,
+                  size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(B > 0 && A > 0 && H > 0 && W > 0 && n_gt > 0 && head_row_stride >= 6 * A, "dana_rpn_loss: bad shape");
+  DANA_CHECK_ARG(heads && labels && argmax && gt_boxes && base_anchors && losses2, "dana_rpn_loss: null pointer");
+  if (!workspace || workspace_bytes < dana_rpn_loss_workspace_bytes()) {
+    dana_set_error("dana_rpn_loss: workspace too small");
+    return DANA_ERR_WORKSPACE;
+  }
+  AnchorGeom g = {A, H, W, feat_stride, n_gt};
+  const long n = (long)B * H * W * A;
+  int blocks = dana_ceil_div(n, 256);
+  if (blocks > 512) blocks = 512;
+  rpn_loss_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(heads, head_row_stride, labels, argmax, gt_boxes,
+                                                           base_anchors, g, B, sigma, inside_weight, outside_weight,
+                                                           (float*)workspace);
+  DANA_CHECK_LAUNCH("dana_rpn_loss");
+  rpn_loss_reduce_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, blocks, B, losses2);
+  DANA_CHECK_LAUNCH("dana_rpn_loss(reduce)");
   return DANA_OK;
 }
 

@@ -532,22 +532,19 @@ class DAnARCNN(nn.Module):
             # host syncs (np.random needs the counts) never drain the main stream's kernel queue
             side = self._stream("targets", dev)
             side.wait_event(inputs_ready)  # NOT wait_stream(main): the trunk is already queued there
+            tr_ = cfg.TRAIN
             with torch.cuda.stream(side):
-                labels, bt, biw, bow = T.anchor_target_layer(fh, fw, gt_boxes, im_info, plan["anchors"])
-                lab = labels.view(-1)
-                keep = lab.ne(-1).nonzero().view(-1)
-                lab_keep = lab[keep].long()
-            for t_ in (bt, biw, bow, keep, lab_keep):
-                t_.record_stream(main)
+                at = ops.anchor_target_assign(gt_boxes.float(), im_info, plan["anchors"], fh, fw, rpn.feat_stride,
+                                              tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP, tr_.RPN_BATCHSIZE,
+                                              tr_.RPN_FG_FRACTION)
+            at["ibuf"].record_stream(main)
+            at["labels"].record_stream(main)
             main.wait_stream(side)
             if tl is not None:
                 tl.append(("anchor targets (host)", _time.perf_counter()))
-            heads4 = heads.view(B, fh, fw, nh)
-            rpn_cls_score = heads4[..., :rpn.nc_score_out].permute(0, 3, 1, 2)  # [B,2A,H,W] view
-            rpn_bbox_pred = heads4[..., rpn.nc_score_out:].permute(0, 3, 1, 2)
-            sc = rpn_cls_score.reshape(B, 2, A * fh, fw).permute(0, 2, 3, 1).reshape(-1, 2)
-            rpn_loss_cls = F.cross_entropy(sc[keep], lab_keep)
-            rpn_loss_bbox = T._smooth_l1_loss(rpn_bbox_pred, bt, biw, bow, sigma=3, dim=[1, 2, 3])
+            # fused RPN losses (rpn.py:97-115) straight from the head buffer [B*hw][2A | 4A]
+            rpn_l = ops.rpn_losses(heads, nh, at, sigma=3.0, inside_weight=tr_.RPN_BBOX_INSIDE_WEIGHTS[0])
+            rpn_loss_cls, rpn_loss_bbox = rpn_l[0], rpn_l[1]
             tr_ = cfg.TRAIN
             fg_per = int(np.round(tr_.FG_FRACTION * tr_.BATCH_SIZE)) or 1
             rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_layer(

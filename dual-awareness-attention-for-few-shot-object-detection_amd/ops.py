@@ -247,6 +247,77 @@ def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_
     return rois_out, labels, tgt, w_in, w_out
 
 
+def anchor_target_assign(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_stride, negative_overlap,
+                         positive_overlap, rpn_batchsize, fg_fraction):
+    """_AnchorTargetLayer (anchor_target_layer.py:48-193) up to the sampled labels: one HIP launch, one D2H
+    read of the fg/bg counts, the reference's np.random.permutation draws (:137-156), one scatter launch.
+    Returns a dict consumed by rpn_losses() / anchor_target_outputs()."""
+    import numpy as np
+    gt_boxes = _chk(gt_boxes.contiguous(), "gt_boxes")
+    im_info = _chk(im_info.contiguous(), "im_info")
+    base_anchors = _chk(base_anchors.contiguous(), "base_anchors")
+    B, n_gt, _ = gt_boxes.shape
+    A = base_anchors.shape[0]
+    total = feat_h * feat_w * A
+    dev = gt_boxes.device
+    labels = torch.empty((B, total), dtype=torch.float32, device=dev)
+    max_ov = torch.empty((B, total), dtype=torch.float32, device=dev)
+    ibuf = torch.empty((3, B, total), dtype=torch.int32, device=dev)  # argmax, fg_list, bg_list
+    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    lib().call("dana_anchor_target_prepare", _p(gt_boxes), _p(im_info), _p(base_anchors), B, A, feat_h, feat_w,
+               feat_stride, n_gt, float(negative_overlap), float(positive_overlap), _p(labels), _p(max_ov), _p(ibuf[0]),
+               _p(ibuf[1]), _p(ibuf[2]), _p(counts), _stream())
+    cnt = counts.cpu().numpy()
+    num_fg = int(fg_fraction * rpn_batchsize)
+    which, pos = [], []
+    num_examples = 0
+    for i in range(B):
+        nf, nb = int(cnt[i, 0]), int(cnt[i, 1])
+        if nf > num_fg:
+            perm = np.random.permutation(nf)[:nf - num_fg]
+            which.append(np.full(perm.shape, 2 * i, dtype=np.int32))
+            pos.append(perm.astype(np.int32))
+        fg_after = min(nf, num_fg)
+        num_bg = rpn_batchsize - fg_after
+        if nb > num_bg:
+            perm = np.random.permutation(nb)[:nb - num_bg]
+            which.append(np.full(perm.shape, 2 * i + 1, dtype=np.int32))
+            pos.append(perm.astype(np.int32))
+        num_examples = fg_after + min(nb, num_bg)  # the LAST image's count is used for all (:156)
+    if which:
+        w_np, p_np = np.concatenate(which), np.concatenate(pos)
+        host = torch.from_numpy(np.concatenate([w_np, p_np])).to(dev, non_blocking=True)
+        n = int(w_np.size)
+        lib().call("dana_anchor_target_disable", _p(labels), _p(ibuf[1]), _p(ibuf[2]), _p(host),
+                   host.data_ptr() + 4 * n, n, total, _stream())
+    return dict(labels=labels, max_ov=max_ov, argmax=ibuf[0], ibuf=ibuf, gt_boxes=gt_boxes, base_anchors=base_anchors,
+                B=B, A=A, H=feat_h, W=feat_w, stride=feat_stride, n_gt=n_gt, num_examples=max(num_examples, 1))
+
+
+def anchor_target_outputs(h, inside_weight=1.0):
+    """the four `_AnchorTargetLayer` outputs in the reference's layouts, from anchor_target_assign()'s handle"""
+    B, A, H, W = h["B"], h["A"], h["H"], h["W"]
+    dev = h["labels"].device
+    labels = torch.empty((B, 1, A * H, W), dtype=torch.float32, device=dev)
+    tgt = torch.empty((B, 4 * A, H, W), dtype=torch.float32, device=dev)
+    w_in, w_out = torch.empty_like(tgt), torch.empty_like(tgt)
+    lib().call("dana_anchor_target_outputs", _p(h["labels"]), _p(h["max_ov"]), _p(h["argmax"]), _p(h["gt_boxes"]),
+               _p(h["base_anchors"]), B, A, H, W, h["stride"], h["n_gt"], float(inside_weight),
+               1.0 / h["num_examples"], _p(labels), _p(tgt), _p(w_in), _p(w_out), _stream())
+    return labels, tgt, w_in, w_out
+
+
+def rpn_losses(heads, head_row_stride, h, sigma=3.0, inside_weight=1.0):
+    """(rpn_loss_cls, rpn_loss_bbox) of rpn.py:97-115, fused over heads[B*H*W][2A | 4A]; -> float32[2] tensor"""
+    _chk(heads, "heads")
+    out = torch.empty((2,), dtype=torch.float32, device=heads.device)
+    ws = _ws(lib().query("dana_rpn_loss_workspace_bytes"), heads.device)
+    lib().call("dana_rpn_loss", _p(heads), head_row_stride, _p(h["labels"]), _p(h["argmax"]), _p(h["gt_boxes"]),
+               _p(h["base_anchors"]), h["B"], h["A"], h["H"], h["W"], h["stride"], h["n_gt"], float(sigma),
+               float(inside_weight), 1.0 / h["num_examples"], _p(out), _p(ws), ws.numel(), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------------

@@ -205,6 +205,33 @@ int dana_proposal_target_gather(const float* rois, const float* gt_boxes, int B,
                                 float* bbox_targets, float* inside_weights, float* outside_weights,
                                 dana_stream_t stream);
 
+/* ---- anchor targets + RPN losses: lib/model/rpn/anchor_target_layer.py:48-193, rpn.py:97-115 ---------- */
+
+/* All H*W*A anchors per image in (h, w, a) order. labels[B][n] before subsampling (-1 / 0 / 1; anchors
+ * outside image 0's bounds stay -1), max_overlaps (-2 = outside), argmax over gt, ascending fg (label 1) /
+ * bg (label 0) lists and counts[B][2] for the host's np.random.permutation draws (:137-156). */
+int dana_anchor_target_prepare(const float* gt_boxes, const float* im_info, const float* base_anchors, int B,
+                               int A, int H, int W, int feat_stride, int n_gt, float negative_overlap,
+                               float positive_overlap, float* labels, float* max_overlaps, int* argmax,
+                               int* fg_list, int* bg_list, int* counts, dana_stream_t stream);
+/* labels[image][list[pos]] = -1 for n subsampled-away entries; which[e] = image*2 + (0 fg | 1 bg). */
+int dana_anchor_target_disable(float* labels, const int* fg_list, const int* bg_list, const int* which,
+                               const int* pos, int n, int anchors_per_image, dana_stream_t stream);
+/* _AnchorTargetLayer's four outputs in the reference layouts: labels_out[B][A*H*W] (a-major),
+ * bbox_targets / inside / outside weights [B][4A][H*W] (:171-191). */
+int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, const int* argmax,
+                               const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
+                               int feat_stride, int n_gt, float inside_weight, float outside_weight,
+                               float* labels_out, float* bbox_targets, float* inside_weights,
+                               float* outside_weights, dana_stream_t stream);
+/* losses2[0] = F.cross_entropy over labels >= 0 (rpn.py:97-105), losses2[1] = _smooth_l1_loss(sigma, dims 1,2,3)
+ * (rpn.py:114), fused over heads[B*H*W][row stride] = (2A cls | 4A bbox) without materialising the targets. */
+size_t dana_rpn_loss_workspace_bytes(void);
+int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels, const int* argmax,
+                  const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W, int feat_stride,
+                  int n_gt, float sigma, float inside_weight, float outside_weight, float* losses2, void* workspace,
+                  size_t workspace_bytes, dana_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

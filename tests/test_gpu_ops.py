@@ -228,3 +228,38 @@ def test_conv_dual_segment_matches_two_single_launches(dev):
                                             shift=sh, relu=True)
         assert g0 == (oh0, ow0) and g1 == (oh1, ow1)
         assert torch.equal(m[:a.size(0)], a) and torch.equal(m[a.size(0):], b)
+
+
+def test_anchor_targets_and_rpn_losses_hip_match_host_logic_same_rng(dev):
+    """HIP _AnchorTargetLayer + fused RPN losses vs the torch restatement (targets.py), same np.random stream"""
+    import torch.nn.functional as F
+    import dana_amd
+    from dana_amd import ops, synthetic as S, targets as T
+    from dana_amd.config import cfg
+    B, H, W = 3, 38, 63
+    _, im_info, gt, _, _ = S.episode_inputs(B, 1, 1, 600, 1000, seed=33)
+    base = torch.from_numpy(T.generate_anchors(scales=np.array(cfg.ANCHOR_SCALES), ratios=np.array(cfg.ANCHOR_RATIOS))).float()
+    tr = cfg.TRAIN
+    np.random.seed(9)
+    ref = T.anchor_target_layer(H, W, gt, im_info, base)
+    np.random.seed(9)
+    h = ops.anchor_target_assign(gt.to(dev), im_info.to(dev), base.to(dev), H, W, 16, tr.RPN_NEGATIVE_OVERLAP,
+                                 tr.RPN_POSITIVE_OVERLAP, tr.RPN_BATCHSIZE, tr.RPN_FG_FRACTION)
+    got = ops.anchor_target_outputs(h)
+    assert torch.equal(got[0].cpu(), ref[0])                       # labels: same anchors kept / disabled
+    assert torch.allclose(got[1].cpu(), ref[1], atol=2e-6)         # targets (logf vs torch.log)
+    assert torch.equal(got[2].cpu(), ref[2]) and torch.equal(got[3].cpu(), ref[3])
+    assert int((ref[0] == 1).sum()) > 0 and int((ref[0] == 0).sum()) > 0
+    # fused losses vs rpn.py:97-115 in torch on the same random head outputs
+    A = 12
+    heads = torch.randn(B * H * W, 6 * A) * 0.5
+    cls = heads[:, :2 * A].view(B, H, W, 2 * A).permute(0, 3, 1, 2)
+    bbox = heads[:, 2 * A:].view(B, H, W, 4 * A).permute(0, 3, 1, 2)
+    sc = cls.reshape(B, 2, A * H, W).permute(0, 2, 3, 1).reshape(-1, 2)
+    lab = ref[0].view(-1)
+    keep = lab.ne(-1).nonzero().view(-1)
+    l_cls = F.cross_entropy(sc[keep], lab[keep].long())
+    l_box = T._smooth_l1_loss(bbox, ref[1], ref[2], ref[3], sigma=3, dim=[1, 2, 3])
+    out = ops.rpn_losses(heads.to(dev), 6 * A, h, sigma=3.0).cpu()
+    assert abs(float(out[0]) - float(l_cls)) <= 1e-5 * max(1.0, abs(float(l_cls)))
+    assert abs(float(out[1]) - float(l_box)) <= 1e-5 * max(1.0, abs(float(l_box)))
