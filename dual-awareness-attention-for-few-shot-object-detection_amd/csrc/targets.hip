@@ -230,7 +230,7 @@ anchor_target_prepare_kernel(const float* __restrict__ gt, const float* __restri
   if (threadIdx.x == 0) run_fg = run_bg = 0;
   __syncthreads();
   const float im_h = (float)(long)im_info[0], im_w = (float)(long)im_info[1];  // long(im_info[0][..]) of IMAGE 0
-  // pass 1: per-anchor max over gt, per-gt max over inside anchors
+  // pass 1a: per-anchor max / first argmax over gt (zero-area gt rows are a wave-uniform shortcut)
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const float4 a = anchor_box(base, g, i);
     const bool inside = a.x >= 0.f && a.y >= 0.f && a.z < im_w && a.w < im_h;
@@ -244,11 +244,23 @@ anchor_target_prepare_kernel(const float* __restrict__ gt, const float* __restri
           best = ov;
           arg = k;
         }
-        atomicMax(&gmax[k], __float_as_int(ov));
       }
     }
     max_ov_out[(long)b * total + i] = inside ? best : -2.f;  // -2 marks "outside the image"
     assign[(long)b * total + i] = arg;
+  }
+  // pass 1b: per-gt max over the inside anchors: gt outer (uniform), anchors inner, one LDS atomic per wave
+  for (int k = 0; k < g.n_gt; ++k) {
+    if (sgt[k * 6 + 5] != 0.f) continue;  // padding row: its column is all zeros
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const float4 a = anchor_box(base, g, i);
+      if (a.x >= 0.f && a.y >= 0.f && a.z < im_w && a.w < im_h)
+        mx = fmaxf(mx, gt_iou(a, (a.z - a.x + 1.f) * (a.w - a.y + 1.f), sgt + k * 6));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&gmax[k], __float_as_int(mx));
   }
   __syncthreads();
   for (int k = threadIdx.x; k < g.n_gt; k += blockDim.x)
@@ -268,7 +280,7 @@ anchor_target_prepare_kernel(const float* __restrict__ gt, const float* __restri
         if (best < neg_ov) label = 0.f;
         bool is_best = false;
         for (int k = 0; k < g.n_gt; ++k)
-          is_best |= (gt_iou(a, area, sgt + k * 6) == __int_as_float(gmax[k]));
+          if (sgt[k * 6 + 5] == 0.f) is_best |= (gt_iou(a, area, sgt + k * 6) == __int_as_float(gmax[k]));
         if (is_best) label = 1.f;
         if (best >= pos_ov) label = 1.f;
       }
