@@ -82,11 +82,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import dana_amd
     from dana_amd import ops, synthetic as S
@@ -114,7 +114,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     barrier()

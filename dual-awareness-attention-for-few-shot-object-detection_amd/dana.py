@@ -138,7 +138,7 @@ class DAnARCNN(nn.Module):
         self.pool_feat_dim = 1024
         self.rcnn_dim = 64
         self.use_winograd = True   # F(2x2,3x3) for the stride-1 3x3 convs with >= winograd_min_cin channels
-        self.winograd_min_cin = 256
+        self.winograd_min_cin = int(__import__('os').environ.get('DANA_WINO_MIN_CIN', 256))  # tuning knob
         self.query_streams = 1
         self.query_sequential = False  # chunks of the query batch one after the other on the main stream
         # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
