@@ -147,8 +147,10 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     b_off[j] = n < p.N ? (unsigned)((n * p.ldb + c4 * 4) * 4) : OOB;
   }
 
-  float4 ra[RA], rb[RB];
-  auto load_tile = [&](int kt) {
+  // two staging register sets: the loads of K-step kt+2 are issued before the MFMAs of K-step kt, so they
+  // have two compute phases to land (and a 2-step conv has its whole K range in flight from the start)
+  float4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+  auto load_tile = [&](int kt, float4(&ra)[RA], float4(&rb)[RB]) {
     const int k0 = kt * BK;
     const bool kok = (k0 + c4 * 4) < p.K;
     int tap;
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < RB; ++j) rb[j] = ldg_b128(rb_src, (kok && b_off[j] != OOB) ? b_off[j] + k0 * 4 : OOB);
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const float4(&ra)[RA], const float4(&rb)[RB]) {
     float* as = As + buf * BM * LDS_LD;
     float* bs = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -212,13 +214,15 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   }
 
   const int nk = (p.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
+  load_tile(0, ra0, rb0);
+  if (nk > 1) load_tile(1, ra1, rb1);
+  store_tile(0, ra0, rb0);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  auto k_step = [&](int kt, float4(&rfree_a)[RA], float4(&rfree_b)[RB], const float4(&rnext_a)[RA],
+                    const float4(&rnext_b)[RB]) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);  // buffer loads in flight across the MFMAs below
+    if (kt + 2 < nk) load_tile(kt + 2, rfree_a, rfree_b);  // rfree held K-step kt, already staged in LDS
     const float* as = As + buf * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + lh * 4;
     const float* bs = Bs + buf * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + lh * 4;
 #pragma unroll
@@ -238,8 +242,12 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    if (kt + 1 < nk) store_tile(buf ^ 1, rnext_a, rnext_b);  // K-step kt+1, issued one step ago
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    k_step(kt, ra0, rb0, ra1, rb1);
+    if (kt + 1 < nk) k_step(kt + 1, ra1, rb1, ra0, rb0);
   }
 
   // ---- epilogue through LDS: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------
