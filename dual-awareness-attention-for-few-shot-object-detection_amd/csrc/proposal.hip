@@ -107,6 +107,54 @@ rois_assemble_kernel(const float4* __restrict__ boxes, const int* __restrict__ k
   o[4] = v.w;
 }
 
+__global__ void __launch_bounds__(256)
+dets_assemble_kernel(const float4* __restrict__ boxes, const float* __restrict__ scores, int R, float* __restrict__ dets) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float4 b = boxes[r];
+  float* o = dets + (long)r * 5;
+  o[0] = b.x;
+  o[1] = b.y;
+  o[2] = b.z;
+  o[3] = b.w;
+  o[4] = scores[r];
+}
+
+// inference.py:106-125 for one image: de-normalise the deltas (x stds + means), bbox_transform_inv on the
+// rois, clip to the image, divide by the image scale; score = cls_prob[:, 1], masked to -inf when it does
+// not pass `thresh` so that the descending sort puts every discarded row after the kept ones.
+__global__ void __launch_bounds__(256)
+detect_decode_kernel(const float* __restrict__ rois, const float* __restrict__ cls_prob,
+                     const float* __restrict__ bbox_pred, const float* __restrict__ im_info, int R, float4 stds,
+                     float4 means, int normalize, float thresh, float4* __restrict__ boxes, float* __restrict__ scores,
+                     int* __restrict__ count) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = false;
+  if (r < R) {
+    const float* q = rois + (long)r * 5;
+    float dx = bbox_pred[r * 4 + 0], dy = bbox_pred[r * 4 + 1], dw = bbox_pred[r * 4 + 2], dh = bbox_pred[r * 4 + 3];
+    if (normalize) {
+      dx = dx * stds.x + means.x;
+      dy = dy * stds.y + means.y;
+      dw = dw * stds.z + means.z;
+      dh = dh * stds.w + means.w;
+    }
+    const float widths = q[3] - q[1] + 1.0f, heights = q[4] - q[2] + 1.0f;
+    const float ctr_x = q[1] + 0.5f * widths, ctr_y = q[2] + 0.5f * heights;
+    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+    const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+    const float im_h = im_info[0], im_w = im_info[1], scale = im_info[2];
+    float x1 = fminf(fmaxf(pcx - 0.5f * pw, 0.f), im_w - 1.f), y1 = fminf(fmaxf(pcy - 0.5f * ph, 0.f), im_h - 1.f);
+    float x2 = fminf(fmaxf(pcx + 0.5f * pw, 0.f), im_w - 1.f), y2 = fminf(fmaxf(pcy + 0.5f * ph, 0.f), im_h - 1.f);
+    boxes[r] = make_float4(x1 / scale, y1 / scale, x2 / scale, y2 / scale);
+    const float sc = cls_prob[r * 2 + 1];
+    valid = sc > thresh;
+    scores[r] = valid ? sc : -__builtin_huge_valf();
+  }
+  const unsigned long long m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __builtin_popcountll(m));
+}
+
 int sort_end_bit(int B) {
   int bits = 0;
   while ((1 << bits) < B) ++bits;
@@ -284,6 +332,79 @@ int dana_proposal_layer(const float* cls, long cls_sb, long cls_sc, long cls_sp,
                 p.total - p.nms_ws, stream);
   if (rc) return rc;
   return dana_rois_assemble(sorted_boxes, keep, num_keep, B, p.topn, mk, post_nms_topn, rois, stream);
+}
+
+// ---- inference post-processing: inference.py:106-140 + utils.py:312-317 -------------
+struct DetectPlan {
+  size_t boxes, scores, order, sorted_scores, sorted_boxes, keep, meta, sort_ws, nms_ws, total;
+};
+static DetectPlan detect_plan(int R) {
+  DetectPlan p;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o += dana_align_up(bytes, 256);
+    return at;
+  };
+  p.boxes = take((size_t)R * 16);
+  p.scores = take((size_t)R * 4);
+  p.order = take((size_t)R * 4);
+  p.sorted_scores = take((size_t)R * 4);
+  p.sorted_boxes = take((size_t)R * 16);
+  p.keep = take((size_t)R * 4);
+  p.meta = take(16);
+  p.sort_ws = take(dana_sort_desc_workspace_bytes(1, R));
+  p.nms_ws = take(dana_nms_workspace_bytes(R, 1));
+  p.total = o;
+  return p;
+}
+
+size_t dana_detect_postprocess_workspace_bytes(int R) { return R > 0 ? detect_plan(R).total : 0; }
+
+// dets[R][5] = (x1, y1, x2, y2, score) of the kept detections in descending score order; meta[0] = number of
+// rows passing the threshold, meta[1] = number of rows NMS kept among ALL R sorted rows: the caller keeps the
+// first `kept positions < meta[0]` (rows below the threshold sort last and can never suppress a valid row).
+int dana_detect_postprocess(const float* rois, const float* cls_prob, const float* bbox_pred, const float* im_info,
+                            int R, const float* stds4, const float* means4, int normalize, float score_thresh,
+                            float nms_thresh, int nms_inclusive, float* dets, int* keep_pos, int* meta,
+                            void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(R >= 0, "dana_detect_postprocess: bad R");
+  DANA_CHECK_ARG(meta, "dana_detect_postprocess: null meta");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(meta, 0, 2 * sizeof(int), s) != hipSuccess) {
+    dana_set_error("dana_detect_postprocess: memset failed");
+    return DANA_ERR_HIP;
+  }
+  if (R == 0) return DANA_OK;
+  DANA_CHECK_ARG(rois && cls_prob && bbox_pred && im_info && stds4 && means4 && dets && keep_pos,
+                 "dana_detect_postprocess: null pointer");
+  const DetectPlan p = detect_plan(R);
+  if (!workspace || workspace_bytes < p.total) {
+    dana_set_error("dana_detect_postprocess: workspace %zu < %zu", workspace_bytes, p.total);
+    return DANA_ERR_WORKSPACE;
+  }
+  char* ws = (char*)workspace;
+  float* boxes = (float*)(ws + p.boxes);
+  float* scores = (float*)(ws + p.scores);
+  int* order = (int*)(ws + p.order);
+  float* sorted_scores = (float*)(ws + p.sorted_scores);
+  float* sorted_boxes = (float*)(ws + p.sorted_boxes);
+  const float4 sd = make_float4(stds4[0], stds4[1], stds4[2], stds4[3]);
+  const float4 mn = make_float4(means4[0], means4[1], means4[2], means4[3]);
+  detect_decode_kernel<<<dana_ceil_div(R, 256), 256, 0, s>>>(rois, cls_prob, bbox_pred, im_info, R, sd, mn, normalize,
+                                                            score_thresh, (float4*)boxes, scores, meta);
+  DANA_CHECK_LAUNCH("dana_detect_postprocess(decode)");
+  int rc = dana_sort_desc(scores, 1, R, order, sorted_scores, ws + p.sort_ws, p.nms_ws - p.sort_ws, stream);
+  if (rc) return rc;
+  rc = dana_gather_boxes(boxes, order, 1, R, R, R, sorted_boxes, stream);
+  if (rc) return rc;
+  rc = dana_nms(sorted_boxes, R, 1, nms_thresh, nms_inclusive, R, keep_pos, R, meta + 1, ws + p.nms_ws,
+                p.total - p.nms_ws, stream);
+  if (rc) return rc;
+  // dets in sorted order for every row; the caller indexes it with keep_pos
+  dets_assemble_kernel<<<dana_ceil_div(R, 256), 256, 0, s>>>((const float4*)sorted_boxes, sorted_scores, R, dets);
+  DANA_CHECK_LAUNCH("dana_detect_postprocess(assemble)");
+  return DANA_OK;
 }
 
 }  // extern "C"

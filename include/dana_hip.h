@@ -100,6 +100,17 @@ int dana_proposal_layer(const float* cls, long cls_sb, long cls_sc, long cls_sp,
                         float nms_thresh, int nms_inclusive, float* rois, void* workspace, size_t workspace_bytes,
                         dana_stream_t stream);
 
+/* Inference post-processing for one image (inference.py:106-140, utils.py:312-317): deltas*stds+means ->
+ * bbox_transform_inv on the rois -> clip_boxes -> / im_scale; rows with cls_prob[:,1] <= score_thresh sort last
+ * (score -inf); descending sort; NMS(nms_thresh). dets[R][5] holds every row in sorted order, keep_pos the kept
+ * positions; meta[0] = rows above the threshold, meta[1] = rows kept: the detections are
+ * dets[keep_pos[i]] for the i with keep_pos[i] < meta[0]. stds4 / means4 are HOST float[4]. */
+size_t dana_detect_postprocess_workspace_bytes(int R);
+int dana_detect_postprocess(const float* rois, const float* cls_prob, const float* bbox_pred, const float* im_info,
+                            int R, const float* stds4, const float* means4, int normalize, float score_thresh,
+                            float nms_thresh, int nms_inclusive, float* dets, int* keep_pos, int* meta,
+                            void* workspace, size_t workspace_bytes, dana_stream_t stream);
+
 /* ---- dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) --------------------- */
 
 /* nn.Conv2d + frozen BatchNorm2d/bias + residual + ReLU (resnet.py:66-102 Bottleneck, :109-112 stem;

@@ -485,3 +485,27 @@ def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_
         idx = torch.cat([fg, top0, top1], 0)
         loss_cls = F.cross_entropy(cls_score[idx], rois_label[idx])
     return rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, loss_cls, loss_bbox, rois_label
+
+
+# ------------------------------------------------------------------------------------------------
+# inference post-processing: inference.py:106-140, utils.py:312-317
+# ------------------------------------------------------------------------------------------------
+def postprocess(rois, cls_prob, bbox_pred, im_info, thresh=0.05, nms_thresh=0.3, nms_inclusive=True):
+    """one image: -> cls_dets [K,5] (x1,y1,x2,y2,score) in descending score order"""
+    t = CFG["TRAIN"]
+    boxes = rois[:, :, 1:5]
+    deltas = bbox_pred.view(-1, 4) * torch.tensor(t["BBOX_NORMALIZE_STDS"]) + torch.tensor(t["BBOX_NORMALIZE_MEANS"])
+    pred = clip_boxes(bbox_transform_inv(boxes, deltas.view(1, -1, 4)), im_info)
+    pred = pred / float(im_info[0][2])
+    scores = cls_prob.squeeze()
+    pred = pred.squeeze(0)
+    inds = torch.nonzero(scores[:, 1] > thresh).view(-1)
+    if inds.numel() == 0:
+        return torch.zeros(0, 5)
+    cls_scores, cls_boxes = scores[:, 1][inds], pred[inds]
+    # utils.py:313 uses torch.sort's default (unstable) order; exact score ties are therefore undefined in the
+    # reference -- the oracle (and the HIP path) break them by index (stable), tests exclude tied rows vs golden
+    _, order = torch.sort(cls_scores, dim=0, descending=True, stable=True)
+    dets = torch.cat((cls_boxes, cls_scores.unsqueeze(1)), 1)[order]
+    keep = torch.from_numpy(native.nms(cls_boxes[order].numpy(), cls_scores[order].numpy(), nms_thresh, nms_inclusive))
+    return dets[keep]

@@ -152,6 +152,33 @@ def e2e(tag, use_ba, training, B, way, shot, H, W, nms_seed=7):
     store["rpn_cls_score"] = inter["rpn_cls_score"].numpy()
     store["rpn_bbox_pred"] = inter["rpn_bbox_pred"].numpy()
     store["pooled_s"] = inter["pooled_feat"][:, ::32].numpy()
+    if not training and B == 1:
+        # inference post-processing with the reference's own functions (inference.py:106-140, utils.py:312-317)
+        ref = R.load()
+        bt, C = ref["bbox_transform"], ref["C"]
+        rois_r, prob_r, pred_r = out_ref[0], out_ref[1], out_ref[2]
+        deltas = pred_r.view(-1, 4) * torch.FloatTensor((0.1, 0.1, 0.2, 0.2)) + torch.FloatTensor((0.0, 0.0, 0.0, 0.0))
+        pb = bt.clip_boxes(bt.bbox_transform_inv(rois_r[:, :, 1:5], deltas.view(1, -1, 4), 1), im_info, 1)
+        pb = (pb / im_info[0][2].item()).squeeze()
+        sc = prob_r.squeeze()
+        for thr_tag, thr in (("t05", 0.05), ("t62", 0.62)):
+            inds = torch.nonzero(sc[:, 1] > thr).view(-1)
+            cs, cb = sc[:, 1][inds], pb[inds, :]
+            _, order = torch.sort(cs, 0, True)
+            dets = torch.cat((cb, cs.unsqueeze(1)), 1)[order]
+            keep = C.nms(cb[order, :], cs[order], 0.3)
+            dets = dets[keep.view(-1).long()]
+            d_or = O.postprocess(out_or[0], out_or[1], out_or[2], im_info, thresh=thr)
+            # exact score ties (degenerate border rois pool identical features) are ordered by torch.sort's
+            # unstable inner sort in the reference's nms (nms_cpu.cpp:24): compare the untied detections only
+            vals, cnts = np.unique(sc[:, 1].numpy(), return_counts=True)
+            tied = set(vals[cnts > 1].tolist())
+            untied = lambda d: d[[i for i in range(d.shape[0]) if float(d[i, 4]) not in tied]]  # noqa: E731
+            a, b_ = untied(dets), untied(d_or)
+            assert a.shape == b_.shape and (a - b_).abs().max().item() <= 1e-4, "postprocess mismatch"
+            store["dets_" + thr_tag] = dets.numpy()
+            store["dets_tied_scores"] = np.array(sorted(tied), dtype=np.float32)
+            print("  postprocess thresh %.2f: %d detections" % (thr, dets.shape[0]))
     store["meta"] = np.array([int(use_ba), int(training), B, way, shot, H, W, 11, 1996, nms_seed])
     save("e2e_" + tag, **store)
 

@@ -126,3 +126,32 @@ def test_model_rejects_cpu_and_bad_supports(dev):
     bad = S.episode_inputs(1, 1, 1, 96, 128, seed=1, support_size=224)
     with pytest.raises(RuntimeError, match="320x320"):
         m(*[t.to(dev) for t in bad])
+
+
+def _untied(d, tied):
+    keep = [i for i in range(d.shape[0]) if float(d[i, 4]) not in tied]
+    return d[keep]
+
+
+@pytest.mark.parametrize("tag", ["eval_small_cisa", "eval_full_ba"])
+def test_inference_postprocess_matches_oracle_and_reference_golden(golden_dir, dev, tag):
+    """SURVEY.md 8f row N1 (inference.py:106-140, utils.py:312-317): decode + threshold + sort + NMS(0.3) on device,
+    fed with the REFERENCE's forward outputs (golden), vs the reference's detections and the oracle."""
+    import dana_amd
+    from dana_amd import synthetic as S
+    from oracle import model_ref as O
+    g = _load(golden_dir, tag)
+    use_ba, training, B, way, shot, H, W = [int(v) for v in g["meta"][:7]]
+    im_info = torch.tensor([[float(H), float(W), 1.0]])
+    rois, prob, pred = torch.from_numpy(g["rois"]), torch.from_numpy(g["cls_prob"]), torch.from_numpy(g["bbox_pred"])
+    tied = set(g["dets_tied_scores"].tolist())
+    for thr, key in ((0.05, "dets_t05"), (0.62, "dets_t62")):
+        got = dana_amd.postprocess.detections(rois.to(dev), prob.to(dev), pred.to(dev), im_info.to(dev), thresh=thr,
+                                              nms_inclusive=True).cpu().numpy()
+        ref = O.postprocess(rois, prob, pred, im_info, thresh=thr, nms_inclusive=True).numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-3   # same stable tie order -> same rows
+        a, b = _untied(got, tied), _untied(g[key], tied)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-3
+    # threshold above every score -> empty result
+    none = dana_amd.postprocess.detections(rois.to(dev), prob.to(dev), pred.to(dev), im_info.to(dev), thresh=2.0)
+    assert none.shape == (0, 5)

@@ -85,3 +85,20 @@ def test_oracle_forward_reproduces_reference_outputs(golden_dir, tag):
             assert abs(float(out[i]) - float(g[name])) <= 2e-5, name
     else:
         assert out[3:] == (0, 0, 0, 0, None)
+
+
+@pytest.mark.parametrize("tag", ["eval_small_cisa", "eval_small_ba", "eval_full_ba"])
+def test_oracle_postprocess_matches_reference_detections(golden_dir, tag):
+    """inference.py:106-140 + utils.py:312-317 on the reference's own forward outputs; detections whose score is
+    exactly tied are excluded (the reference orders ties with an unstable sort inside nms, nms_cpu.cpp:24)."""
+    g = np.load(os.path.join(golden_dir, "e2e_%s.npz" % tag))
+    H, W = int(g["meta"][5]), int(g["meta"][6])
+    im_info = torch.tensor([[float(H), float(W), 1.0]])
+    tied = set(g["dets_tied_scores"].tolist())
+    for thr, key in ((0.05, "dets_t05"), (0.62, "dets_t62")):
+        d = O.postprocess(torch.from_numpy(g["rois"]), torch.from_numpy(g["cls_prob"]), torch.from_numpy(g["bbox_pred"]),
+                          im_info, thresh=thr).numpy()
+        a = d[[i for i in range(len(d)) if float(d[i, 4]) not in tied]]
+        b = g[key][[i for i in range(len(g[key])) if float(g[key][i, 4]) not in tied]]
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4
+    assert len(g["dets_t62"]) < len(g["dets_t05"])
