@@ -194,8 +194,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, sd)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier(device_ids=[local])  # the other ranks wait for rank 0's roofline pass before tearing down
         dist.destroy_process_group()
 
 
