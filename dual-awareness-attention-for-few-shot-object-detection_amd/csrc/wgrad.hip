@@ -1,0 +1,276 @@
+// Weight gradient of the NHWC convolutions / Linear layers on the fp32 matrix cores (groundwork for the
+// training step, SURVEY.md 8d variant S): the contraction runs over PIXELS,
+//
+//   dW[n][k] = sum_m dY[m][n] * X(m, k)          n = out channel, k = (kh, kw, cin), m = output pixel
+//
+// i.e. a "TN" GEMM whose reduction index is the row index of both operands. Output tile 64(n) x 64(k) per
+// workgroup (4 waves 2x2, one 32x32x2 f32 MFMA tile each), reduction in steps of 32 pixels: the dY slab
+// [32][64 n] and the implicit-im2col X slab [32][64 k] are staged with float4 loads along their contiguous
+// (channel) axis, exactly as they sit in HBM, and the MFMA fragments are read column-wise from LDS
+// (ds_read_b32, 68-dword rows: conflict-free). The pixel range is split over gridDim.z workgroups whose
+// partial tiles go to a workspace and are summed in a fixed order by a second kernel (deterministic, no
+// float atomics -- unlike the reference's cuDNN backward-filter algorithms).
+//
+// Replaces what autograd + cuDNN do for nn.Conv2d / nn.Linear weights in the reference's train step
+// (train.py:141-143: loss.backward()); BN is frozen (dana.py:362-385) so dY arrives already scaled.
+#include "common.h"
+#include "../../include/dana_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+constexpr int WLD = 68;  // LDS row stride (dwords) of a [32][64] slab
+
+struct WgradParams {
+  const float* dY;   // [M][ldy]
+  const float* X;    // NHWC input, pixel stride ldx
+  float* partial;    // [S][N][K]
+  int M, N, K;
+  int IH, IW, OH, OW, Cin, KH, KW, stride, pad;
+  int ldy, ldx;
+  int m_chunk;       // pixels per gridDim.z slice (multiple of 32)
+  unsigned y_bytes, x_bytes;
+};
+
+__device__ __forceinline__ float4 ldg_b128(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return *(float4*)&v;
+}
+
+// grid = (N/64 tiles, K/64 tiles, S); block 256
+__global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(16))) float Gs[2][32][WLD];
+  __shared__ __attribute__((aligned(16))) float Xs[2][32][WLD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int m_begin = blockIdx.z * p.m_chunk;
+  const int m_end = min(p.M, m_begin + p.m_chunk);
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, (int)p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)p.x_bytes, 0x00020000);
+
+  // the 64 k-columns of this tile lie inside ONE filter tap (Cin % 64 == 0): wave-uniform tap geometry
+  const int tap = k0 / p.Cin, cin0 = k0 - tap * p.Cin;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  // staging: thread -> (row r = tid / 16 (+16), float4 column c4 = tid % 16) of a [32][64] slab
+  const int c4 = tid & 15, r0 = tid >> 4;
+  const bool n_ok = (n0 + c4 * 4) < p.N;  // N % 4 == 0: a float4 is all-in or all-out
+
+  float4 gy[2], gx[2];
+  auto load_slab = [&](int mb) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = mb + r0 + 16 * j;
+      const bool ok = m < m_end;
+      gy[j] = ldg_b128(ysrc, (ok && n_ok) ? (unsigned)((m * p.ldy + n0 + c4 * 4) * 4) : OOB);
+      const int mm = ok ? m : 0;
+      const int ohw = p.OH * p.OW;
+      const int img = mm / ohw, rem = mm - img * ohw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+      const bool in = ok && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+      gx[j] = ldg_b128(xsrc, in ? (unsigned)((((img * p.IH + ih) * p.IW + iw) * p.ldx + cin0 + c4 * 4) * 4) : OOB);
+    }
+  };
+  auto store_slab = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *(float4*)&Gs[buf][r0 + 16 * j][c4 * 4] = gy[j];
+      *(float4*)&Xs[buf][r0 + 16 * j][c4 * 4] = gx[j];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int steps = (m_end - m_begin + 31) / 32;
+  if (steps > 0) {
+    load_slab(m_begin);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < steps) load_slab(m_begin + (s + 1) * 32);
+      const float* g = &Gs[buf][lh][wn * 32 + li];
+      const float* x = &Xs[buf][lh][wk * 32 + li];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)  // MFMA step q contracts pixels {2q, 2q+1} of the slab
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g[2 * q * WLD], x[2 * q * WLD], acc, 0, 0, 0);
+      if (s + 1 < steps) store_slab(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // C/D map: col = lane&31 (k), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (n)
+  float* out = p.partial + (long)blockIdx.z * p.N * p.K;
+  const int k = k0 + wk * 32 + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (n < p.N && k < p.K) out[(long)n * p.K + k] = acc[r];
+  }
+}
+
+// dW[i] = (accumulate ? dW[i] : 0) + sum_s partial[s][i], fixed order
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW, long n4, int S, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = accumulate ? dW[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < S; ++s) {
+    const float4 v = partial[(long)s * n4 + i];
+    a.x += v.x;
+    a.y += v.y;
+    a.z += v.z;
+    a.w += v.w;
+  }
+  dW[i] = a;
+}
+
+// packed weight [cout][kh][kw][cin] (* scale[cout]) -> data-gradient weight [cin][kh'][kw'][cout], spatially flipped
+__global__ void __launch_bounds__(256)
+dgrad_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int cout,
+                    int cin, int KH, int KW) {
+  const long total = (long)cout * cin * KH * KW;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = (int)(i % cout);
+  const int kw = (int)((i / cout) % KW);
+  const int kh = (int)((i / cout / KW) % KH);
+  const long ci = i / cout / KW / KH;
+  const float s = scale ? scale[co] : 1.f;
+  out[i] = w[(((long)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * cin + ci] * s;
+}
+
+// strided 1x1 data gradient: g_in[b][2oh*s][2ow*s][:] = compact[b][oh][ow][:], zeros elsewhere (memset by caller)
+__global__ void __launch_bounds__(256)
+upsample_scatter_kernel(const float4* __restrict__ compact, float4* __restrict__ out, int OH, int OW, int IH, int IW,
+                        int C4, int stride, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C4);
+  const int ow = (int)((i / C4) % OW);
+  const int oh = (int)((i / C4 / OW) % OH);
+  const long b = i / C4 / OW / OH;
+  out[((b * IH + (long)oh * stride) * IW + (long)ow * stride) * C4 + c] = compact[i];
+}
+
+int pick_split(int tiles, int M) {
+  int S = (1024 + tiles - 1) / tiles;  // aim for ~4 workgroups per CU
+  const int maxS = (M + 255) / 256;    // at least 8 reduction steps per slice
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  if (S > 64) S = 64;
+  return S;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dana_conv2d_wgrad_workspace_bytes(int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride,
+                                         int pad) {
+  if (batch <= 0 || cin <= 0 || cout <= 0) return 0;
+  const int oh = (in_h + 2 * pad - kh) / stride + 1, ow = (in_w + 2 * pad - kw) / stride + 1;
+  const int K = kh * kw * cin, M = batch * oh * ow;
+  const int tiles = ((cout + 63) / 64) * ((K + 63) / 64);
+  return (size_t)pick_split(tiles, M) * cout * K * sizeof(float);
+}
+
+/* dW[cout][kh][kw][cin] (the packed layout of dana_conv2d_nhwc) (+)= sum over output pixels of
+ * grad_out[m][cout] * input patch. grad_out is the gradient w.r.t. the conv output (already multiplied by the
+ * frozen-BN scale and the ReLU mask by the caller); cin % 64 == 0, cout % 4 == 0. */
+int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* grad_weight, int batch, int in_h,
+                           int in_w, int cin, int cout, int kh, int kw, int stride, int pad, long in_pix_stride,
+                           long grad_pix_stride, int accumulate, void* workspace, size_t workspace_bytes,
+                           dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && in_h > 0 && in_w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+                 "dana_conv2d_wgrad_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad_out && input && grad_weight, "dana_conv2d_wgrad_nhwc: null pointer");
+  DANA_CHECK_ARG(cin % 64 == 0 && cout % 4 == 0, "dana_conv2d_wgrad_nhwc: needs cin %% 64 == 0 and cout %% 4 == 0");
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.dY = grad_out;
+  p.X = input;
+  p.IH = in_h;
+  p.IW = in_w;
+  p.OH = (in_h + 2 * pad - kh) / stride + 1;
+  p.OW = (in_w + 2 * pad - kw) / stride + 1;
+  DANA_CHECK_ARG(p.OH > 0 && p.OW > 0, "dana_conv2d_wgrad_nhwc: empty output");
+  p.M = batch * p.OH * p.OW;
+  p.N = cout;
+  p.K = kh * kw * cin;
+  p.Cin = cin;
+  p.KH = kh;
+  p.KW = kw;
+  p.stride = stride;
+  p.pad = pad;
+  p.ldx = (int)(in_pix_stride > 0 ? in_pix_stride : cin);
+  p.ldy = (int)(grad_pix_stride > 0 ? grad_pix_stride : cout);
+  DANA_CHECK_ARG(p.ldx % 4 == 0 && p.ldy % 4 == 0 && ((uintptr_t)grad_out & 15) == 0 && ((uintptr_t)input & 15) == 0 &&
+                     ((uintptr_t)grad_weight & 15) == 0,
+                 "dana_conv2d_wgrad_nhwc: strides / pointers must be 16-byte aligned");
+  const long xb = (long)batch * in_h * in_w * p.ldx * 4, yb = (long)p.M * p.ldy * 4;
+  DANA_CHECK_ARG(xb < (long)OOB && yb < (long)OOB, "dana_conv2d_wgrad_nhwc: operand span >= 2 GiB; split the batch");
+  p.x_bytes = (unsigned)xb;
+  p.y_bytes = (unsigned)yb;
+  const int tn = (cout + 63) / 64, tk = (p.K + 63) / 64;
+  const int S = pick_split(tn * tk, p.M);
+  p.m_chunk = ((p.M + S - 1) / S + 31) / 32 * 32;
+  const size_t need = (size_t)S * cout * p.K * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("dana_conv2d_wgrad_nhwc: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  p.partial = (float*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(tn, tk, S);
+  wgrad_f32_kernel<<<grid, 256, 0, s>>>(p);
+  DANA_CHECK_LAUNCH("dana_conv2d_wgrad_nhwc");
+  const long n4 = (long)cout * p.K / 4;
+  wgrad_reduce_kernel<<<dana_ceil_div(n4, 256), 256, 0, s>>>((const float4*)workspace, (float4*)grad_weight, n4, S,
+                                                             accumulate);
+  DANA_CHECK_LAUNCH("dana_conv2d_wgrad_nhwc(reduce)");
+  return DANA_OK;
+}
+
+/* Weights for the data gradient of a stride-1 conv: out[cin][kh][kw][cout] = w[cout][KH-1-kh][KW-1-kw][cin] * scale[cout]
+ * (scale = the frozen-BN scale folded into the incoming gradient; NULL = 1). dgrad is then
+ * dana_conv2d_nhwc(grad_out, out, ..., cin<->cout swapped, same pad). */
+int dana_conv2d_dgrad_weight(const float* w_packed, const float* scale, float* out, int cout, int cin, int kh, int kw,
+                             dana_stream_t stream) {
+  DANA_CHECK_ARG(w_packed && out && cout > 0 && cin > 0 && kh > 0 && kw > 0, "dana_conv2d_dgrad_weight: bad args");
+  const long total = (long)cout * cin * kh * kw;
+  dgrad_weight_kernel<<<dana_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(w_packed, scale, out, cout, cin, kh,
+                                                                                   kw);
+  DANA_CHECK_LAUNCH("dana_conv2d_dgrad_weight");
+  return DANA_OK;
+}
+
+/* Data gradient of a strided 1x1 conv: scatter compact[batch][oh][ow][C] to out[batch][ih][iw][C] at (oh*stride,
+ * ow*stride), zero elsewhere (resnet.py:71: the stride-2 1x1 convs of the Caffe bottleneck). */
+int dana_upsample_scatter_nhwc(const float* compact, float* out, int batch, int oh, int ow, int ih, int iw,
+                               int channels, int stride, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && oh > 0 && ow > 0 && ih >= (oh - 1) * stride + 1 && iw >= (ow - 1) * stride + 1 &&
+                     channels % 4 == 0 && stride > 0,
+                 "dana_upsample_scatter_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(compact && out, "dana_upsample_scatter_nhwc: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, (size_t)batch * ih * iw * channels * sizeof(float), s) != hipSuccess) {
+    dana_set_error("dana_upsample_scatter_nhwc: memset failed");
+    return DANA_ERR_HIP;
+  }
+  const long total = (long)batch * oh * ow * (channels / 4);
+  upsample_scatter_kernel<<<dana_ceil_div(total, 256), 256, 0, s>>>((const float4*)compact, (float4*)out, oh, ow, ih,
+                                                                    iw, channels / 4, stride, total);
+  DANA_CHECK_LAUNCH("dana_upsample_scatter_nhwc");
+  return DANA_OK;
+}
+
+}  // extern "C"

@@ -539,3 +539,40 @@ def attn_softmax_unary_(scores, unary, rows, rows_per_batch, nseg, length, ld, k
                ld, kpad,
                float(unary_gamma), float(out_scale), _stream())
     return scores
+
+
+# ------------------------------------------------------------------------------------------------
+# backward building blocks (groundwork for the training step)
+# ------------------------------------------------------------------------------------------------
+def conv2d_wgrad(grad_out, x, batch, in_h, in_w, cin, cout, kh, kw, stride, pad, in_stride=0, grad_stride=0,
+                 out=None):
+    """dW in the packed layout [cout][kh*kw*cin] = sum over output pixels of grad_out^T . im2col(x)."""
+    _chk(grad_out, "grad_out")
+    _chk(x, "x")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((cout, kh * kw * cin), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().query("dana_conv2d_wgrad_workspace_bytes", batch, in_h, in_w, cin, cout, kh, kw, stride, pad),
+             x.device)
+    lib().call("dana_conv2d_wgrad_nhwc", _p(grad_out), _p(x), _p(out), batch, in_h, in_w, cin, cout, kh, kw, stride,
+               pad, in_stride, grad_stride, int(accumulate), _p(ws), ws.numel(), _stream())
+    return out
+
+
+def conv2d_dgrad(grad_out, w_packed, batch, in_h, in_w, cin, cout, kh, kw, stride, pad, scale=None):
+    """grad w.r.t. the NHWC conv input [batch*in_h*in_w][cin]; grad_out [batch*oh*ow][cout]."""
+    _chk(grad_out, "grad_out")
+    wd = torch.empty((cin, kh * kw * cout), dtype=torch.float32, device=grad_out.device)
+    lib().call("dana_conv2d_dgrad_weight", _p(_chk(w_packed, "w_packed")), _p(scale), _p(wd), cout, cin, kh, kw,
+               _stream())
+    oh = (in_h + 2 * pad - kh) // stride + 1
+    ow = (in_w + 2 * pad - kw) // stride + 1
+    if stride == 1:
+        gx, _, _ = conv2d_nhwc(grad_out, batch, oh, ow, cout, wd, cin, kh, kw, 1, kh - 1 - pad)
+        return gx
+    if kh != 1 or kw != 1 or pad != 0:
+        raise NotImplementedError("strided data gradient only for the 1x1 convs of the Caffe bottleneck")
+    compact, _, _ = conv2d_nhwc(grad_out, batch, oh, ow, cout, wd, cin, 1, 1, 1, 0)
+    gx = torch.empty((batch * in_h * in_w, cin), dtype=torch.float32, device=grad_out.device)
+    lib().call("dana_upsample_scatter_nhwc", _p(compact), _p(gx), batch, oh, ow, in_h, in_w, cin, stride, _stream())
+    return gx

@@ -243,6 +243,25 @@ int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels,
                   int n_gt, float sigma, float inside_weight, float outside_weight, float* losses2, void* workspace,
                   size_t workspace_bytes, dana_stream_t stream);
 
+/* ---- backward building blocks of the conv / Linear layers (training step, SURVEY.md 8d variant S) --------
+ * what autograd + cuDNN compute for nn.Conv2d in the reference's loss.backward() (train.py:141-143) */
+
+/* grad_weight[cout][kh][kw][cin] (+)= sum_m grad_out[m][cout] * im2col(input)[m][...]; deterministic split-M
+ * reduction through the workspace. cin % 64 == 0, cout % 4 == 0. */
+size_t dana_conv2d_wgrad_workspace_bytes(int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride,
+                                         int pad);
+int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* grad_weight, int batch, int in_h,
+                           int in_w, int cin, int cout, int kh, int kw, int stride, int pad, long in_pix_stride,
+                           long grad_pix_stride, int accumulate, void* workspace, size_t workspace_bytes,
+                           dana_stream_t stream);
+/* weights for the data gradient of a stride-1 conv: out[cin][kh][kw][cout] = w[cout][KH-1-kh][KW-1-kw][cin]*scale[cout];
+ * grad_input = dana_conv2d_nhwc(grad_out, out, cin <-> cout swapped, same kernel size / pad) */
+int dana_conv2d_dgrad_weight(const float* w_packed, const float* scale, float* out, int cout, int cin, int kh, int kw,
+                             dana_stream_t stream);
+/* data gradient of a strided 1x1 conv: scatter the compact result to the strided positions, zero elsewhere */
+int dana_upsample_scatter_nhwc(const float* compact, float* out, int batch, int oh, int ow, int ih, int iw,
+                               int channels, int stride, dana_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

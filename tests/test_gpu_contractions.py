@@ -193,3 +193,31 @@ def test_winograd_3x3_vs_torch(dev, case):
     assert (out[:, Cout:] == -7).all()
     got = ops.nhwc_to_nchw(out, N, Cout, H, W, in_stride=Cout + 8).cpu()
     _close(got, ref)
+
+
+@pytest.mark.parametrize("case", [(2, 19, 23, 64, 64, 3, 1, 1), (2, 20, 20, 256, 128, 1, 2, 0), (1, 38, 63, 256, 256, 3, 1, 1),
+                                  (3, 7, 7, 1024, 512, 1, 2, 0), (2, 12, 16, 128, 512, 1, 1, 0)])
+def test_conv_backward_blocks_vs_torch_autograd(dev, case):
+    """weight gradient (split-M TN contraction on the MFMA) and data gradient vs torch autograd in fp64"""
+    ops = _ops()
+    N, H, W, Cin, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k)).requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    oh, ow = y.shape[2:]
+    xd = ops.nchw_to_nhwc(x.detach().float().to(dev))
+    gyd = ops.nchw_to_nhwc(gy.float().to(dev)).view(-1, Cout)
+    wp = ops.pack_conv_weight(w.detach().float().to(dev))
+    dw = ops.conv2d_wgrad(gyd, xd, N, H, W, Cin, Cout, k, k, stride, pad)
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)  # packed layout [cout][kh][kw][cin]
+    _close(dw.cpu(), ref_dw, 2e-5)
+    dx = ops.conv2d_dgrad(gyd, wp, N, H, W, Cin, Cout, k, k, stride, pad)
+    ref_dx = x.grad.permute(0, 2, 3, 1).reshape(-1, Cin)
+    _close(dx.cpu(), ref_dx, 2e-5)
+    # accumulate=True adds onto an existing gradient buffer
+    acc = dw.clone()
+    ops.conv2d_wgrad(gyd, xd, N, H, W, Cin, Cout, k, k, stride, pad, out=acc)
+    _close(acc.cpu(), 2 * ref_dw, 2e-5)
