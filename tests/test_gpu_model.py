@@ -155,3 +155,24 @@ def test_inference_postprocess_matches_oracle_and_reference_golden(golden_dir, d
     # threshold above every score -> empty result
     none = dana_amd.postprocess.detections(rois.to(dev), prob.to(dev), pred.to(dev), im_info.to(dev), thresh=2.0)
     assert none.shape == (0, 5)
+
+
+@pytest.mark.parametrize("B,H,W,shot,ba", [(3, 157, 203, 1, True), (2, 130, 321, 2, False)])
+def test_eval_forward_odd_sizes_vs_oracle(dev, B, H, W, shot, ba):
+    """odd image sizes (ceil-mode maxpool edge, clipped Winograd tiles, partial igemm tiles), B > 1"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    from oracle import model_ref as O
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=ba, way=2, shot=shot, classes=["fg", "bg"])
+    sd = S.fill_state_dict(m.state_dict(), seed=21, profile="test")
+    m.load_state_dict(sd)
+    m.to(dev).eval()
+    inputs = S.episode_inputs(B, 1, shot, H, W, seed=5)
+    with torch.no_grad():
+        out = m(*[t.to(dev) for t in inputs])
+        ref = O.forward(sd, *inputs, False, 1, shot, ba, nms_inclusive=False)
+    r, rg = out[0].cpu().numpy().reshape(-1, 5), ref[0].numpy().reshape(-1, 5)
+    matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
+    assert matched.mean() >= 0.98
+    assert np.abs(out[1].cpu().numpy() - ref[1].numpy())[matched].max() <= 1e-4
+    assert np.abs(out[2].cpu().numpy() - ref[2].numpy())[matched].max() <= 1e-4
