@@ -1,0 +1,269 @@
+// Small element-wise / reduction kernels of the backward pass (training step groundwork, SURVEY.md 8d
+// variant S). The contractions of the backward (data and weight gradients) run on igemm.hip / wgrad.hip;
+// these are the HBM-bound glue between them: ReLU masks, frozen-BN row scaling of weight gradients, bias
+// gradients (column sums), packed -> OIHW weight-gradient layout, pooling adjoints, softmax adjoints.
+#include "common.h"
+#include "../../include/dana_hip.h"
+
+namespace {
+
+int grid_for(long total, int block) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 65535L * 16 ? 65535L * 16 : g));
+}
+
+// g[r][c] = act[r][c] > 0 ? g[r][c] : 0   (adjoint of ReLU; act = the saved layer OUTPUT)
+__global__ void __launch_bounds__(256)
+relu_mask_kernel(float4* __restrict__ g, const float4* __restrict__ act, int C4, long ldg4, long lda4, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const long r = i / C4;
+    const int c = (int)(i % C4);
+    float4 v = g[r * ldg4 + c];
+    const float4 a = act[r * lda4 + c];
+    v.x = a.x > 0.f ? v.x : 0.f;
+    v.y = a.y > 0.f ? v.y : 0.f;
+    v.z = a.z > 0.f ? v.z : 0.f;
+    v.w = a.w > 0.f ? v.w : 0.f;
+    g[r * ldg4 + c] = v;
+  }
+}
+
+// y[r][c] (+)= alpha * x[r][c]
+__global__ void __launch_bounds__(256)
+axpy_kernel(float4* __restrict__ y, const float4* __restrict__ x, int C4, long ldy4, long ldx4, long total, float alpha,
+            int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const long r = i / C4;
+    const int c = (int)(i % C4);
+    const float4 a = x[r * ldx4 + c];
+    float4 v = accumulate ? y[r * ldy4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x += alpha * a.x;
+    v.y += alpha * a.y;
+    v.z += alpha * a.z;
+    v.w += alpha * a.w;
+    y[r * ldy4 + c] = v;
+  }
+}
+
+// dw[n][:] *= scale[n]
+__global__ void __launch_bounds__(256)
+rowscale_kernel(float* __restrict__ dw, const float* __restrict__ scale, long K, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x)
+    dw[i] *= scale[i / K];
+}
+
+// packed [O][KH][KW][I] -> OIHW (+= into the parameter's .grad when accumulate)
+__global__ void __launch_bounds__(256)
+unpack_weight_kernel(const float* __restrict__ packed, float* __restrict__ w, int I, int KH, int KW, long total,
+                     int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int kw = (int)(i % KW);
+    const int kh = (int)((i / KW) % KH);
+    const int ci = (int)((i / KW / KH) % I);
+    const long o = i / KW / KH / I;
+    const float v = packed[((o * KH + kh) * KW + kw) * I + ci];
+    w[i] = accumulate ? w[i] + v : v;
+  }
+}
+
+// out[c] (+)= sum_r x[r][c]  -- two-stage deterministic: grid (C/64, chunks), then a tiny finisher
+constexpr int CS_ROWS = 256;
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, long rows, int C, long ld) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  float s = 0.f;
+  if (col < C)
+    for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + col];
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < C)
+    partial[(long)blockIdx.y * C + col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(256)
+colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int chunks, int C, float alpha,
+                    int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += partial[(long)k * C + c];
+  out[c] = (accumulate ? out[c] : 0.f) + alpha * s;
+}
+
+// adjoint of the k x k / stride average pool: gin[b][h][w][c] = (1/k^2) * sum of gout over the windows covering (h, w)
+__global__ void __launch_bounds__(256)
+avgpool_bwd_kernel(const float4* __restrict__ gout, float4* __restrict__ gin, int H, int W, int OH, int OW, int C4, int k,
+                   int stride, long total) {
+  const float inv = 1.f / (float)(k * k);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const int w = (int)((i / C4) % W);
+    const int h = (int)((i / C4 / W) % H);
+    const long b = i / C4 / W / H;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oh = 0; oh < OH; ++oh) {
+      if (h < oh * stride || h >= oh * stride + k) continue;
+      for (int ow = 0; ow < OW; ++ow) {
+        if (w < ow * stride || w >= ow * stride + k) continue;
+        const float4 v = gout[((b * OH + oh) * OW + ow) * C4 + c];
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+      }
+    }
+    gin[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+
+// adjoint of softmax over the last dim, in place on g: g <- p * (g - sum(p * g)); one wave per row
+__global__ void __launch_bounds__(256)
+softmax_bwd_rows_kernel(float* __restrict__ g, const float* __restrict__ p, long rows, int L, long ldg, long ldp) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* gr = g + r * ldg;
+  const float* pr = p + r * ldp;
+  float dot = 0.f;
+  for (int l = lane; l < L; l += 64) dot += gr[l] * pr[l];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  for (int l = lane; l < L; l += 64) gr[l] = pr[l] * (gr[l] - dot);
+}
+
+// tiny general GEMM for the skinny heads (N or K of 2 / 4 / 72): c[m][n] (+)= alpha * sum_k a(m,k) * b(k,n) with
+// arbitrary element strides; one lane per output element -- only for problems of a few MFLOP
+__global__ void __launch_bounds__(256)
+gemm_small_kernel(const float* __restrict__ a, long sam, long sak, const float* __restrict__ b, long sbk, long sbn,
+                  float* __restrict__ c, long scm, long scn, int M, int N, int K, float alpha, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * N) return;
+  const int n = (int)(i % N);
+  const long m = i / N;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += a[m * sam + k * sak] * b[k * sbk + n * sbn];
+  float* o = c + m * scm + n * scn;
+  *o = (accumulate ? *o : 0.f) + alpha * s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dana_relu_mask(float* grad, const float* act, long rows, int channels, long ld_grad, long ld_act,
+                   dana_stream_t stream) {
+  DANA_CHECK_ARG(rows >= 0 && channels > 0 && channels % 4 == 0, "dana_relu_mask: bad shape");
+  if (rows == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad && act, "dana_relu_mask: null pointer");
+  if (ld_grad <= 0) ld_grad = channels;
+  if (ld_act <= 0) ld_act = channels;
+  DANA_CHECK_ARG(ld_grad % 4 == 0 && ld_act % 4 == 0, "dana_relu_mask: strides %% 4 != 0");
+  const long total = rows * (channels / 4);
+  relu_mask_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((float4*)grad, (const float4*)act, channels / 4,
+                                                                          ld_grad / 4, ld_act / 4, total);
+  DANA_CHECK_LAUNCH("dana_relu_mask");
+  return DANA_OK;
+}
+
+int dana_axpy_rows(float* y, const float* x, long rows, int channels, long ld_y, long ld_x, float alpha,
+                   int accumulate, dana_stream_t stream) {
+  DANA_CHECK_ARG(rows >= 0 && channels > 0 && channels % 4 == 0, "dana_axpy_rows: bad shape");
+  if (rows == 0) return DANA_OK;
+  DANA_CHECK_ARG(y && x, "dana_axpy_rows: null pointer");
+  if (ld_y <= 0) ld_y = channels;
+  if (ld_x <= 0) ld_x = channels;
+  DANA_CHECK_ARG(ld_y % 4 == 0 && ld_x % 4 == 0, "dana_axpy_rows: strides %% 4 != 0");
+  const long total = rows * (channels / 4);
+  axpy_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((float4*)y, (const float4*)x, channels / 4, ld_y / 4,
+                                                                     ld_x / 4, total, alpha, accumulate);
+  DANA_CHECK_LAUNCH("dana_axpy_rows");
+  return DANA_OK;
+}
+
+int dana_rowscale(float* dw, const float* scale, int rows, long cols, dana_stream_t stream) {
+  DANA_CHECK_ARG(dw && scale && rows > 0 && cols > 0, "dana_rowscale: bad args");
+  const long total = (long)rows * cols;
+  rowscale_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(dw, scale, cols, total);
+  DANA_CHECK_LAUNCH("dana_rowscale");
+  return DANA_OK;
+}
+
+int dana_unpack_conv_weight_grad(const float* packed, float* w_oihw, int cout, int cin, int kh, int kw, int accumulate,
+                                 dana_stream_t stream) {
+  DANA_CHECK_ARG(packed && w_oihw && cout > 0 && cin > 0 && kh > 0 && kw > 0, "dana_unpack_conv_weight_grad: bad args");
+  const long total = (long)cout * cin * kh * kw;
+  unpack_weight_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(packed, w_oihw, cin, kh, kw, total,
+                                                                              accumulate);
+  DANA_CHECK_LAUNCH("dana_unpack_conv_weight_grad");
+  return DANA_OK;
+}
+
+size_t dana_colsum_workspace_bytes(long rows, int channels) {
+  if (rows <= 0 || channels <= 0) return 0;
+  return (size_t)((rows + CS_ROWS - 1) / CS_ROWS) * channels * sizeof(float);
+}
+
+int dana_colsum(const float* x, float* out, long rows, int channels, long ld, float alpha, int accumulate,
+                void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(rows > 0 && channels > 0 && x && out, "dana_colsum: bad args");
+  if (ld <= 0) ld = channels;
+  const size_t need = dana_colsum_workspace_bytes(rows, channels);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("dana_colsum: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  const int chunks = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+  DANA_CHECK_ARG(chunks <= 65535, "dana_colsum: too many rows");
+  dim3 grid(dana_ceil_div(channels, 64), chunks);
+  colsum_partial_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (float*)workspace, rows, channels, ld);
+  DANA_CHECK_LAUNCH("dana_colsum(partial)");
+  colsum_final_kernel<<<dana_ceil_div(channels, 256), 256, 0, (hipStream_t)stream>>>((const float*)workspace, out, chunks,
+                                                                                      channels, alpha, accumulate);
+  DANA_CHECK_LAUNCH("dana_colsum(final)");
+  return DANA_OK;
+}
+
+int dana_avgpool_backward_nhwc(const float* grad_out, float* grad_in, int batch, int height, int width, int channels,
+                               int k, int stride, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && k > 0 && stride > 0 && height >= k && width >= k && channels % 4 == 0,
+                 "dana_avgpool_backward_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad_out && grad_in, "dana_avgpool_backward_nhwc: null pointer");
+  const int oh = (height - k) / stride + 1, ow = (width - k) / stride + 1;
+  const long total = (long)batch * height * width * (channels / 4);
+  avgpool_bwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)grad_out, (float4*)grad_in,
+                                                                            height, width, oh, ow, channels / 4, k, stride,
+                                                                            total);
+  DANA_CHECK_LAUNCH("dana_avgpool_backward_nhwc");
+  return DANA_OK;
+}
+
+int dana_softmax_rows_backward(float* grad, const float* prob, long rows, int length, long ld_grad, long ld_prob,
+                               dana_stream_t stream) {
+  DANA_CHECK_ARG(rows >= 0 && length > 0, "dana_softmax_rows_backward: bad shape");
+  if (rows == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad && prob, "dana_softmax_rows_backward: null pointer");
+  if (ld_grad <= 0) ld_grad = length;
+  if (ld_prob <= 0) ld_prob = length;
+  softmax_bwd_rows_kernel<<<dana_ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(grad, prob, rows, length, ld_grad,
+                                                                                   ld_prob);
+  DANA_CHECK_LAUNCH("dana_softmax_rows_backward");
+  return DANA_OK;
+}
+
+int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const float* b, long b_stride_k, long b_stride_n,
+                    float* c, long c_stride_m, long c_stride_n, int m, int n, int k, float alpha, int accumulate,
+                    dana_stream_t stream) {
+  DANA_CHECK_ARG(m >= 0 && n >= 0 && k > 0, "dana_gemm_small: bad shape");
+  if (m == 0 || n == 0) return DANA_OK;
+  DANA_CHECK_ARG(a && b && c, "dana_gemm_small: null pointer");
+  const long total = (long)m * n;
+  gemm_small_kernel<<<dana_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(
+      a, a_stride_m, a_stride_k, b, b_stride_k, b_stride_n, c, c_stride_m, c_stride_n, m, n, k, alpha, accumulate);
+  DANA_CHECK_LAUNCH("dana_gemm_small");
+  return DANA_OK;
+}
+
+}  // extern "C"

@@ -288,7 +288,8 @@ class DAnARCNN(nn.Module):
                                scale=c["scale"], shift=c["shift"], residual=residual, relu=relu,
                                in_stride=in_stride, out=out, out_stride=out_stride, res_stride=res_stride)
 
-    def _bottleneck(self, x, n, h, w, bp, out=None, out_stride=0, in_stride=0):
+    def _bottleneck(self, x, n, h, w, bp, out=None, out_stride=0, in_stride=0, save=None):
+        """save: optional list; receives dict(x, o1, o2, o3, h1, w1) for backward.bottleneck_backward"""
         o1, h1, w1 = self._conv(x, n, h, w, bp["c1"], True, in_stride=in_stride)
         o2, _, _ = self._conv(o1, n, h1, w1, bp["c2"], True)
         if bp["ds"] is not None:
@@ -298,6 +299,8 @@ class DAnARCNN(nn.Module):
             res, rs = x, in_stride
         o3, _, _ = self._conv(o2, n, h1, w1, bp["c3"], True, residual=res, res_stride=rs, out=out,
                               out_stride=out_stride)
+        if save is not None:
+            save.append(dict(x=x, o1=o1, o2=o2, o3=o3, h1=h1, w1=w1))
         return o3, h1, w1
 
     def _rcnn_base(self, im, plan, out_stride=0, out_buf=None):

@@ -576,3 +576,62 @@ def conv2d_dgrad(grad_out, w_packed, batch, in_h, in_w, cin, cout, kh, kw, strid
     gx = torch.empty((batch * in_h * in_w, cin), dtype=torch.float32, device=grad_out.device)
     lib().call("dana_upsample_scatter_nhwc", _p(compact), _p(gx), batch, oh, ow, in_h, in_w, cin, stride, _stream())
     return gx
+
+
+def relu_mask_(grad, act, rows, channels, ld_grad=0, ld_act=0):
+    lib().call("dana_relu_mask", _p(_chk(grad, "grad")), _p(_chk(act, "act")), rows, channels, ld_grad, ld_act, _stream())
+    return grad
+
+
+def axpy_rows_(y, x, rows, channels, ld_y=0, ld_x=0, alpha=1.0, accumulate=True):
+    lib().call("dana_axpy_rows", _p(_chk(y, "y")), _p(_chk(x, "x")), rows, channels, ld_y, ld_x, float(alpha),
+               int(bool(accumulate)), _stream())
+    return y
+
+
+def rowscale_(dw, scale, rows, cols):
+    lib().call("dana_rowscale", _p(_chk(dw, "dw")), _p(_chk(scale, "scale")), rows, cols, _stream())
+    return dw
+
+
+def unpack_conv_weight_grad(packed, grad_oihw, cout, cin, kh, kw, accumulate):
+    lib().call("dana_unpack_conv_weight_grad", _p(_chk(packed, "packed")), _p(_chk(grad_oihw, "grad")), cout, cin, kh, kw,
+               int(bool(accumulate)), _stream())
+    return grad_oihw
+
+
+def colsum(x, rows, channels, ld=0, out=None, alpha=1.0):
+    _chk(x, "x")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((channels,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().query("dana_colsum_workspace_bytes", rows, channels), x.device)
+    lib().call("dana_colsum", _p(x), _p(out), rows, channels, ld, float(alpha), int(accumulate), _p(ws), ws.numel(),
+               _stream())
+    return out
+
+
+def avgpool_backward(grad_out, B, H, W, C, k, stride):
+    _chk(grad_out, "grad_out")
+    gin = torch.empty((B, H * W, C), dtype=torch.float32, device=grad_out.device)
+    lib().call("dana_avgpool_backward_nhwc", _p(grad_out), _p(gin), B, H, W, C, k, stride, _stream())
+    return gin
+
+
+def softmax_rows_backward_(grad, prob, rows, length, ld_grad=0, ld_prob=0):
+    lib().call("dana_softmax_rows_backward", _p(_chk(grad, "grad")), _p(_chk(prob, "prob")), rows, length, ld_grad,
+               ld_prob, _stream())
+    return grad
+
+
+def gemm_small(a, a_strides, b, b_strides, m, n, k, out=None, c_strides=None, alpha=1.0):
+    """c[m][n] (+)= alpha * sum_k a(m,k) b(k,n) with element strides (a: (m,k), b: (k,n), c: (m,n)); tiny problems only"""
+    _chk(a, "a")
+    _chk(b, "b")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        c_strides = (n, 1)
+    lib().call("dana_gemm_small", _p(a), a_strides[0], a_strides[1], _p(b), b_strides[0], b_strides[1], _p(out),
+               c_strides[0], c_strides[1], m, n, k, float(alpha), int(accumulate), _stream())
+    return out

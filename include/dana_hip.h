@@ -262,6 +262,25 @@ int dana_conv2d_dgrad_weight(const float* w_packed, const float* scale, float* o
 int dana_upsample_scatter_nhwc(const float* compact, float* out, int batch, int oh, int ow, int ih, int iw,
                                int channels, int stride, dana_stream_t stream);
 
+/* element-wise / reduction glue of the backward pass */
+int dana_relu_mask(float* grad, const float* act, long rows, int channels, long ld_grad, long ld_act,
+                   dana_stream_t stream);                       /* grad *= (saved output > 0) */
+int dana_axpy_rows(float* y, const float* x, long rows, int channels, long ld_y, long ld_x, float alpha,
+                   int accumulate, dana_stream_t stream);        /* y (+)= alpha * x, strided rows */
+int dana_rowscale(float* dw, const float* scale, int rows, long cols, dana_stream_t stream); /* frozen-BN scale on dW rows */
+int dana_unpack_conv_weight_grad(const float* packed, float* w_oihw, int cout, int cin, int kh, int kw, int accumulate,
+                                 dana_stream_t stream);          /* packed [O][KH][KW][I] -> OIHW (.grad layout) */
+size_t dana_colsum_workspace_bytes(long rows, int channels);
+int dana_colsum(const float* x, float* out, long rows, int channels, long ld, float alpha, int accumulate,
+                void* workspace, size_t workspace_bytes, dana_stream_t stream);   /* bias gradients, deterministic */
+int dana_avgpool_backward_nhwc(const float* grad_out, float* grad_in, int batch, int height, int width, int channels,
+                               int k, int stride, dana_stream_t stream);
+int dana_softmax_rows_backward(float* grad, const float* prob, long rows, int length, long ld_grad, long ld_prob,
+                               dana_stream_t stream);            /* grad <- p * (grad - <p, grad>) */
+int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const float* b, long b_stride_k, long b_stride_n,
+                    float* c, long c_stride_m, long c_stride_n, int m, int n, int k, float alpha, int accumulate,
+                    dana_stream_t stream);                       /* skinny heads (N or K of 2 / 4) */
+
 #ifdef __cplusplus
 }
 #endif
