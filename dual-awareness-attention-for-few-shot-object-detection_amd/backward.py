@@ -5,11 +5,17 @@ transformed weights, weight gradients on the split-M TN MFMA kernel, and the ele
 backward.hip. Frozen BatchNorm (dana.py:362-385) only scales gradients; BN parameters, conv1/bn1/layer1 get none
 (dana.py:350-360, cfg.RESNET.FIXED_BLOCKS = 1).
 
-Status: the bottleneck / conv / linear adjoints below are complete and tested against autograd
-(tests/test_gpu_backward.py); the orchestration of the full model backward is the next round's work."""
+`model_backward` is the whole-model adjoint: it consumes the context a `save_for_backward` forward left in
+`model._ctx` and accumulates `.grad` on every trainable parameter, checked against autograd of the oracle
+(tests/test_gpu_backward.py)."""
+import math
+
 import torch
+import torch.nn.functional as F
 
 from . import ops
+from . import targets as T
+from .config import cfg
 
 
 class WeightGrads:
@@ -17,8 +23,10 @@ class WeightGrads:
 
     def __init__(self):
         self.packed = {}
+        self.convs = {}
 
     def add_conv(self, key, g, x, n, h, w, c, in_stride=0, grad_stride=0):
+        self.convs[key] = c
         buf = self.packed.get(key)
         if buf is None:
             self.packed[key] = ops.conv2d_wgrad(g, x, n, h, w, c["cin"], c["cout"], c["k"], c["k"], c["stride"],
@@ -37,6 +45,10 @@ class WeightGrads:
             param.grad = torch.empty_like(param)
         ops.unpack_conv_weight_grad(buf, param.grad, c["cout"], c["cin"], c["k"], c["k"], accumulate=not fresh)
 
+    def finish_all(self, model):
+        for key in list(self.packed):
+            self.finish_conv(key, self.convs[key], model.get_parameter(key + ".weight"))
+
 
 def conv_backward(g, x, n, h, w, c, grads, key, need_dx=True, in_stride=0):
     """g: gradient w.r.t. the conv+BN output [n*oh*ow][cout] (ReLU mask already applied).
@@ -54,7 +66,7 @@ def bottleneck_backward(g_out, saved, n, h, w, bp, grads, key, need_dx=True):
     h1, w1 = saved["h1"], saved["w1"]
     m_out = n * h1 * w1
     cout = bp["c3"]["cout"]
-    g = ops.relu_mask_(g_out, saved["o3"], m_out, cout)  # through the final ReLU (resnet.py:100)
+    g = ops.relu_mask_(g_out, saved["o3"], m_out, cout, ld_act=saved.get("o3_ld", 0))  # final ReLU (resnet.py:100)
     # main branch: conv3 <- conv2 <- conv1
     g2 = conv_backward(g, saved["o2"], n, h1, w1, bp["c3"], grads, key + ".conv3")
     ops.relu_mask_(g2, saved["o2"], m_out, bp["c2"]["cout"])
@@ -69,3 +81,210 @@ def bottleneck_backward(g_out, saved, n, h, w, bp, grads, key, need_dx=True):
     elif need_dx:
         ops.axpy_rows_(dx, g, n * h * w, cout)
     return dx
+
+
+def _acc(param, g):
+    g = g.view_as(param)
+    if param.grad is None:
+        param.grad = g.clone()
+    else:
+        param.grad.add_(g)
+
+
+def _attention_backward(d_dense, ld_dd, a, unary, q, k_, s_mat, Bn, rows_b, nseg, L, Kp, dq, ugamma, k_batch, s_batch,
+                        u_batch, d_k_out, d_s_out, d_u_out):
+    """Adjoint of one dual-awareness attention  dense = ((softmax_seg(q k^T / sqrt(dq)) + ugamma u) / nseg) s
+    (dana.py:118-154 / 258-283) for Bn images of rows_b query rows each.
+      d_dense [Bn*rows_b][1024] (row stride ld_dd); a = the saved attention [Bn][rows_b][Kp]; q [Bn*rows_b][dq];
+      k_ / s_mat / unary: key, value and unary rows of image b start at b * k_batch / s_batch / u_batch (floats).
+    Accumulates into d_k_out (rows of image b at b*k_batch), d_s_out (b*s_batch), d_u_out (b*u_batch); returns d_q."""
+    dev = a.device
+    K = nseg * L
+    dA = torch.zeros((Bn, rows_b, Kp), dtype=torch.float32, device=dev)
+    ops.gemm_nt(d_dense, s_mat, rows_b, K, 1024, lda=ld_dd, out=dA, ldc=Kp, batch=Bn, batch_a=rows_b * ld_dd,
+                batch_b=s_batch, batch_c=rows_b * Kp)
+    dflat = d_dense.view(-1)
+    for b in range(Bn):  # d s[b] += a[b]^T . d_dense[b]
+        t = ops.conv2d_wgrad(a[b], dflat[b * rows_b * ld_dd:], 1, 1, rows_b, 1024, Kp, 1, 1, 1, 0, in_stride=ld_dd,
+                             grad_stride=Kp)
+        ops.axpy_rows_(d_s_out.view(-1)[b * s_batch:], t, K, 1024)
+        ops.colsum(dA[b], rows_b, K, ld=Kp, alpha=ugamma / nseg, out=d_u_out.view(-1)[b * u_batch:])
+    ops.attn_softmax_unary_backward_(dA, a, unary, Bn * rows_b, rows_b, nseg, L, Kp, Kp, ugamma, 1.0 / nseg,
+                                     1.0 / math.sqrt(dq), unary_batch_stride=u_batch)
+    kt = ops.transpose_batched(k_, Bn, K, dq, ldi=dq, ldo=Kp, in_batch=k_batch)  # [Bn][dq][Kp], zero padded
+    d_q = ops.gemm_nt(dA, kt, rows_b, dq, Kp, lda=Kp, ldb=Kp, batch=Bn, batch_a=rows_b * Kp, batch_b=dq * Kp)
+    qf = q.view(-1)
+    for b in range(Bn):  # d k[b] += dS0[b]^T . q[b]
+        t = ops.conv2d_wgrad(dA[b], qf[b * rows_b * dq:], 1, 1, rows_b, dq, Kp, 1, 1, 1, 0, grad_stride=Kp)
+        ops.axpy_rows_(d_k_out.view(-1)[b * k_batch:], t, K, dq)
+    return d_q.view(Bn * rows_b, dq)
+
+
+def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
+    """d(sum_i grad_losses[i] * loss_i)/d(parameters) for the four training losses (rpn_loss_cls, rpn_loss_bbox,
+    RCNN_loss_cls, RCNN_loss_bbox) of the last `save_for_backward` forward: what train.py:141-143's
+    `loss.backward()` computes, accumulated into `.grad` of the trainable parameters (BN, conv1 and layer1 are
+    frozen: dana.py:350-385)."""
+    ctx = model._ctx
+    plan = ctx["plan"]
+    B, shot, way, R, Ns = ctx["B"], ctx["shot"], ctx["way"], ctx["R"], ctx["Ns"]
+    fh, fw = ctx["fh"], ctx["fw"]
+    hw = fh * fw
+    P2, L = 49, 400
+    n_roi = B * R
+    d, dq = model.rpn_reduce_dim, model.rcnn_reduce_dim
+    g1, g2, g3, g4 = [float(x) for x in grad_losses]
+    corr = ctx["corr"]
+    dev = corr.device
+    grads = WeightGrads()
+    ug = model.unary_gamma
+
+    # -- seeds: d losses / d (cls_score_all, bbox_pred) (dana.py:203-217; tiny, through torch autograd) --
+    sc = ctx["cls_score_all"].detach().clone().requires_grad_(True)
+    bp_ = ctx["bbox_pred"].detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        topk = ctx["topk"]
+        seed = (g3 * F.cross_entropy(sc[topk], ctx["rois_label"][topk])
+                + g4 * T._smooth_l1_loss(bp_, ctx["rois_target"], ctx["rois_inside_ws"], ctx["rois_outside_ws"]))
+    seed.backward()
+    d_score, d_bbox = sc.grad.contiguous(), bp_.grad.contiguous()
+
+    # -- box branch: RCNN_bbox_pred <- mean <- layer4 (dana.py:246,387-389) --
+    wb = model.RCNN_bbox_pred.weight.detach()
+    _acc(model.RCNN_bbox_pred.weight, ops.gemm_small(d_bbox, (1, 4), ctx["fc7"], (2048, 1), 4, 2048, n_roi))
+    _acc(model.RCNN_bbox_pred.bias, ops.colsum(d_bbox, n_roi, 4))
+    d_fc7 = ops.gemm_small(d_bbox, (4, 1), wb, (2048, 1), n_roi, 2048, 4)
+    l4 = ctx["l4_saved"]
+    npos = l4[-1]["h1"] * l4[-1]["w1"]
+    g = ops.broadcast_rows(d_fc7, n_roi, npos, 2048, alpha=1.0 / npos)
+    for sv in reversed(l4):
+        g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"])
+    d_pooled = g  # [n_roi*49][1024]
+
+    # -- RoI-level attention heads (dana.py:248-292), positive then negative supports --
+    q_pe, q2, sp_pe, k2, un2 = ctx["q_pe"], ctx["q2"], ctx["sp_pe"], ctx["k2"], ctx["un2"]
+    K2, K2p = ctx["K2"], ctx["K2p"]
+    wt = model.rcnn_transform_layer.weight.detach()
+    w1 = model.output_score_layer.linear1.weight.detach()
+    w2 = model.output_score_layer.linear2.weight.detach()
+    rd = model.rcnn_dim
+    nhid = w1.size(0)
+    d_q2 = torch.zeros((n_roi * P2, dq), dtype=torch.float32, device=dev)
+    d_trq = torch.zeros((n_roi * P2, rd), dtype=torch.float32, device=dev)
+    d_sp_pe = torch.zeros((Ns * P2, 1024), dtype=torch.float32, device=dev)
+    d_k2 = torch.zeros((Ns * P2, dq), dtype=torch.float32, device=dev)
+    d_un2 = torch.zeros((Ns, P2), dtype=torch.float32, device=dev)
+    d_wt = torch.zeros_like(wt)
+    for hi, hc in enumerate(ctx["heads"]):
+        off = hc["offset"]
+        ds = d_score[hi * n_roi:(hi + 1) * n_roi].contiguous()
+        _acc(model.output_score_layer.linear2.weight, ops.gemm_small(ds, (1, 2), hc["hid"], (nhid, 1), 2, nhid, n_roi))
+        _acc(model.output_score_layer.linear2.bias, ops.colsum(ds, n_roi, 2))
+        d_hid = ops.gemm_small(ds, (2, 1), w2, (nhid, 1), n_roi, nhid, 2)
+        ops.relu_mask_(d_hid, hc["hid"], n_roi, nhid)
+        dw1, db1, d_tr = ops.linear_backward(d_hid, hc["tr"], w1, n_roi, nhid, P2 * rd)
+        _acc(model.output_score_layer.linear1.weight, dw1)
+        _acc(model.output_score_layer.linear1.bias, db1)
+        ops.axpy_rows_(d_trq, d_tr, n_roi * P2, rd)
+        dwt_d, _, d_dense = ops.linear_backward(d_tr, hc["dense"], wt.view(-1)[1024:], n_roi * P2, rd, 1024, ldw=2048)
+        ops.axpy_rows_(d_wt.view(-1)[1024:], dwt_d, rd, 1024, ld_y=2048)
+        d_qh = _attention_backward(d_dense, 1024, hc["sc2"], un2.view(-1)[off * P2:], q2, k2.view(-1)[off * P2 * dq:],
+                                   sp_pe.view(-1)[off * P2 * 1024:], B, R * P2, shot, P2, K2p, dq, ug,
+                                   way * shot * P2 * dq, way * shot * P2 * 1024, way * shot * P2,
+                                   d_k2.view(-1)[off * P2 * dq:], d_sp_pe.view(-1)[off * P2 * 1024:],
+                                   d_un2.view(-1)[off * P2:])
+        ops.axpy_rows_(d_q2, d_qh, n_roi * P2, dq)
+
+    # -- RoI-level query side: Q projection + the q half of rcnn_transform_layer; PE is additive --
+    ops.colmean_sub_(d_q2, n_roi, P2, dq)
+    wq2 = model.rcnn_adapt_q_layer.weight.detach()
+    dwq2, dbq2, d_q_pe = ops.linear_backward(d_q2, q_pe, wq2, n_roi * P2, dq, 1024)
+    _acc(model.rcnn_adapt_q_layer.weight, dwq2)
+    _acc(model.rcnn_adapt_q_layer.bias, dbq2)
+    dwt_q, dbt, _ = ops.linear_backward(d_trq, q_pe, wt, n_roi * P2, rd, 1024, ldw=2048, dx_out=d_q_pe, dx_ld=1024)
+    ops.axpy_rows_(d_wt, dwt_q, rd, 1024, ld_y=2048)
+    _acc(model.rcnn_transform_layer.weight, d_wt)
+    _acc(model.rcnn_transform_layer.bias, dbt)
+    ops.axpy_rows_(d_pooled, d_q_pe, n_roi * P2, 1024)
+    d_bf = ops.roi_align_backward(d_pooled.view(n_roi, 7, 7, 1024), ctx["rois"].view(-1, 5), 1.0 / 16.0, 7, 7, B, 1024,
+                                  fh, fw, 0, layout=ops.NHWC)  # [B][fh][fw][1024]
+
+    # -- RoI-level support side: K projection, unary term, PE, 14x14 average pool (dana.py:105-108,271-277) --
+    ops.colmean_sub_(d_k2, Ns, P2, dq)
+    wk2 = model.rcnn_adapt_k_layer.weight.detach()
+    dwk2, dbk2, _ = ops.linear_backward(d_k2, sp_pe, wk2, Ns * P2, dq, 1024, dx_out=d_sp_pe, dx_ld=1024)
+    _acc(model.rcnn_adapt_k_layer.weight, dwk2)
+    _acc(model.rcnn_adapt_k_layer.bias, dbk2)
+    ops.softmax_rows_backward_(d_un2, un2, Ns, P2)
+    wu2 = model.rcnn_unary_layer.weight.detach()
+    _acc(model.rcnn_unary_layer.weight, ops.rowdot_backward(sp_pe, d_un2, wu2, Ns * P2, 1024, grad_x=d_sp_pe))
+    _acc(model.rcnn_unary_layer.bias, ops.colsum(d_un2, Ns * P2, 1))
+    d_sup = ops.avgpool_backward(d_sp_pe, Ns, 20, 20, 1024, 14, 1)  # [Ns][400][1024]
+
+    # -- RPN: losses -> heads -> 3x3 conv (rpn.py:58-115) --
+    rpn = model.RCNN_rpn
+    nh = ctx["nh"]
+    d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
+                                    inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0])
+    dwh, dbh, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512)
+    ns = rpn.nc_score_out
+    _acc(rpn.RPN_cls_score.weight, dwh[:ns])
+    _acc(rpn.RPN_cls_score.bias, dbh[:ns])
+    _acc(rpn.RPN_bbox_pred.weight, dwh[ns:])
+    _acc(rpn.RPN_bbox_pred.bias, dbh[ns:])
+    ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
+    c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None)
+    grads.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn)
+    _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
+    d_corr = ops.conv2d_dgrad(d_x, plan["rpn_conv_w"], B, fh, fw, rpn.din, 512, 3, 3, 1, 1)  # [B*hw][2048]
+
+    # -- RPN-level attention (dana.py:118-154): corr = [base_feat | dense] --
+    K1 = shot * L
+    s_pe, kp, qp, unary = ctx["s_pe"], ctx["kp"], ctx["qp"], ctx["unary"]
+    d_s_pe = torch.zeros((B, K1, 1024), dtype=torch.float32, device=dev)
+    d_kp = torch.zeros((B * K1, d), dtype=torch.float32, device=dev)
+    d_un = torch.zeros((B * shot, L), dtype=torch.float32, device=dev)
+    d_qp = _attention_backward(d_corr.view(-1)[1024:], 2048, ctx["scores"], unary, qp, kp, s_pe, B, hw, shot, L, K1, d,
+                               ug, K1 * d, K1 * 1024, K1, d_kp, d_s_pe, d_un)
+    ops.colmean_sub_(d_qp, B, hw, d)
+    ops.colmean_sub_(d_kp, B * shot, L, d)
+    wq = model.rpn_adapt_q_layer.weight.detach()
+    dwq, dbq, _ = ops.linear_backward(d_qp, corr, wq, B * hw, d, 1024, ldx=2048, dx_out=d_corr, dx_ld=2048)
+    _acc(model.rpn_adapt_q_layer.weight, dwq)
+    _acc(model.rpn_adapt_q_layer.bias, dbq)
+    wk = model.rpn_adapt_k_layer.weight.detach()
+    dwk, dbk, _ = ops.linear_backward(d_kp, s_pe, wk, B * K1, d, 1024, dx_out=d_s_pe, dx_ld=1024)
+    _acc(model.rpn_adapt_k_layer.weight, dwk)
+    _acc(model.rpn_adapt_k_layer.bias, dbk)
+    ops.softmax_rows_backward_(d_un, unary, B * shot, L)
+    wu = model.rpn_unary_layer.weight.detach()
+    _acc(model.rpn_unary_layer.weight, ops.rowdot_backward(s_pe, d_un, wu, B * K1, 1024, grad_x=d_s_pe))
+    _acc(model.rpn_unary_layer.bias, ops.colsum(d_un, B * K1, 1))
+    if model.semantic_enhance:  # BA block (dana.py:133-137)
+        s_pre, ba_w = ctx["s_pre"], ctx["ba_w"]
+        G = B * shot
+        gvec = torch.empty((G, 1024), dtype=torch.float32, device=dev)
+        gsum = torch.empty((G, 1024), dtype=torch.float32, device=dev)
+        dsf, spf = d_s_pe.view(-1), s_pre.view(-1)
+        for gi in range(G):
+            gv = ops.gemm_small(ba_w.view(-1)[gi * L:], (0, 1), spf[gi * L * 1024:], (1024, 1), 1, 1024, L)
+            gvec[gi].copy_(gv.view(-1))
+            gsum[gi].copy_(ops.colsum(dsf[gi * L * 1024:], L, 1024))
+        d_w = ops.ba_backward_(d_s_pe, s_pre, ba_w, gvec, gsum, G, L, 1024, gamma=model.channel_gamma, slope=0.01)
+        ops.softmax_rows_backward_(d_w, ba_w, G, L)
+        wc = model.rpn_channel_k_layer.weight.detach()
+        _acc(model.rpn_channel_k_layer.weight, ops.rowdot_backward(s_pre, d_w, wc, G * L, 1024, grad_x=d_s_pe))
+        _acc(model.rpn_channel_k_layer.bias, ops.colsum(d_w, G * L, 1))
+    for b in range(B):  # the positive supports' PE-added maps (dana.py:103,130)
+        ops.axpy_rows_(d_sup.view(-1)[b * way * shot * L * 1024:], d_s_pe[b], K1, 1024)
+
+    # -- trunk: query (RoIAlign + RPN paths meet in base_feat) and supports; layer3, layer2 (layer1 is frozen) --
+    ops.axpy_rows_(d_corr, d_bf, B * hw, 1024, ld_y=2048)
+    g = torch.empty((B * hw, 1024), dtype=torch.float32, device=dev)
+    ops.axpy_rows_(g, d_corr, B * hw, 1024, ld_x=2048, accumulate=False)
+    for saved, gg in ((ctx["q_saved"], g), (ctx["s_saved"], d_sup.view(Ns * L, 1024))):
+        for i, sv in enumerate(reversed(saved)):
+            gg = bottleneck_backward(gg, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"],
+                                     need_dx=i < len(saved) - 1)
+    grads.finish_all(model)
+    model._ctx = None

@@ -267,3 +267,246 @@ int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const floa
 }
 
 }  // extern "C"
+
+// ---- attention adjoints ---------------------------------------------------------------------------------
+namespace {
+
+// adjoint of dana_rowdot (nn.Linear(dim, 1)): partial[chunk][c] = sum_r dl[r] * x[r][c]  (-> dw by colsum_final)
+// and, when dx is given, dx[r][c] += dl[r] * w[c].
+__global__ void __launch_bounds__(256)
+rowdot_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dl, const float* __restrict__ w,
+                  float* __restrict__ dx, float* __restrict__ partial, long rows, int C, long ld_x, long ld_dx) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  float s = 0.f;
+  if (col < C) {
+    const float wc = w[col];
+    for (long r = r0 + rl; r < r1; r += 4) {
+      const float d = dl[r];
+      s += d * x[r * ld_x + col];
+      if (dx) dx[r * ld_dx + col] += d * wc;
+    }
+  }
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < C)
+    partial[(long)blockIdx.y * C + col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// out[g][p][c] (+)= alpha * in[g][c]   (adjoint of a mean / sum over p)
+__global__ void __launch_bounds__(256)
+broadcast_rows_kernel(const float4* __restrict__ in, float4* __restrict__ out, long groups, int P, int C4, float alpha,
+                      int accumulate) {
+  const long total = groups * P * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const long g = i / C4 / P;
+    float4 v = in[g * C4 + c];
+    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+    if (accumulate) {
+      const float4 o = out[i];
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    out[i] = v;
+  }
+}
+
+// BA block adjoint, second half (dana.py:133-137): with g[c] = sum_l w[l] S[l][c] and S' = S + gamma * leaky(g):
+//   dg[c] = gamma * leaky'(g[c]) * colsum_l(dS')[c];   dS[l][c] = dS'[l][c] + w[l] * dg[c];   dw[l] = sum_c S[l][c] dg[c]
+// one wave per row (group, l); gsum = colsum_l(dS') [groups][C], gvec = g [groups][C]
+__global__ void __launch_bounds__(256)
+ba_bwd_kernel(float* __restrict__ dS, const float* __restrict__ S, const float* __restrict__ wgt,
+              const float* __restrict__ gvec, const float* __restrict__ gsum, float* __restrict__ dw, long rows, int L, int C,
+              float gamma, float slope) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long grp = row / L;
+  const float wl = wgt[row];
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float gv = gvec[grp * C + c];
+    const float dg = gamma * (gv > 0.f ? 1.f : slope) * gsum[grp * C + c];
+    acc += S[row * C + c] * dg;
+    dS[row * C + c] += wl * dg;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) dw[row] = acc;
+}
+
+// A = (softmax_seg(S0) + ugamma * u) * out_scale was formed in place by attn_softmax_unary_kernel; here, in
+// place on dA (same [rows][ld] shape): p = A / out_scale - ugamma * u, g = dA * out_scale,
+// dS0 = alpha * p * (g - <p, g>) per segment; pad columns are zeroed. One wave per row.
+__global__ void __launch_bounds__(256)
+attn_softmax_unary_bwd_kernel(float* __restrict__ dA, const float* __restrict__ A, const float* __restrict__ unary,
+                              long rows, long rows_per_batch, long unary_batch_stride, int nseg, int L, long ld,
+                              int kpad, float ugamma, float out_scale, float alpha) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* g = dA + row * ld;
+  const float* a = A + row * ld;
+  const float* u = unary + (row / rows_per_batch) * unary_batch_stride;
+  const float inv = 1.f / out_scale;
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    float dot = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float p = a[sgm * L + l] * inv - ugamma * u[sgm * L + l];
+      dot += p * (g[sgm * L + l] * out_scale);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    for (int l = lane; l < L; l += 64) {
+      const float p = a[sgm * L + l] * inv - ugamma * u[sgm * L + l];
+      g[sgm * L + l] = alpha * p * (g[sgm * L + l] * out_scale - dot);
+    }
+  }
+  for (int l = nseg * L + lane; l < kpad; l += 64) g[l] = 0.f;
+}
+
+struct AnchorGeomB {
+  int A, H, W, stride, n_gt;
+};
+__device__ __forceinline__ float4 anchor_box_b(const float* __restrict__ base, const AnchorGeomB& g, int i) {
+  const int a = i % g.A, k = i / g.A;
+  const float sx = (float)((k % g.W) * g.stride), sy = (float)((k / g.W) * g.stride);
+  return make_float4(base[a * 4 + 0] + sx, base[a * 4 + 1] + sy, base[a * 4 + 2] + sx, base[a * 4 + 3] + sy);
+}
+
+// d heads of the fused RPN losses (rpn_loss_kernel): d_heads[B*H*W][row stride] zero-initialised by the caller
+//   cls : (softmax(s) - onehot(label)) * g_cls / count      for labels >= 0   (count read from the loss pass)
+//   bbox: g_box / B * outside_w * inside_w * dSmoothL1      for labels == 1
+__global__ void __launch_bounds__(256)
+rpn_loss_bwd_kernel(const float* __restrict__ heads, long hs, const float* __restrict__ labels,
+                    const int* __restrict__ assign, const float* __restrict__ gt, const float* __restrict__ base,
+                    AnchorGeomB g, int B, float sigma, float inside_w, float outside_w, const float* __restrict__ losses3,
+                    float g_cls, float g_box, float* __restrict__ dheads) {
+  const int total = g.H * g.W * g.A;
+  const long n = (long)B * total;
+  const float s2 = sigma * sigma;
+  const float count = losses3[2];
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)blockDim.x * gridDim.x) {
+    const int b = (int)(e / total), i = (int)(e % total);
+    const float label = labels[e];
+    if (label < 0.f) continue;
+    const int a = i % g.A, k = i / g.A;
+    const long ro = ((long)b * g.H * g.W + k) * hs;
+    const float s0 = heads[ro + a], s1 = heads[ro + g.A + a];
+    const float m = fmaxf(s0, s1);
+    const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+    const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+    const float sc = g_cls / count;
+    dheads[ro + a] = (p0 - (label == 0.f ? 1.f : 0.f)) * sc;
+    dheads[ro + g.A + a] = (p1 - (label == 1.f ? 1.f : 0.f)) * sc;
+    if (label == 1.f) {
+      const float4 an = anchor_box_b(base, g, i);
+      const float* q = gt + ((long)b * g.n_gt + assign[e]) * 5;
+      const float ew = an.z - an.x + 1.0f, eh = an.w - an.y + 1.0f;
+      const float ecx = an.x + 0.5f * ew, ecy = an.y + 0.5f * eh;
+      const float gw = q[2] - q[0] + 1.0f, gh = q[3] - q[1] + 1.0f;
+      const float t[4] = {(q[0] + 0.5f * gw - ecx) / ew, (q[1] + 0.5f * gh - ecy) / eh, logf(gw / ew), logf(gh / eh)};
+      const long bo = ro + 2 * g.A + 4 * a;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = inside_w * (heads[bo + j] - t[j]);
+        const float ad = fabsf(d);
+        const float dl = ad < 1.f / s2 ? d * s2 : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        dheads[bo + j] = g_box / (float)B * outside_w * inside_w * dl;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dana_rowdot_backward(const float* x, const float* grad_out, const float* w, float* grad_x, float* grad_w, long rows,
+                         int dim, long ld_x, long ld_grad_x, int accumulate_w, void* workspace, size_t workspace_bytes,
+                         dana_stream_t stream) {
+  DANA_CHECK_ARG(rows > 0 && dim > 0 && x && grad_out && w && grad_w, "dana_rowdot_backward: bad args");
+  if (ld_x <= 0) ld_x = dim;
+  if (ld_grad_x <= 0) ld_grad_x = dim;
+  const size_t need = dana_colsum_workspace_bytes(rows, dim);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("dana_rowdot_backward: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  const int chunks = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+  DANA_CHECK_ARG(chunks <= 65535, "dana_rowdot_backward: too many rows");
+  dim3 grid(dana_ceil_div(dim, 64), chunks);
+  rowdot_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, grad_out, w, grad_x, (float*)workspace, rows, dim, ld_x,
+                                                          ld_grad_x);
+  DANA_CHECK_LAUNCH("dana_rowdot_backward(partial)");
+  colsum_final_kernel<<<dana_ceil_div(dim, 256), 256, 0, (hipStream_t)stream>>>((const float*)workspace, grad_w, chunks, dim,
+                                                                                1.f, accumulate_w);
+  DANA_CHECK_LAUNCH("dana_rowdot_backward(final)");
+  return DANA_OK;
+}
+
+int dana_broadcast_rows(const float* in, float* out, long groups, int positions, int channels, float alpha,
+                        int accumulate, dana_stream_t stream) {
+  DANA_CHECK_ARG(groups >= 0 && positions > 0 && channels > 0 && channels % 4 == 0, "dana_broadcast_rows: bad shape");
+  if (groups == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && out, "dana_broadcast_rows: null pointer");
+  const long total = groups * positions * (channels / 4);
+  broadcast_rows_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)in, (float4*)out, groups,
+                                                                               positions, channels / 4, alpha, accumulate);
+  DANA_CHECK_LAUNCH("dana_broadcast_rows");
+  return DANA_OK;
+}
+
+int dana_ba_backward(float* grad_s, const float* s, const float* weights, const float* gvec, const float* gsum,
+                     float* grad_weights, long groups, int length, int dim, float gamma, float slope,
+                     dana_stream_t stream) {
+  DANA_CHECK_ARG(groups >= 0 && length > 0 && dim > 0, "dana_ba_backward: bad shape");
+  if (groups == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad_s && s && weights && gvec && gsum && grad_weights, "dana_ba_backward: null pointer");
+  const long rows = groups * length;
+  ba_bwd_kernel<<<dana_ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(grad_s, s, weights, gvec, gsum, grad_weights, rows,
+                                                                        length, dim, gamma, slope);
+  DANA_CHECK_LAUNCH("dana_ba_backward");
+  return DANA_OK;
+}
+
+int dana_attn_softmax_unary_backward(float* grad_a, const float* a, const float* unary, long rows, long rows_per_batch,
+                                     long unary_batch_stride, int nseg, int length, long ld, int kpad,
+                                     float unary_gamma, float out_scale, float alpha, dana_stream_t stream) {
+  DANA_CHECK_ARG(rows >= 0 && rows_per_batch > 0 && nseg > 0 && length > 0 && ld >= (long)nseg * length && kpad <= ld,
+                 "dana_attn_softmax_unary_backward: bad shape");
+  if (rows == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad_a && a && unary, "dana_attn_softmax_unary_backward: null pointer");
+  attn_softmax_unary_bwd_kernel<<<dana_ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(
+      grad_a, a, unary, rows, rows_per_batch, unary_batch_stride > 0 ? unary_batch_stride : (long)nseg * length, nseg,
+      length, ld, kpad, unary_gamma, out_scale, alpha);
+  DANA_CHECK_LAUNCH("dana_attn_softmax_unary_backward");
+  return DANA_OK;
+}
+
+int dana_rpn_loss_backward(const float* heads, long head_row_stride, const float* labels, const int* argmax,
+                           const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
+                           int feat_stride, int n_gt, float sigma, float inside_weight, float outside_weight,
+                           const float* losses3, float grad_cls, float grad_box, float* grad_heads,
+                           dana_stream_t stream) {
+  DANA_CHECK_ARG(B > 0 && A > 0 && H > 0 && W > 0 && n_gt > 0 && losses3, "dana_rpn_loss_backward: bad shape");
+  DANA_CHECK_ARG(heads && labels && argmax && gt_boxes && base_anchors && grad_heads,
+                 "dana_rpn_loss_backward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_heads, 0, (size_t)B * H * W * head_row_stride * sizeof(float), s) != hipSuccess) {
+    dana_set_error("dana_rpn_loss_backward: memset failed");
+    return DANA_ERR_HIP;
+  }
+  AnchorGeomB g = {A, H, W, feat_stride, n_gt};
+  const long n = (long)B * H * W * A;
+  int blocks = dana_ceil_div(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  rpn_loss_bwd_kernel<<<blocks, 256, 0, s>>>(heads, head_row_stride, labels, argmax, gt_boxes, base_anchors, g, B, sigma,
+                                             inside_weight, outside_weight, losses3, grad_cls, grad_box, grad_heads);
+  DANA_CHECK_LAUNCH("dana_rpn_loss_backward");
+  return DANA_OK;
+}
+
+}  // extern "C"

@@ -440,6 +440,7 @@ rpn_loss_reduce_kernel(const float* __restrict__ partial, int nblocks, int B, fl
   if (threadIdx.x == 0) {
     out[0] = ce / cnt;        // F.cross_entropy mean over the kept anchors (rpn.py:104)
     out[1] = sl1 / (float)B;  // sum over dims [1,2,3], mean over the batch (rpn.py:114, net_utils.py:82-84)
+    out[2] = cnt;             // the cross-entropy's divisor, for dana_rpn_loss_backward
   }
 }
 
@@ -538,10 +539,10 @@ size_t dana_rpn_loss_workspace_bytes(void) { return 512 * 3 * sizeof(float); }
 
 int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels, const int* argmax,
                   const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W, int feat_stride,
-                  int n_gt, float sigma, float inside_weight, float outside_weight, float* losses2, void* workspace,
+                  int n_gt, float sigma, float inside_weight, float outside_weight, float* losses3, void* workspace,
                   size_t workspace_bytes, dana_stream_t stream) {
   DANA_CHECK_ARG(B > 0 && A > 0 && H > 0 && W > 0 && n_gt > 0 && head_row_stride >= 6 * A, "dana_rpn_loss: bad shape");
-  DANA_CHECK_ARG(heads && labels && argmax && gt_boxes && base_anchors && losses2, "dana_rpn_loss: null pointer");
+  DANA_CHECK_ARG(heads && labels && argmax && gt_boxes && base_anchors && losses3, "dana_rpn_loss: null pointer");
   if (!workspace || workspace_bytes < dana_rpn_loss_workspace_bytes()) {
     dana_set_error("dana_rpn_loss: workspace too small");
     return DANA_ERR_WORKSPACE;
@@ -554,7 +555,7 @@ int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels,
                                                            base_anchors, g, B, sigma, inside_weight, outside_weight,
                                                            (float*)workspace);
   DANA_CHECK_LAUNCH("dana_rpn_loss");
-  rpn_loss_reduce_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, blocks, B, losses2);
+  rpn_loss_reduce_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, blocks, B, losses3);
   DANA_CHECK_LAUNCH("dana_rpn_loss(reduce)");
   return DANA_OK;
 }

@@ -266,8 +266,8 @@ class DAnARCNN(nn.Module):
         return p
 
     def _stream(self, name, dev):
-        if getattr(self, "_single_stream", False):  # bench.py's per-launch timing pass: no overlap
-            return torch.cuda.current_stream()
+        if getattr(self, "_single_stream", False) or (self.training and getattr(self, "save_for_backward", False)):
+            return torch.cuda.current_stream()  # bench.py's per-launch timing pass / saved-for-backward runs: no overlap
         key = ("stream", name, str(dev))
         st = self._consts.get(key)
         if st is None:
@@ -288,8 +288,8 @@ class DAnARCNN(nn.Module):
                                scale=c["scale"], shift=c["shift"], residual=residual, relu=relu,
                                in_stride=in_stride, out=out, out_stride=out_stride, res_stride=res_stride)
 
-    def _bottleneck(self, x, n, h, w, bp, out=None, out_stride=0, in_stride=0, save=None):
-        """save: optional list; receives dict(x, o1, o2, o3, h1, w1) for backward.bottleneck_backward"""
+    def _bottleneck(self, x, n, h, w, bp, out=None, out_stride=0, in_stride=0, save=None, key=None):
+        """save: optional list; receives dict(x, o1, o2, o3, h1, w1, ...) for backward.bottleneck_backward"""
         o1, h1, w1 = self._conv(x, n, h, w, bp["c1"], True, in_stride=in_stride)
         o2, _, _ = self._conv(o1, n, h1, w1, bp["c2"], True)
         if bp["ds"] is not None:
@@ -300,10 +300,10 @@ class DAnARCNN(nn.Module):
         o3, _, _ = self._conv(o2, n, h1, w1, bp["c3"], True, residual=res, res_stride=rs, out=out,
                               out_stride=out_stride)
         if save is not None:
-            save.append(dict(x=x, o1=o1, o2=o2, o3=o3, h1=h1, w1=w1))
+            save.append(dict(x=x, o1=o1, o2=o2, o3=o3, h1=h1, w1=w1, n=n, h=h, w=w, bp=bp, key=key, o3_ld=out_stride))
         return o3, h1, w1
 
-    def _rcnn_base(self, im, plan, out_stride=0, out_buf=None):
+    def _rcnn_base(self, im, plan, out_stride=0, out_buf=None, save=None):
         """RCNN_base (dana.py:344-345) on NCHW input -> (NHWC flat buffer [n*h*w][out_stride or 1024], h, w).
         out_buf: write the result there (row stride out_stride) instead of allocating."""
         n, _, H, W = im.shape
@@ -322,7 +322,8 @@ class DAnARCNN(nn.Module):
                     ww = (w - 1) // bp["c1"]["stride"] + 1
                     out = out_buf if out_buf is not None else torch.empty((n * hh * ww, out_stride),
                                                                           dtype=torch.float32, device=im.device)
-                x, h, w = self._bottleneck(x, n, h, w, bp, out=out, out_stride=out_stride if last else 0)
+                x, h, w = self._bottleneck(x, n, h, w, bp, out=out, out_stride=out_stride if last else 0,
+                                           save=save if li > 0 else None, key="RCNN_base.%d.%d" % (4 + li, bi))
         return x, h, w
 
     @staticmethod
@@ -407,6 +408,13 @@ class DAnARCNN(nn.Module):
                 e.record()
                 gev.append((name, e))
 
+        ctx = None
+        if training and getattr(self, "save_for_backward", False):
+            # everything backward.model_backward needs; the forward then runs on ONE stream (saved tensors are
+            # consumed by the backward on the caller's stream)
+            if self.merge_trunk or self.query_streams != 1:
+                raise RuntimeError("save_for_backward needs merge_trunk=False and query_streams=1")
+            ctx = self._ctx = dict(plan=plan, B=B, shot=shot, way=way, q_saved=[], s_saved=[], l4_saved=[], heads=[])
         mark("begin")
         inputs_ready = torch.cuda.Event()
         inputs_ready.record()
@@ -433,7 +441,7 @@ class DAnARCNN(nn.Module):
         else:
             sup_stream.wait_event(inputs_ready)
             with torch.cuda.stream(sup_stream):
-                sup, sh_, sw_ = self._rcnn_base(sup_ims, plan)  # [Ns*400][1024]
+                sup, sh_, sw_ = self._rcnn_base(sup_ims, plan, save=ctx["s_saved"] if ctx is not None else None)
             # the query batch itself is split over `query_streams` streams: kernels of different images
             # overlap each other's prologue / epilogue / tail phases on the CUs
             qs = max(1, min(int(self.query_streams), B))
@@ -443,7 +451,8 @@ class DAnARCNN(nn.Module):
             for i in range(qs):
                 b0, b1 = bounds[i], bounds[i + 1]
                 if i == 0 or self.query_sequential:
-                    self._rcnn_base(im_data[b0:b1], plan, out_stride=2048, out_buf=corr[b0 * fh * fw:])
+                    self._rcnn_base(im_data[b0:b1], plan, out_stride=2048, out_buf=corr[b0 * fh * fw:],
+                                    save=ctx["q_saved"] if ctx is not None else None)
                 else:
                     st_i = self._stream("query%d" % i, dev)
                     st_i.wait_event(inputs_ready)
@@ -466,6 +475,8 @@ class DAnARCNN(nn.Module):
                 wc, bc = self._w(self.rpn_channel_k_layer)
                 wgt = ops.rowdot(s_pe, wc, bc, B * shot * L, 1024)
                 ops.softmax_rows_(wgt, B * shot, L)
+                if ctx is not None:
+                    ctx.update(s_pre=s_pe.clone(), ba_w=wgt)
                 ops.ba_apply_(s_pe, wgt, B * shot, L, 1024, gamma=self.channel_gamma, slope=0.01)
             wk, bk = self._w(self.rpn_adapt_k_layer)
             kp = ops.gemm_nt(s_pe, wk, B * shot * L, d, 1024, shift=bk)
@@ -488,6 +499,8 @@ class DAnARCNN(nn.Module):
                 t_.record_stream(main)
             support_done = torch.cuda.Event()
             support_done.record()
+            if ctx is not None:
+                ctx.update(sup=sup, s_pe=s_pe, kp=kp, unary=unary, sp_pe=sp_pe, k2=k2, un2=un2, Ns=Ns)
 
         # -- RPN-level dual-awareness attention, query side (dana.py:118-154) --
         wq, bq = self._w(self.rpn_adapt_q_layer)
@@ -502,6 +515,8 @@ class DAnARCNN(nn.Module):
                     batch_a=hw * K1, batch_b=1024 * K1, batch_c=hw * 2048)
         if inter is not None:
             inter["corr"] = (corr, B, fh, fw)
+        if ctx is not None:
+            ctx.update(corr=corr, fh=fh, fw=fw, qp=qp, scores=scores)
 
         mark("rpn-level attention (incl. wait for support stream)")
         # -- RPN head + proposals (rpn.py:58-78, proposal_layer.py:49-190) --
@@ -548,6 +563,8 @@ class DAnARCNN(nn.Module):
             # fused RPN losses (rpn.py:97-115) straight from the head buffer [B*hw][2A | 4A]
             rpn_l = ops.rpn_losses(heads, nh, at, sigma=3.0, inside_weight=tr_.RPN_BBOX_INSIDE_WEIGHTS[0])
             rpn_loss_cls, rpn_loss_bbox = rpn_l[0], rpn_l[1]
+            if ctx is not None:
+                ctx.update(rpn_x=x, rpn_heads=heads, nh=nh, at=at, rpn_l=rpn_l)
             tr_ = cfg.TRAIN
             fg_per = int(np.round(tr_.FG_FRACTION * tr_.BATCH_SIZE)) or 1
             rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_layer(
@@ -582,8 +599,9 @@ class DAnARCNN(nn.Module):
         l4_stream.wait_event(pooled_ready)
         with torch.cuda.stream(l4_stream):
             y, h4, w4 = pooled, P, P
-            for bp in plan["layer4"]:
-                y, h4, w4 = self._bottleneck(y, n_roi, h4, w4, bp)
+            for bi, bp in enumerate(plan["layer4"]):
+                y, h4, w4 = self._bottleneck(y, n_roi, h4, w4, bp, save=ctx["l4_saved"] if ctx is not None else None,
+                                             key="RCNN_top.0.%d" % bi)
             fc7 = ops.spatial_mean(y, n_roi, h4 * w4, 2048)
             wb, bb = self._w(self.RCNN_bbox_pred)
             bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
@@ -625,8 +643,13 @@ class DAnARCNN(nn.Module):
             hid = ops.gemm_nt(tr, w1, n_roi, w1.size(0), P2 * self.rcnn_dim, shift=b1, relu=True)
             score = ops.gemm_nt(hid, w2, n_roi, 2, w1.size(0), shift=b2)
             prob = ops.softmax_rows_(score.clone(), n_roi, 2)
+            if ctx is not None:
+                ctx["heads"].append(dict(offset=offset, sc2=sc2, dense=dense, tr=tr, hid=hid))
             return prob, score
 
+        if ctx is not None:
+            ctx.update(rois=rois, R=R, q_pe=q_pe, q2=q2, fc7=fc7, K2=K2, K2p=K2p)
+            cls_prob, cls_score_all = head(0)  # ctx["heads"] order: positive, negative
         if training:  # the negative-support head (dana.py:190) on its own stream, concurrent with the positive one
             neg_stream = self._stream("neg_head", dev)
             neg_stream.wait_event(q_ready)
@@ -638,7 +661,8 @@ class DAnARCNN(nn.Module):
                     t_.record_stream(neg_stream)
                 neg_done = torch.cuda.Event()
                 neg_done.record()
-        cls_prob, cls_score_all = head(0)
+        if ctx is None:
+            cls_prob, cls_score_all = head(0)
         mark("pos head")
         main.wait_event(l4_done)
         if training:
@@ -665,6 +689,9 @@ class DAnARCNN(nn.Module):
             top1 = real_bg[real_bg >= int(n_all * 0.5)][:bg_num_1]
             topk = torch.cat([fg_inds, top0, top1], dim=0)
             RCNN_loss_cls = F.cross_entropy(cls_score_all[topk], rois_label[topk])
+            if ctx is not None:
+                ctx.update(cls_score_all=cls_score_all, bbox_pred=bbox_pred, rois_label=rois_label, topk=topk,
+                           rois_target=rois_target, rois_inside_ws=rois_inside_ws, rois_outside_ws=rois_outside_ws)
         mark("rcnn losses")
         if tl is not None:
             tl.append(("rcnn losses", _time.perf_counter()))

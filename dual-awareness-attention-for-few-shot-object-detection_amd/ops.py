@@ -308,9 +308,9 @@ def anchor_target_outputs(h, inside_weight=1.0):
 
 
 def rpn_losses(heads, head_row_stride, h, sigma=3.0, inside_weight=1.0):
-    """(rpn_loss_cls, rpn_loss_bbox) of rpn.py:97-115, fused over heads[B*H*W][2A | 4A]; -> float32[2] tensor"""
+    """(rpn_loss_cls, rpn_loss_bbox) of rpn.py:97-115, fused over heads[B*H*W][2A | 4A]; -> float32[3] tensor (cls, box, #labeled)"""
     _chk(heads, "heads")
-    out = torch.empty((2,), dtype=torch.float32, device=heads.device)
+    out = torch.empty((3,), dtype=torch.float32, device=heads.device)  # cls, box, number of labeled anchors
     ws = _ws(lib().query("dana_rpn_loss_workspace_bytes"), heads.device)
     lib().call("dana_rpn_loss", _p(heads), head_row_stride, _p(h["labels"]), _p(h["argmax"]), _p(h["gt_boxes"]),
                _p(h["base_anchors"]), h["B"], h["A"], h["H"], h["W"], h["stride"], h["n_gt"], float(sigma),
@@ -635,3 +635,71 @@ def gemm_small(a, a_strides, b, b_strides, m, n, k, out=None, c_strides=None, al
     lib().call("dana_gemm_small", _p(a), a_strides[0], a_strides[1], _p(b), b_strides[0], b_strides[1], _p(out),
                c_strides[0], c_strides[1], m, n, k, float(alpha), int(accumulate), _stream())
     return out
+
+
+def rowdot_backward(x, grad_out, w, rows, dim, grad_x=None, grad_w=None, ld_x=0, ld_grad_x=0):
+    """adjoint of rowdot(): returns grad_w [dim] (accumulated into grad_w when given); grad_x += grad_out (x) w"""
+    _chk(x, "x")
+    _chk(grad_out, "grad_out")
+    accumulate = grad_w is not None
+    if grad_w is None:
+        grad_w = torch.empty((dim,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().query("dana_colsum_workspace_bytes", rows, dim), x.device)
+    lib().call("dana_rowdot_backward", _p(x), _p(grad_out), _p(_chk(w.detach().contiguous(), "w")), _p(grad_x),
+               _p(grad_w), rows, dim, ld_x, ld_grad_x, int(accumulate), _p(ws), ws.numel(), _stream())
+    return grad_w
+
+
+def broadcast_rows(x, groups, positions, channels, alpha=1.0, out=None):
+    _chk(x, "x")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((groups * positions, channels), dtype=torch.float32, device=x.device)
+    lib().call("dana_broadcast_rows", _p(x), _p(out), groups, positions, channels, float(alpha), int(accumulate),
+               _stream())
+    return out
+
+
+def ba_backward_(grad_s, s, weights, gvec, gsum, groups, length, dim, gamma=0.1, slope=0.01):
+    grad_w = torch.empty((groups * length,), dtype=torch.float32, device=s.device)
+    lib().call("dana_ba_backward", _p(_chk(grad_s, "grad_s")), _p(_chk(s, "s")), _p(_chk(weights, "weights")),
+               _p(_chk(gvec, "gvec")), _p(_chk(gsum, "gsum")), _p(grad_w), groups, length, dim, float(gamma),
+               float(slope), _stream())
+    return grad_w
+
+
+def attn_softmax_unary_backward_(grad_a, a, unary, rows, rows_per_batch, nseg, length, ld, kpad, unary_gamma, out_scale,
+                                 alpha, unary_batch_stride=0):
+    lib().call("dana_attn_softmax_unary_backward", _p(_chk(grad_a, "grad_a")), _p(_chk(a, "a")), _p(_chk(unary, "unary")),
+               rows, rows_per_batch, unary_batch_stride, nseg, length, ld, kpad, float(unary_gamma), float(out_scale),
+               float(alpha), _stream())
+    return grad_a
+
+
+def rpn_loss_backward(heads, head_row_stride, h, losses3, grad_cls=1.0, grad_box=1.0, sigma=3.0, inside_weight=1.0):
+    """d(grad_cls * rpn_loss_cls + grad_box * rpn_loss_bbox) / d heads, same [B*H*W][row stride] layout"""
+    _chk(heads, "heads")
+    g = torch.empty_like(heads)
+    lib().call("dana_rpn_loss_backward", _p(heads), head_row_stride, _p(h["labels"]), _p(h["argmax"]), _p(h["gt_boxes"]),
+               _p(h["base_anchors"]), h["B"], h["A"], h["H"], h["W"], h["stride"], h["n_gt"], float(sigma),
+               float(inside_weight), 1.0 / h["num_examples"], _p(_chk(losses3, "losses3")), float(grad_cls),
+               float(grad_box), _p(g), _stream())
+    return g
+
+
+def linear_backward(g, x, w, m, n, k, ldx=0, ldg=0, ldw=0, need_dx=True, dx_out=None, dx_ld=0):
+    """y[m][n] = x[m][:k] . w[n][:k]^T + b: returns (dW [n][k] dense, db [n], dx [m][k] or None).
+    n % 4 == 0 and k % 64 == 0 (the split-M TN MFMA kernel); dx goes through the forward GEMM on w^T and is
+    ACCUMULATED into dx_out (row stride dx_ld) when that is given."""
+    ldw = ldw or k
+    dw = conv2d_wgrad(g, x, 1, 1, m, k, n, 1, 1, 1, 0, in_stride=ldx, grad_stride=ldg)
+    db = colsum(g, m, n, ld=ldg)
+    dx = None
+    if need_dx:
+        wt = torch.empty((k, n), dtype=torch.float32, device=g.device)  # [k][n] = w^T
+        lib().call("dana_transpose_batched", _p(_chk(w, "w")), _p(wt), 1, n, k, ldw, n, n * ldw, k * n, _stream())
+        if dx_out is None:
+            dx = gemm_nt(g, wt, m, k, n, lda=ldg)
+        else:
+            dx = gemm_nt(g, wt, m, k, n, lda=ldg, out=dx_out, ldc=dx_ld or k, residual=dx_out, ldr=dx_ld or k)
+    return dw, db, dx

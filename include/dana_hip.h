@@ -235,12 +235,12 @@ int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, c
                                int feat_stride, int n_gt, float inside_weight, float outside_weight,
                                float* labels_out, float* bbox_targets, float* inside_weights,
                                float* outside_weights, dana_stream_t stream);
-/* losses2[0] = F.cross_entropy over labels >= 0 (rpn.py:97-105), losses2[1] = _smooth_l1_loss(sigma, dims 1,2,3)
- * (rpn.py:114), fused over heads[B*H*W][row stride] = (2A cls | 4A bbox) without materialising the targets. */
+/* losses3[0] = F.cross_entropy over labels >= 0 (rpn.py:97-105), losses3[1] = _smooth_l1_loss(sigma, dims 1,2,3)
+ * (rpn.py:114), losses3[2] = number of labels >= 0; fused over heads[B*H*W][row stride] = (2A cls | 4A bbox) without materialising the targets. */
 size_t dana_rpn_loss_workspace_bytes(void);
 int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels, const int* argmax,
                   const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W, int feat_stride,
-                  int n_gt, float sigma, float inside_weight, float outside_weight, float* losses2, void* workspace,
+                  int n_gt, float sigma, float inside_weight, float outside_weight, float* losses3, void* workspace,
                   size_t workspace_bytes, dana_stream_t stream);
 
 /* ---- backward building blocks of the conv / Linear layers (training step, SURVEY.md 8d variant S) --------
@@ -280,6 +280,31 @@ int dana_softmax_rows_backward(float* grad, const float* prob, long rows, int le
 int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const float* b, long b_stride_k, long b_stride_n,
                     float* c, long c_stride_m, long c_stride_n, int m, int n, int k, float alpha, int accumulate,
                     dana_stream_t stream);                       /* skinny heads (N or K of 2 / 4) */
+
+/* adjoint of dana_rowdot: grad_w[dim] (+)= sum_r grad_out[r] x[r]; grad_x[r] += grad_out[r] w (grad_x may be NULL);
+ * workspace: dana_colsum_workspace_bytes(rows, dim) */
+int dana_rowdot_backward(const float* x, const float* grad_out, const float* w, float* grad_x, float* grad_w, long rows,
+                         int dim, long ld_x, long ld_grad_x, int accumulate_w, void* workspace, size_t workspace_bytes,
+                         dana_stream_t stream);
+/* out[g][p][:] (+)= alpha * in[g][:] : adjoint of dana_spatial_mean_nhwc (alpha = 1/positions) */
+int dana_broadcast_rows(const float* in, float* out, long groups, int positions, int channels, float alpha,
+                        int accumulate, dana_stream_t stream);
+/* adjoint of dana_ba_apply (dana.py:133-137), in place on grad_s [groups*length][dim]: s = the block's INPUT,
+ * gvec[groups][dim] = weights^T s, gsum[groups][dim] = column sums of grad_s per group; grad_weights[groups*length] out */
+int dana_ba_backward(float* grad_s, const float* s, const float* weights, const float* gvec, const float* gsum,
+                     float* grad_weights, long groups, int length, int dim, float gamma, float slope,
+                     dana_stream_t stream);
+/* adjoint of dana_attn_softmax_unary, in place on grad_a: -> alpha * dL/d(raw scores) (alpha = the 1/sqrt(d) of QK^T) */
+int dana_attn_softmax_unary_backward(float* grad_a, const float* a, const float* unary, long rows, long rows_per_batch,
+                                     long unary_batch_stride, int nseg, int length, long ld, int kpad,
+                                     float unary_gamma, float out_scale, float alpha, dana_stream_t stream);
+/* adjoint of dana_rpn_loss w.r.t. the head buffer: grad_heads[B*H*W][row stride] (zero-filled here);
+ * losses3 = dana_rpn_loss's DEVICE output (its [2] is the cross-entropy's divisor); grad_cls / grad_box = upstream scalars */
+int dana_rpn_loss_backward(const float* heads, long head_row_stride, const float* labels, const int* argmax,
+                           const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
+                           int feat_stride, int n_gt, float sigma, float inside_weight, float outside_weight,
+                           const float* losses3, float grad_cls, float grad_box, float* grad_heads,
+                           dana_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -418,8 +418,52 @@ def rcnn_head(pooled, support_pooled, sd, n_shot, inter=None):
 # ------------------------------------------------------------------------------------------------
 # the whole forward: dana.py:87-220
 # ------------------------------------------------------------------------------------------------
+def roi_align_torch(feat, rois, scale, P):
+    """Differentiable (w.r.t. feat) restatement of ROIAlign_cpu.cpp:116-245 with sampling_ratio = 0, used only to
+    obtain reference GRADIENTS through autograd (tests/test_gpu_backward.py); checked against the C oracle."""
+    B, C, H, W = feat.shape
+    outs = []
+
+    def prep(v, size):
+        valid = (v >= -1.0) & (v <= size)
+        v = v.clamp(min=0)
+        lo = v.floor().long()
+        edge = lo >= size - 1
+        hi = torch.where(edge, torch.full_like(lo, size - 1), lo + 1)
+        lo = torch.where(edge, torch.full_like(lo, size - 1), lo)
+        v = torch.where(edge, lo.to(v.dtype), v)
+        frac = v - lo.to(v.dtype)
+        return valid, lo, hi, frac, 1.0 - frac
+
+    for r in rois.detach().float():
+        b = int(r[0])
+        x1, y1, x2, y2 = [r[i] * scale for i in range(1, 5)]
+        rw = torch.clamp(x2 - x1, min=1.0)
+        rh = torch.clamp(y2 - y1, min=1.0)
+        bw, bh = rw / P, rh / P
+        gh, gw = int(math.ceil(float(rh) / P)), int(math.ceil(float(rw) / P))
+        ip = torch.arange(P, dtype=torch.float32).view(P, 1)
+        ys = (y1 + ip * bh + (torch.arange(gh, dtype=torch.float32).view(1, gh) + 0.5) * bh / gh).reshape(-1)
+        xs = (x1 + ip * bw + (torch.arange(gw, dtype=torch.float32).view(1, gw) + 0.5) * bw / gw).reshape(-1)
+        vy, ylo, yhi, ly, hy = prep(ys, H)
+        vx, xlo, xhi, lx, hx = prep(xs, W)
+        plane = feat[b]
+        ly, hy, lx, hx = [t.to(feat.dtype) for t in (ly, hy, lx, hx)]
+
+        def g(yi, xi):
+            return plane[:, yi][:, :, xi]
+
+        val = (hy[:, None] * hx[None, :] * g(ylo, xlo) + hy[:, None] * lx[None, :] * g(ylo, xhi)
+               + ly[:, None] * hx[None, :] * g(yhi, xlo) + ly[:, None] * lx[None, :] * g(yhi, xhi))
+        val = val * (vy[:, None] & vx[None, :]).to(feat.dtype)
+        outs.append(val.view(C, P, gh, P, gw).sum((2, 4)) / (gh * gw))
+    return torch.stack(outs, 0)
+
+
 def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_way=2, n_shot=3, use_ba=False,
-            nms_inclusive=True, inter=None):
+            nms_inclusive=True, inter=None, differentiable=False):
+    """differentiable=True: the state-dict tensors may require grad (RoIAlign through roi_align_torch; the proposal
+    layer sees detached inputs, as rpn.py:73 passes .data)"""
     B = im_data.shape[0]
     base_feat = rcnn_base(im_data, sd)
     sup = rcnn_base(support_ims.reshape(-1, *support_ims.shape[2:]), sd)
@@ -441,7 +485,7 @@ def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_
     if inter is not None:
         inter["rpn_cls_score"] = cls
         inter["rpn_bbox_pred"] = bbox
-    rois = proposal_layer(prob, bbox, im_info, "TRAIN" if training else "TEST", nms_inclusive, inter)
+    rois = proposal_layer(prob.detach(), bbox.detach(), im_info, "TRAIN" if training else "TEST", nms_inclusive, inter)
     rpn_loss_cls = rpn_loss_bbox = 0
     rois_label = None
     if training:
@@ -459,8 +503,11 @@ def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_
         rw_out = rw_out.view(-1, 4)
     if inter is not None:
         inter["rois"] = rois
-    pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
-                                                       1.0 / 16.0, 7, 7, 0))
+    if differentiable:
+        pooled = roi_align_torch(base_feat, rois.view(-1, 5), 1.0 / 16.0, 7)
+    else:
+        pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
+                                                           1.0 / 16.0, 7, 7, 0))
     if inter is not None:
         inter["pooled_feat"] = pooled
     bbox_pred, cls_prob, cls_score = rcnn_head(pooled, pos_pooled, sd, n_shot, inter)

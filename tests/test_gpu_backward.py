@@ -62,3 +62,94 @@ def test_bottleneck_backward_vs_autograd(dev, stride, inplanes, planes, hw):
         grads.finish_conv("b." + nm, c, mod.weight)
         _close(mod.weight.grad.cpu(), sd["b.%s.weight" % nm].grad)
     assert not grads.packed
+
+
+def test_rpn_loss_backward_vs_autograd(dev):
+    from dana_amd import ops, targets as T
+    from dana_amd.config import cfg
+    torch.manual_seed(5)
+    np.random.seed(11)
+    B, H, W, n_gt = 2, 12, 16, 6
+    A = len(cfg.ANCHOR_SCALES) * len(cfg.ANCHOR_RATIOS)
+    gt = torch.zeros(B, n_gt, 5)
+    for b in range(B):
+        for k in range(3 + b):
+            x1, y1 = np.random.uniform(0, 150), np.random.uniform(0, 100)
+            gt[b, k] = torch.tensor([x1, y1, x1 + np.random.uniform(20, 100), y1 + np.random.uniform(20, 90), 1.0])
+    im_info = torch.tensor([[H * 16.0, W * 16.0, 1.0]] * B)
+    anchors = torch.from_numpy(T.generate_anchors(scales=np.array(cfg.ANCHOR_SCALES),
+                                                  ratios=np.array(cfg.ANCHOR_RATIOS))).float()
+    tr = cfg.TRAIN
+    h = ops.anchor_target_assign(gt.to(dev), im_info.to(dev), anchors.to(dev), H, W, 16, tr.RPN_NEGATIVE_OVERLAP,
+                                 tr.RPN_POSITIVE_OVERLAP, tr.RPN_BATCHSIZE, tr.RPN_FG_FRACTION)
+    lab, tgt, w_in, w_out = [t.cpu() for t in ops.anchor_target_outputs(h)]
+    heads = (torch.randn(B * H * W, 6 * A) * 0.5)
+    hd = heads.clone().double().requires_grad_(True)
+    cls = hd[:, :2 * A].view(B, H, W, 2 * A).permute(0, 3, 1, 2)
+    bbox = hd[:, 2 * A:].view(B, H, W, 4 * A).permute(0, 3, 1, 2)
+    sc = cls.reshape(B, 2, A * H, W).permute(0, 2, 3, 1).reshape(-1, 2)
+    lv = lab.view(-1)
+    keep = lv.ne(-1).nonzero().view(-1)
+    l_cls = F.cross_entropy(sc[keep], lv[keep].long())
+    l_box = T._smooth_l1_loss(bbox, tgt.double(), w_in.double(), w_out.double(), sigma=3, dim=[1, 2, 3])
+    (0.7 * l_cls + 1.3 * l_box).backward()
+    hg = heads.to(dev)
+    l3 = ops.rpn_losses(hg, 6 * A, h, sigma=3.0)
+    g = ops.rpn_loss_backward(hg, 6 * A, h, l3, 0.7, 1.3, sigma=3.0)
+    assert float(l3[2]) == float(keep.numel())
+    _close(g.cpu(), hd.grad, 1e-5)
+
+
+@pytest.mark.parametrize("use_ba", [False, True])
+def test_model_backward_vs_oracle_autograd(dev, use_ba):
+    """every trainable parameter's gradient of (rpn_cls + rpn_box + rcnn_cls + rcnn_box), HIP backward vs autograd
+    through the oracle (same weights, inputs and np.random stream -> same sampled anchors / rois)"""
+    import dana_amd
+    from dana_amd import synthetic as S, backward as BW
+    from oracle import model_ref as O
+    B, way, shot, H, W = 2, 2, 3, 192, 256
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=use_ba, way=way, shot=shot, classes=["fg", "bg"])
+    sd = S.fill_state_dict(m.state_dict(), seed=21, profile="test")
+    m.load_state_dict(sd)
+    m.to(dev).train()
+    m.nms_inclusive = True
+    inputs = S.episode_inputs(B, way, shot, H, W, seed=22)
+    weights = (1.0, 0.5, 2.0, 1.5)
+
+    def trainable(k):
+        if "bn" in k or "downsample.1" in k or "running_" in k or "num_batches" in k:
+            return False
+        return not (k.startswith("RCNN_base.0") or k.startswith("RCNN_base.1") or k.startswith("RCNN_base.4"))
+
+    osd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and trainable(k) else v.clone())
+           for k, v in sd.items()}
+    np.random.seed(33)
+    out = O.forward(osd, *inputs, training=True, n_way=way, n_shot=shot, use_ba=use_ba, nms_inclusive=True,
+                    differentiable=True)
+    loss = sum(wt * l for wt, l in zip(weights, out[3:7]))
+    loss.backward()
+
+    m.save_for_backward = True
+    np.random.seed(33)
+    with torch.no_grad():
+        res = m(*[t.to(dev) for t in inputs])
+    assert np.array_equal(res[7].cpu().numpy(), out[7].numpy()), "different sampled rois: cannot compare gradients"
+    for a, b in zip(res[3:7], out[3:7]):
+        assert abs(float(a) - float(b.detach())) <= 1e-4 * max(1.0, abs(float(b.detach())))
+    BW.model_backward(m, weights)
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    worst = []
+    gmax = max(v.grad.abs().max().item() for v in osd.values() if v.dtype.is_floating_point and v.requires_grad)
+    for k, v in osd.items():
+        if not (v.dtype.is_floating_point and v.requires_grad):
+            continue
+        assert v.grad is not None, k
+        g = params[k].grad
+        assert g is not None, "no HIP gradient for %s" % k
+        # biases in front of a mean subtraction / softmax have an exactly-zero gradient: both sides hold fp32
+        # round-off there (1e-9), hence the floor relative to the largest gradient of the model
+        scale = v.grad.abs().max().item() + 1e-3 * gmax
+        worst.append(((g.cpu() - v.grad).abs().max().item() / scale, k, scale))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-3, "largest relative gradient errors: %s" % (worst[:8],)
