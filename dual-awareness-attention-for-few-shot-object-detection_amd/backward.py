@@ -45,9 +45,10 @@ class WeightGrads:
             param.grad = torch.empty_like(param)
         ops.unpack_conv_weight_grad(buf, param.grad, c["cout"], c["cin"], c["k"], c["k"], accumulate=not fresh)
 
-    def finish_all(self, model):
+    def finish_all(self, model, prefix=""):
         for key in list(self.packed):
-            self.finish_conv(key, self.convs[key], model.get_parameter(key + ".weight"))
+            if key.startswith(prefix):
+                self.finish_conv(key, self.convs[key], model.get_parameter(key + ".weight"))
 
 
 def conv_backward(g, x, n, h, w, c, grads, key, need_dx=True, in_stride=0):
@@ -81,6 +82,41 @@ def bottleneck_backward(g_out, saved, n, h, w, bp, grads, key, need_dx=True):
     elif need_dx:
         ops.axpy_rows_(dx, g, n * h * w, cout)
     return dx
+
+
+def _block_convs(prefix, bp):
+    names = [prefix + ".conv3.weight", prefix + ".conv2.weight", prefix + ".conv1.weight"]
+    if bp["ds"] is not None:
+        names.append(prefix + ".downsample.0.weight")
+    return names
+
+
+def grad_stages(model):
+    """[(stage, [parameter names])] in the order model_backward FINISHES the gradients: the trainer lays its flat
+    gradient buffer out in this order so that all-reduce buckets can leave while the rest of the backward runs."""
+    plan = model._get_plan()
+    lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
+    st = [("box branch", lin("RCNN_bbox_pred") + [n for bi in (2, 1, 0)
+                                                 for n in _block_convs("RCNN_top.0.%d" % bi, plan["layer4"][bi])])]
+    st.append(("roi heads", lin("output_score_layer.linear2") + lin("output_score_layer.linear1")
+               + lin("rcnn_adapt_q_layer") + lin("rcnn_transform_layer") + lin("rcnn_adapt_k_layer")
+               + lin("rcnn_unary_layer")))
+    rpn_att = lin("rpn_adapt_q_layer") + lin("rpn_adapt_k_layer") + lin("rpn_unary_layer")
+    if model.semantic_enhance:
+        rpn_att += lin("rpn_channel_k_layer")
+    st.append(("rpn", lin("RCNN_rpn.RPN_cls_score") + lin("RCNN_rpn.RPN_bbox_pred") + lin("RCNN_rpn.RPN_Conv") + rpn_att))
+    for li in (2, 1):  # RCNN_base.6 (layer3) then RCNN_base.5 (layer2); layer1 is frozen
+        layer = plan["layers"][li]
+        for bi in reversed(range(len(layer))):
+            key = "RCNN_base.%d.%d" % (4 + li, bi)
+            st.append((key, _block_convs(key, layer[bi])))
+    return st
+
+
+def _ready(model, names):
+    cb = getattr(model, "_grad_ready_cb", None)
+    if cb is not None:
+        cb(names)
 
 
 def _acc(param, g):
@@ -160,6 +196,9 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     for sv in reversed(l4):
         g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"])
     d_pooled = g  # [n_roi*49][1024]
+    grads.finish_all(model, "RCNN_top")
+    stages = grad_stages(model)
+    _ready(model, stages[0][1])
 
     # -- RoI-level attention heads (dana.py:248-292), positive then negative supports --
     q_pe, q2, sp_pe, k2, un2 = ctx["q_pe"], ctx["q2"], ctx["sp_pe"], ctx["k2"], ctx["un2"]
@@ -220,6 +259,7 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     _acc(model.rcnn_unary_layer.weight, ops.rowdot_backward(sp_pe, d_un2, wu2, Ns * P2, 1024, grad_x=d_sp_pe))
     _acc(model.rcnn_unary_layer.bias, ops.colsum(d_un2, Ns * P2, 1))
     d_sup = ops.avgpool_backward(d_sp_pe, Ns, 20, 20, 1024, 14, 1)  # [Ns][400][1024]
+    _ready(model, stages[1][1])
 
     # -- RPN: losses -> heads -> 3x3 conv (rpn.py:58-115) --
     rpn = model.RCNN_rpn
@@ -277,14 +317,23 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
         _acc(model.rpn_channel_k_layer.bias, ops.colsum(d_w, G * L, 1))
     for b in range(B):  # the positive supports' PE-added maps (dana.py:103,130)
         ops.axpy_rows_(d_sup.view(-1)[b * way * shot * L * 1024:], d_s_pe[b], K1, 1024)
+    grads.finish_all(model, "RCNN_rpn")
+    _ready(model, stages[2][1])
 
     # -- trunk: query (RoIAlign + RPN paths meet in base_feat) and supports; layer3, layer2 (layer1 is frozen) --
     ops.axpy_rows_(d_corr, d_bf, B * hw, 1024, ld_y=2048)
     g = torch.empty((B * hw, 1024), dtype=torch.float32, device=dev)
     ops.axpy_rows_(g, d_corr, B * hw, 1024, ld_x=2048, accumulate=False)
-    for saved, gg in ((ctx["q_saved"], g), (ctx["s_saved"], d_sup.view(Ns * L, 1024))):
-        for i, sv in enumerate(reversed(saved)):
-            gg = bottleneck_backward(gg, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"],
-                                     need_dx=i < len(saved) - 1)
-    grads.finish_all(model)
+    #    block by block for both batches, so that each block's weight gradient is final (and may be all-reduced)
+    #    while the earlier blocks are still being differentiated
+    gq, gs = g, d_sup.view(Ns * L, 1024)
+    qs, ss = ctx["q_saved"], ctx["s_saved"]
+    nblk = len(qs)
+    for i in range(nblk - 1, -1, -1):
+        sq, s_ = qs[i], ss[i]
+        gq = bottleneck_backward(gq, sq, sq["n"], sq["h"], sq["w"], sq["bp"], grads, sq["key"], need_dx=i > 0)
+        gs = bottleneck_backward(gs, s_, s_["n"], s_["h"], s_["w"], s_["bp"], grads, s_["key"], need_dx=i > 0)
+        grads.finish_all(model, sq["key"] + ".")
+        _ready(model, _block_convs(sq["key"], sq["bp"]))
+    assert not grads.packed
     model._ctx = None

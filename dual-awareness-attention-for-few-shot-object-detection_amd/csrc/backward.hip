@@ -271,6 +271,28 @@ int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const floa
 // ---- attention adjoints ---------------------------------------------------------------------------------
 namespace {
 
+// torch.optim.SGD(momentum) over a flat parameter segment (train.py:86-87): g' = g + wd * p;
+// buf = first ? g' : momentum * buf + g';  p -= lr * buf.  grad_scale folds the 1/world_size of the gradient mean.
+__global__ void __launch_bounds__(256)
+sgd_momentum_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ buf, long n4, float lr,
+                    float momentum, float wd, float grad_scale, int first) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)blockDim.x * gridDim.x) {
+    float4 pv = p[i];
+    const float4 gv = g[i];
+    float4 b = first ? make_float4(0.f, 0.f, 0.f, 0.f) : buf[i];
+    b.x = momentum * b.x + (gv.x * grad_scale + wd * pv.x);
+    b.y = momentum * b.y + (gv.y * grad_scale + wd * pv.y);
+    b.z = momentum * b.z + (gv.z * grad_scale + wd * pv.z);
+    b.w = momentum * b.w + (gv.w * grad_scale + wd * pv.w);
+    pv.x -= lr * b.x;
+    pv.y -= lr * b.y;
+    pv.z -= lr * b.z;
+    pv.w -= lr * b.w;
+    buf[i] = b;
+    p[i] = pv;
+  }
+}
+
 // adjoint of dana_rowdot (nn.Linear(dim, 1)): partial[chunk][c] = sum_r dl[r] * x[r][c]  (-> dw by colsum_final)
 // and, when dx is given, dx[r][c] += dl[r] * w[c].
 __global__ void __launch_bounds__(256)
@@ -423,6 +445,20 @@ rpn_loss_bwd_kernel(const float* __restrict__ heads, long hs, const float* __res
 }  // namespace
 
 extern "C" {
+
+int dana_sgd_momentum(float* params, const float* grads, float* momentum_buf, long n, float lr, float momentum,
+                      float weight_decay, float grad_scale, int first_step, dana_stream_t stream) {
+  DANA_CHECK_ARG(n >= 0 && n % 4 == 0, "dana_sgd_momentum: n must be a multiple of 4 (pad the flat segment)");
+  if (n == 0) return DANA_OK;
+  DANA_CHECK_ARG(params && grads && momentum_buf, "dana_sgd_momentum: null pointer");
+  DANA_CHECK_ARG((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) & 15) == 0,
+                 "dana_sgd_momentum: buffers must be 16-byte aligned");
+  sgd_momentum_kernel<<<grid_for(n / 4, 256), 256, 0, (hipStream_t)stream>>>((float4*)params, (const float4*)grads,
+                                                                            (float4*)momentum_buf, n / 4, lr, momentum,
+                                                                            weight_decay, grad_scale, first_step);
+  DANA_CHECK_LAUNCH("dana_sgd_momentum");
+  return DANA_OK;
+}
 
 int dana_rowdot_backward(const float* x, const float* grad_out, const float* w, float* grad_x, float* grad_w, long rows,
                          int dim, long ld_x, long ld_grad_x, int accumulate_w, void* workspace, size_t workspace_bytes,

@@ -113,6 +113,23 @@ def positional_encoding_table(max_len, d_model=1024):
     return pe
 
 
+class _LossBridge(torch.autograd.Function):
+    """Connects the four training losses to torch autograd so that the reference's `loss.backward()`
+    (train.py:141-143) drives backward.model_backward: gradients land in `.grad` of the model's parameters."""
+
+    @staticmethod
+    def forward(fctx, anchor, model, l1, l2, l3, l4):
+        fctx.model = model
+        return l1.clone(), l2.clone(), l3.clone(), l4.clone()
+
+    @staticmethod
+    def backward(fctx, g1, g2, g3, g4):
+        from . import backward as BW
+        gs = [torch.zeros((), device=fctx.model._grad_anchor.device) if g is None else g.reshape(()) for g in (g1, g2, g3, g4)]
+        BW.model_backward(fctx.model, torch.stack(gs).tolist())  # one D2H read of the four upstream scalars
+        return None, None, None, None, None, None
+
+
 class DAnARCNN(nn.Module):
     """Dual-Awareness-Attention Faster R-CNN (dana.py:19,327)."""
 
@@ -166,6 +183,8 @@ class DAnARCNN(nn.Module):
         self.output_score_layer = FFN(64 * 49, dim_in)
         self._plan = None
         self._consts = {}
+        self._ctx = None          # saved-for-backward context of the last training forward
+        self._grad_anchor = None  # autograd leaf the loss bridge hangs on
 
     # ---- reference API -------------------------------------------------------------------------
     def create_architecture(self):
@@ -266,7 +285,7 @@ class DAnARCNN(nn.Module):
         return p
 
     def _stream(self, name, dev):
-        if getattr(self, "_single_stream", False) or (self.training and getattr(self, "save_for_backward", False)):
+        if getattr(self, "_single_stream", False) or getattr(self, "_ctx", None) is not None:
             return torch.cuda.current_stream()  # bench.py's per-launch timing pass / saved-for-backward runs: no overlap
         key = ("stream", name, str(dev))
         st = self._consts.get(key)
@@ -409,12 +428,15 @@ class DAnARCNN(nn.Module):
                 gev.append((name, e))
 
         ctx = None
-        if training and getattr(self, "save_for_backward", False):
+        self._bridge = training and torch.is_grad_enabled()  # train.py:141-143 will call loss.backward()
+        if training and (self._bridge or getattr(self, "save_for_backward", False)):
             # everything backward.model_backward needs; the forward then runs on ONE stream (saved tensors are
             # consumed by the backward on the caller's stream)
             if self.merge_trunk or self.query_streams != 1:
                 raise RuntimeError("save_for_backward needs merge_trunk=False and query_streams=1")
             ctx = self._ctx = dict(plan=plan, B=B, shot=shot, way=way, q_saved=[], s_saved=[], l4_saved=[], heads=[])
+        else:
+            self._ctx = None
         mark("begin")
         inputs_ready = torch.cuda.Event()
         inputs_ready.record()
@@ -695,4 +717,10 @@ class DAnARCNN(nn.Module):
         mark("rcnn losses")
         if tl is not None:
             tl.append(("rcnn losses", _time.perf_counter()))
+        if ctx is not None and self._bridge:
+            # hand the four losses to autograd: loss.backward() runs backward.model_backward on the HIP kernels
+            if self._grad_anchor is None or self._grad_anchor.device != dev:
+                self._grad_anchor = torch.zeros(1, device=dev, requires_grad=True)
+            rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox = _LossBridge.apply(
+                self._grad_anchor, self, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox)
         return rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox, rois_label

@@ -703,3 +703,11 @@ def linear_backward(g, x, w, m, n, k, ldx=0, ldg=0, ldw=0, need_dx=True, dx_out=
         else:
             dx = gemm_nt(g, wt, m, k, n, lda=ldg, out=dx_out, ldc=dx_ld or k, residual=dx_out, ldr=dx_ld or k)
     return dw, db, dx
+
+
+def sgd_momentum_(params, grads, buf, lr, momentum, weight_decay, grad_scale=1.0, first_step=False):
+    """fused torch.optim.SGD(momentum) update of one flat fp32 segment (numel % 4 == 0), in place"""
+    n = params.numel()
+    lib().call("dana_sgd_momentum", _p(_chk(params, "params")), _p(_chk(grads, "grads")), _p(_chk(buf, "buf")), n,
+               float(lr), float(momentum), float(weight_decay), float(grad_scale), int(bool(first_step)), _stream())
+    return params

@@ -1,0 +1,155 @@
+"""The reference's training iteration (train.py:125-143) on the HIP path, one process per GPU:
+
+    zero_grad -> model(...) -> loss = sum of the four loss means -> loss.backward() -> optimizer.step()
+
+* `FlatBuckets`: parameters, gradients and momentum live in flat fp32 buffers laid out in the order
+  backward.model_backward FINISHES the gradients, cut into buckets at parameter boundaries. As soon as a bucket's
+  gradients are final it leaves on an asynchronous all-reduce (RCCL over xGMI when the process group is `nccl`;
+  `gloo` on CPU in the tests) while the rest of the backward still runs: the one exchange step of the data-parallel
+  path (replaces nn.DataParallel's reduce-add onto GPU 0, train.py:104-105).
+* `Trainer`: torch.optim.SGD(momentum) semantics of train.py:76-87 (2x learning rate and no weight decay for biases)
+  as one fused HIP launch per flat segment; the 1/world_size of the gradient mean is folded into that launch.
+"""
+import torch
+import torch.distributed as dist
+
+from . import backward as BW
+from .config import cfg
+
+
+class FlatBuckets:
+    """Flat storage for an ordered list of (name, tensor) + bucketed asynchronous all-reduce of the gradients."""
+
+    def __init__(self, named_params, bucket_bytes=32 << 20, process_group=None, world_size=None):
+        named_params = list(named_params)
+        if not named_params:
+            raise ValueError("FlatBuckets: no parameters")
+        dev = named_params[0][1].device
+        self.names = [n for n, _ in named_params]
+        self.offsets, off = {}, 0
+        for n, p in named_params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("FlatBuckets: %s must be float32 on %s" % (n, dev))
+            self.offsets[n] = (off, p.numel())
+            off += (p.numel() + 3) // 4 * 4  # every parameter starts 16-byte aligned
+        self.numel = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        # buckets: consecutive parameters up to bucket_bytes (a larger parameter is its own bucket)
+        self.buckets, start, cur = [], 0, []
+        for n in self.names:
+            o, k = self.offsets[n]
+            if cur and (o + k - start) * 4 > bucket_bytes:
+                self.buckets.append((start, o, cur))
+                start, cur = o, []
+            cur.append(n)
+        self.buckets.append((start, off, cur))
+        self.bucket_of = {n: i for i, (_, _, ns) in enumerate(self.buckets) for n in ns}
+        self.group = process_group
+        self.world = world_size if world_size is not None else (
+            dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1)
+        self._pending = [len(ns) for _, _, ns in self.buckets]
+        self._works = []
+        self.launch_order = []
+        for n, p in named_params:  # re-point parameter and gradient storage into the flat buffers
+            o, k = self.offsets[n]
+            self.params[o:o + k].copy_(p.detach().reshape(-1))
+            p.data = self.params[o:o + k].view(p.shape)
+            p.grad = self.grads[o:o + k].view(p.shape)
+
+    def zero_grad(self):
+        self.grads.zero_()
+        self._pending = [len(ns) for _, _, ns in self.buckets]
+        self._works = []
+        self.launch_order = []
+
+    def mark_ready(self, names):
+        """the gradients of `names` are final: launch every bucket that became complete"""
+        for n in names:
+            i = self.bucket_of.get(n)
+            if i is None:
+                continue  # frozen parameter
+            self._pending[i] -= 1
+            if self._pending[i] == 0:
+                self._launch(i)
+            elif self._pending[i] < 0:
+                raise RuntimeError("FlatBuckets: %s marked ready twice" % n)
+
+    def _launch(self, i):
+        self.launch_order.append(i)
+        if self.world > 1:
+            s, e, _ = self.buckets[i]
+            self._works.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait_all(self):
+        """all buckets must have left; blocks the current stream (not the host, for nccl) until the sums arrived"""
+        missing = [i for i, k in enumerate(self._pending) if k > 0]
+        if missing:
+            raise RuntimeError("FlatBuckets: gradients never marked ready in buckets %s (e.g. %s)"
+                               % (missing, self.buckets[missing[0]][2][:3]))
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def broadcast_params(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.params, src, group=self.group)
+
+
+class Trainer:
+    def __init__(self, model, lr, momentum=None, weight_decay=None, double_bias=None, bias_decay=None,
+                 process_group=None, bucket_bytes=32 << 20):
+        self.model = model
+        self.lr = float(lr)
+        self.momentum = float(cfg.TRAIN.MOMENTUM if momentum is None else momentum)
+        wd = float(cfg.TRAIN.WEIGHT_DECAY if weight_decay is None else weight_decay)
+        double_bias = cfg.TRAIN.DOUBLE_BIAS if double_bias is None else double_bias
+        bias_decay = cfg.TRAIN.BIAS_DECAY if bias_decay is None else bias_decay
+        params = dict(model.named_parameters())
+        order = [n for _, names in BW.grad_stages(model) for n in names if params[n].requires_grad]
+        left = [n for n, p in params.items() if p.requires_grad and n not in set(order)]
+        if left:
+            raise RuntimeError("trainable parameters without a HIP gradient: %s" % left[:5])
+        # train.py:79-84: 'bias' in key -> lr * (DOUBLE_BIAS + 1), weight decay only if BIAS_DECAY
+        w_names = [n for n in order if "bias" not in n]
+        b_names = [n for n in order if "bias" in n]
+        self.weights = FlatBuckets([(n, params[n]) for n in w_names], bucket_bytes, process_group)
+        self.biases = FlatBuckets([(n, params[n]) for n in b_names], bucket_bytes, process_group)
+        self.groups = [(self.weights, 1.0, wd), (self.biases, float(double_bias) + 1.0, wd if bias_decay else 0.0)]
+        self.bufs = [torch.zeros_like(fb.params) for fb, _, _ in self.groups]
+        self.steps = 0
+        model._plan = None  # parameter storage moved: re-pack on the next forward
+        model._grad_ready_cb = self._on_ready
+        for fb, _, _ in self.groups:
+            fb.broadcast_params(0)  # one-time parameter broadcast (replicas start identical)
+
+    def _on_ready(self, names):
+        for fb, _, _ in self.groups:
+            fb.mark_ready(names)
+
+    def zero_grad(self):
+        for fb, _, _ in self.groups:
+            fb.zero_grad()
+
+    def optimizer_step(self):
+        from . import ops
+        for (fb, lr_mult, wd), buf in zip(self.groups, self.bufs):
+            fb.wait_all()
+            ops.sgd_momentum_(fb.params, fb.grads, buf, self.lr * lr_mult, self.momentum, wd,
+                              grad_scale=1.0 / fb.world, first_step=self.steps == 0)
+        self.steps += 1
+        self.model._plan = None  # weights changed under the packed / folded / Winograd-transformed copies
+
+    def step(self, im_data, im_info, gt_boxes, num_boxes, support_ims):
+        """one training iteration; returns the model's 8-tuple (losses detached)"""
+        self.zero_grad()
+        with torch.enable_grad():
+            out = self.model(im_data, im_info, gt_boxes, num_boxes, support_ims)
+            loss = out[3].mean() + out[4].mean() + out[5].mean() + out[6].mean()  # train.py:138-139
+        loss.backward()
+        self.optimizer_step()
+        return out
+
+    def adjust_learning_rate(self, decay=0.1):
+        """net_utils.adjust_learning_rate (train.py:118-120)"""
+        self.lr *= decay

@@ -281,6 +281,10 @@ int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const floa
                     float* c, long c_stride_m, long c_stride_n, int m, int n, int k, float alpha, int accumulate,
                     dana_stream_t stream);                       /* skinny heads (N or K of 2 / 4) */
 
+/* torch.optim.SGD with momentum over a flat fp32 segment (train.py:76-87: lr, 2x lr and no decay for biases):
+ * g' = grad_scale * g + weight_decay * p; buf = first_step ? g' : momentum * buf + g'; p -= lr * buf */
+int dana_sgd_momentum(float* params, const float* grads, float* momentum_buf, long n, float lr, float momentum,
+                      float weight_decay, float grad_scale, int first_step, dana_stream_t stream);
 /* adjoint of dana_rowdot: grad_w[dim] (+)= sum_r grad_out[r] x[r]; grad_x[r] += grad_out[r] w (grad_x may be NULL);
  * workspace: dana_colsum_workspace_bytes(rows, dim) */
 int dana_rowdot_backward(const float* x, const float* grad_out, const float* w, float* grad_x, float* grad_w, long rows,

@@ -153,3 +153,58 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba):
         worst.append(((g.cpu() - v.grad).abs().max().item() / scale, k, scale))
     worst.sort(reverse=True)
     assert worst[0][0] <= 5e-3, "largest relative gradient errors: %s" % (worst[:8],)
+
+
+def test_trainer_step_matches_reference_loop_with_torch_sgd(dev):
+    """two iterations of train.py:125-143 (zero_grad, forward, summed loss, loss.backward(), SGD step with the
+    bias / weight parameter groups of train.py:76-87) through the autograd bridge + torch.optim.SGD, against
+    Trainer.step (flat buffers + fused HIP SGD): same parameters afterwards, and the second forward sees the update"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    from dana_amd.config import cfg
+    from dana_amd.trainer import Trainer
+    B, way, shot, H, W = 2, 2, 2, 160, 224
+    lr = 0.01
+
+    def build():
+        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=way, shot=shot, classes=["fg", "bg"])
+        m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=5, profile="test"))
+        return m.to(dev).train()
+
+    inputs = [t.to(dev) for t in S.episode_inputs(B, way, shot, H, W, seed=6)]
+    ma, mb = build(), build()
+    groups = []
+    for key, value in dict(ma.named_parameters()).items():
+        if value.requires_grad:
+            if "bias" in key:
+                groups.append({"params": [value], "lr": lr * (cfg.TRAIN.DOUBLE_BIAS + 1),
+                               "weight_decay": cfg.TRAIN.BIAS_DECAY and cfg.TRAIN.WEIGHT_DECAY or 0})
+            else:
+                groups.append({"params": [value], "lr": lr, "weight_decay": cfg.TRAIN.WEIGHT_DECAY})
+    opt = torch.optim.SGD(groups, momentum=cfg.TRAIN.MOMENTUM)
+    tr = Trainer(mb, lr)
+    losses_a, losses_b = [], []
+    for it in range(2):
+        np.random.seed(40 + it)
+        ma.zero_grad()
+        out = ma(*inputs)
+        loss = out[3].mean() + out[4].mean() + out[5].mean() + out[6].mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses_a.append([float(x.detach()) for x in out[3:7]])
+        np.random.seed(40 + it)
+        outb = tr.step(*inputs)
+        losses_b.append([float(x.detach()) for x in outb[3:7]])
+    assert losses_a[0] == losses_b[0]
+    assert losses_a[0] != losses_a[1], "the second forward must see the updated weights"
+    for x, y in zip(losses_a[1], losses_b[1]):
+        assert abs(x - y) <= 1e-5 * max(1.0, abs(x))
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    for k in pa:
+        d = (pa[k].detach() - pb[k].detach()).abs().max().item()
+        assert d <= 1e-6 + 1e-5 * pa[k].detach().abs().max().item(), (k, d)
+    sd0 = S.fill_state_dict(ma.state_dict(), seed=5, profile="test")
+    moved = [k for k in pa if pa[k].requires_grad and not torch.equal(pa[k].detach().cpu(), sd0[k])]
+    # the 7 biases in front of a mean subtraction / softmax have zero gradient (and no weight decay): they stay
+    assert len(moved) == sum(p.requires_grad for p in pa.values()) - 7

@@ -41,6 +41,34 @@ def _worker(rank, world, port, q):
         parallel.allreduce_mean_(grads, bucket_bytes=64)
         assert torch.allclose(grads[0], torch.full((7, 3), 1.5)) and torch.allclose(grads[1], torch.full((5,), 15.0))
         assert torch.allclose(grads[2], torch.full((2, 2), -0.5))
+        # the trainer's flat gradient buckets: all-reduce leaves bucket by bucket as gradients are marked final
+        from dana_amd.trainer import FlatBuckets
+        torch.manual_seed(3)
+        ps = [("a.weight", torch.nn.Parameter(torch.randn(6, 5))), ("b.weight", torch.nn.Parameter(torch.randn(33))),
+              ("c.weight", torch.nn.Parameter(torch.randn(4, 4))), ("d.weight", torch.nn.Parameter(torch.randn(7)))]
+        before = [p.detach().clone() for _, p in ps]
+        fb = FlatBuckets(ps, bucket_bytes=160)  # -> buckets {a}, {b}, {c, d}
+        assert [ns for _, _, ns in fb.buckets] == [["a.weight"], ["b.weight"], ["c.weight", "d.weight"]]
+        assert all(torch.equal(p.detach(), b0_) for (_, p), b0_ in zip(ps, before))  # values survive the re-pointing
+        assert all(o % 4 == 0 for o, _ in fb.offsets.values())
+        fb.zero_grad()
+        for i, (_, p) in enumerate(ps):
+            p.grad.add_(float((rank + 1) * (i + 1)))
+        fb.mark_ready(["a.weight"])
+        fb.mark_ready(["c.weight"])
+        assert fb.launch_order == [0]
+        fb.mark_ready(["d.weight", "frozen.weight", "b.weight"])
+        assert fb.launch_order == [0, 2, 1]
+        fb.wait_all()
+        for i, (_, p) in enumerate(ps):  # SUM over the two ranks; the mean's 1/world is folded into the SGD launch
+            assert torch.allclose(p.grad, torch.full_like(p, 3.0 * (i + 1)))
+        fb.zero_grad()
+        fb.mark_ready(["a.weight"])
+        try:
+            fb.wait_all()
+            raise AssertionError("wait_all must refuse while buckets never left")
+        except RuntimeError:
+            pass
         # step time = max over ranks
         assert parallel.max_over_ranks(1.0 + rank, torch.device("cpu")) == 2.0
         q.put((rank, "ok"))
