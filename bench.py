@@ -41,7 +41,10 @@ def parse():
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--ba", action="store_true", help="full BA+CISA (configs[2]); default CISA only (configs[1])")
-    ap.add_argument("--mode", default="train", choices=["train", "eval"], help="train-mode forward (default)")
+    ap.add_argument("--mode", default="train", choices=["train", "eval", "step"],
+                    help="train: train-mode forward (variant F, the headline); eval: inference forward; step: the full "
+                         "training iteration fwd+bwd+gradient all-reduce+SGD (variant S) as the headline")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the secondary variant-S measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
@@ -90,7 +93,7 @@ def main():
 
     import dana_amd
     from dana_amd import ops, synthetic as S
-    training = args.mode == "train"
+    training = args.mode in ("train", "step")
     way = args.way if training else 1
     model = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=args.ba, way=args.way, shot=args.shot,
                                classes=["fg", "bg"])
@@ -103,10 +106,21 @@ def main():
     inputs = [t.to(dev) for t in S.episode_inputs(args.batch, way, args.shot, args.height, args.width,
                                                   seed=1996 + rank)]
 
-    def step():
+    trainer = [None]
+
+    def train_step():
+        # train.py:125-143: zero_grad, forward, summed loss, backward (HIP kernels, bucketed RCCL all-reduce of the
+        # gradients overlapped with it), fused SGD
+        if trainer[0] is None:
+            from dana_amd.trainer import Trainer
+            trainer[0] = Trainer(model, lr=1e-5)
+        return trainer[0].step(*inputs)
+
+    def fwd_step():
         with torch.no_grad():
             return model(*inputs)
 
+    step = train_step if args.mode == "step" else fwd_step
     np.random.seed(1996 + rank)
     for _ in range(args.warmup):
         step()
@@ -128,9 +142,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    what = "training step fwd+bwd+allreduce+SGD" if args.mode == "step" else "%s-mode forward" % args.mode
     result = {
-        "metric": "query-images/sec (res50, way=%d, shot=%d, bs=%d per GPU, %s-mode forward)" % (
-            args.way, args.shot, args.batch, args.mode),
+        "metric": "query-images/sec (res50, way=%d, shot=%d, bs=%d per GPU, %s)" % (
+            args.way, args.shot, args.batch, what),
         "value": round(world * args.batch * args.steps / dt, 3),
         "unit": "query-images/sec",
         "n_gpus": world,
@@ -144,13 +159,46 @@ def main():
         "dtype": "f32",
         "data": "synthetic (seeded N(0,64^2) query/support pixels, 3 gt boxes/image, random-init weights)",
         "config": {"workload": "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d 320x320 "
-                               "supports/episode, %s, %s-mode forward" % (
+                               "supports/episode, %s, %s" % (
                                    2 if args.ba else 1, args.way, args.shot, args.batch, args.height, args.width,
-                                   way * args.shot, "BA+CISA" if args.ba else "CISA only", args.mode),
+                                   way * args.shot, "BA+CISA" if args.ba else "CISA only", what),
                    "global_batch": world * args.batch, "parallelism": "episodes sharded, %d rank(s)" % world},
     }
 
-    if rank == 0 and not args.no_roofline:
+    if args.mode == "train" and not args.no_train_step:
+        # secondary measurement, every rank: variant S, the full training iteration with the
+        # gradient all-reduce over RCCL as its one exchange step. Same episodes, same timing protocol.
+        ks, kw = max(3, min(args.steps, 10)), 5  # the first iterations grow the allocator's pools
+        for _ in range(kw):
+            train_step()
+        barrier()
+        t0 = time.perf_counter()
+        marks = []
+        for _ in range(ks):
+            train_step()
+            if os.environ.get("DANA_BENCH_DEBUG"):
+                torch.cuda.synchronize()
+                marks.append(time.perf_counter())
+        barrier()
+        dts = time.perf_counter() - t0
+        if marks:
+            print("train_step iteration ms:", " ".join("%.1f" % ((b_ - a_) * 1e3) for a_, b_ in zip([t0] + marks, marks)),
+                  file=sys.stderr)
+        if world > 1:
+            t = torch.tensor([dts], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        tr = trainer[0]
+        result["train_step"] = {
+            "what": "train.py:125-143 iteration: forward + backward (HIP kernels) + bucketed gradient all-reduce "
+                    "(%s) + fused SGD" % ("RCCL, %d ranks" % world if world > 1 else "single rank: no exchange"),
+            "value": round(world * args.batch * ks / dts, 3), "unit": "query-images/sec", "steps": ks, "warmup": kw,
+            "ms_per_step": round(1000.0 * dts / ks, 3),
+            "gradient_mbytes": round(4e-6 * sum(fb.numel for fb, _, _ in tr.groups), 1),
+            "buckets": sum(len(fb.buckets) for fb, _, _ in tr.groups),
+        }
+
+    if rank == 0 and not args.no_roofline and args.mode != "step":
         # dominant kernel family: igemm_f32_kernel (every conv / Linear / bmm). Same K steps, each launch
         # bracketed by HIP events recorded on the stream the kernel is launched on (torch's current stream).
         # The product overlaps independent branches on several streams; for a per-kernel duration the

@@ -51,37 +51,61 @@ class WeightGrads:
                 self.finish_conv(key, self.convs[key], model.get_parameter(key + ".weight"))
 
 
+def _dgrad_weights(c):
+    """flipped / transposed / BN-scaled weights of the data-gradient conv (+ their Winograd transform when the
+    forward conv took the Winograd path), cached in the plan entry: computed once per weight update"""
+    if c.get("wd") is None:
+        c["wd"] = ops.conv2d_dgrad_weight(c["w"], c["cout"], c["cin"], c["k"], c["k"], c.get("scale"))
+        c["ud"] = None
+        if c.get("u") is not None and c["cout"] % 64 == 0:
+            c["ud"] = ops.winograd_filter_transform(c["wd"], c["cin"], c["cout"])
+    return c["wd"], c["ud"]
+
+
+def conv_dgrad(g, n, h, w, c, residual=None, mask=None, compact_out=False):
+    """dL/d(conv input) [n*h*w][cin] from g = dL/d(conv+BN output); + residual, then the ReLU adjoint of `mask`"""
+    wd, ud = _dgrad_weights(c)
+    return ops.conv2d_dgrad(g, c["w"], n, h, w, c["cin"], c["cout"], c["k"], c["k"], c["stride"], c["pad"], wd=wd, ud=ud,
+                            residual=residual, mask=mask, compact_out=compact_out)
+
+
 def conv_backward(g, x, n, h, w, c, grads, key, need_dx=True, in_stride=0):
     """g: gradient w.r.t. the conv+BN output [n*oh*ow][cout] (ReLU mask already applied).
     Records dW (raw, scale applied at finish) and returns dx [n*h*w][cin] (or None)."""
     grads.add_conv(key, g, x, n, h, w, c, in_stride=in_stride)
-    if not need_dx:
-        return None
-    return ops.conv2d_dgrad(g, c["w"], n, h, w, c["cin"], c["cout"], c["k"], c["k"], c["stride"], c["pad"],
-                            scale=c.get("scale"))
+    return conv_dgrad(g, n, h, w, c) if need_dx else None
 
 
-def bottleneck_backward(g_out, saved, n, h, w, bp, grads, key, need_dx=True):
-    """Adjoint of DAnARCNN._bottleneck. saved = dict(x, o1, o2, o3, h1, w1) from the forward; g_out = dL/d(o3).
-    Returns dL/dx [n*h*w][cin] (None if not needed). g_out is consumed (masked in place)."""
+def bottleneck_backward(g, saved, n, h, w, bp, grads, key, need_dx=True, mask_dx=True, g_masked=False):
+    """Adjoint of DAnARCNN._bottleneck. saved = dict(x, o1, o2, o3, h1, w1) from the forward; g = dL/d(o3), with the
+    final ReLU's adjoint (resnet.py:100) already applied when g_masked. Returns dL/dx [n*h*w][cin] (None if not
+    needed); with mask_dx the ReLU adjoint of the layer that produced x is already applied to it (x is then the
+    previous bottleneck's output, so the caller passes g_masked=True there). Every ReLU adjoint and the residual
+    sum ride in the epilogue of a data-gradient conv."""
     h1, w1 = saved["h1"], saved["w1"]
     m_out = n * h1 * w1
     cout = bp["c3"]["cout"]
-    g = ops.relu_mask_(g_out, saved["o3"], m_out, cout, ld_act=saved.get("o3_ld", 0))  # final ReLU (resnet.py:100)
-    # main branch: conv3 <- conv2 <- conv1
-    g2 = conv_backward(g, saved["o2"], n, h1, w1, bp["c3"], grads, key + ".conv3")
-    ops.relu_mask_(g2, saved["o2"], m_out, bp["c2"]["cout"])
-    g1 = conv_backward(g2, saved["o1"], n, h1, w1, bp["c2"], grads, key + ".conv2")
-    ops.relu_mask_(g1, saved["o1"], m_out, bp["c1"]["cout"])
-    dx = conv_backward(g1, saved["x"], n, h, w, bp["c1"], grads, key + ".conv1", need_dx=need_dx)
-    # residual branch (resnet.py:96-99)
+    if not g_masked:
+        ops.relu_mask_(g, saved["o3"], m_out, cout, ld_act=saved.get("o3_ld", 0))
+    x = saved["x"]
+    grads.add_conv(key + ".conv3", g, saved["o2"], n, h1, w1, bp["c3"])
+    g2 = conv_dgrad(g, n, h1, w1, bp["c3"], mask=saved["o2"])
+    grads.add_conv(key + ".conv2", g2, saved["o1"], n, h1, w1, bp["c2"])
+    g1 = conv_dgrad(g2, n, h1, w1, bp["c2"], mask=saved["o1"])
+    grads.add_conv(key + ".conv1", g1, x, n, h, w, bp["c1"])
     if bp["ds"] is not None:
-        dxr = conv_backward(g, saved["x"], n, h, w, bp["ds"], grads, key + ".downsample.0", need_dx=need_dx)
-        if need_dx:
-            ops.axpy_rows_(dx, dxr, n * h * w, bp["c1"]["cin"])
-    elif need_dx:
-        ops.axpy_rows_(dx, g, n * h * w, cout)
-    return dx
+        grads.add_conv(key + ".downsample.0", g, x, n, h, w, bp["ds"])
+    if not need_dx:
+        return None
+    mk = x if mask_dx else None
+    if bp["ds"] is None:  # identity shortcut (resnet.py:96-99): dx = dgrad(conv1) + g
+        return conv_dgrad(g1, n, h, w, bp["c1"], residual=g, mask=mk)
+    if bp["c1"]["stride"] == 1:
+        dxr = conv_dgrad(g, n, h, w, bp["ds"])
+        return conv_dgrad(g1, n, h, w, bp["c1"], residual=dxr, mask=mk)
+    # both 1x1 convs are strided (resnet.py:71, downsample): sum the compact gradients, scatter once
+    cr = conv_dgrad(g, n, h, w, bp["ds"], compact_out=True)
+    return conv_dgrad(g1, n, h, w, bp["c1"], residual=cr, mask=mk)
 
 
 def _block_convs(prefix, bp):
@@ -193,8 +217,9 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     l4 = ctx["l4_saved"]
     npos = l4[-1]["h1"] * l4[-1]["w1"]
     g = ops.broadcast_rows(d_fc7, n_roi, npos, 2048, alpha=1.0 / npos)
-    for sv in reversed(l4):
-        g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"])
+    for i, sv in enumerate(reversed(l4)):  # the first block's input is the RoIAlign output: no ReLU in front of it
+        g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"],
+                                mask_dx=i < len(l4) - 1, g_masked=i > 0)
     d_pooled = g  # [n_roi*49][1024]
     grads.finish_all(model, "RCNN_top")
     stages = grad_stages(model)
@@ -214,8 +239,9 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     d_k2 = torch.zeros((Ns * P2, dq), dtype=torch.float32, device=dev)
     d_un2 = torch.zeros((Ns, P2), dtype=torch.float32, device=dev)
     d_wt = torch.zeros_like(wt)
-    for hi, hc in enumerate(ctx["heads"]):
+    for hc in ctx["heads"]:
         off = hc["offset"]
+        hi = 0 if off == 0 else 1  # rows of cls_score_all: positive-support scores first (dana.py:194)
         ds = d_score[hi * n_roi:(hi + 1) * n_roi].contiguous()
         _acc(model.output_score_layer.linear2.weight, ops.gemm_small(ds, (1, 2), hc["hid"], (nhid, 1), 2, nhid, n_roi))
         _acc(model.output_score_layer.linear2.bias, ops.colsum(ds, n_roi, 2))
@@ -276,7 +302,8 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None)
     grads.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn)
     _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
-    d_corr = ops.conv2d_dgrad(d_x, plan["rpn_conv_w"], B, fh, fw, rpn.din, 512, 3, 3, 1, 1)  # [B*hw][2048]
+    c_rpn["u"] = plan["rpn_conv_u"]
+    d_corr = conv_dgrad(d_x, B, fh, fw, c_rpn)  # [B*hw][2048]
 
     # -- RPN-level attention (dana.py:118-154): corr = [base_feat | dense] --
     K1 = shot * L
@@ -331,8 +358,10 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     nblk = len(qs)
     for i in range(nblk - 1, -1, -1):
         sq, s_ = qs[i], ss[i]
-        gq = bottleneck_backward(gq, sq, sq["n"], sq["h"], sq["w"], sq["bp"], grads, sq["key"], need_dx=i > 0)
-        gs = bottleneck_backward(gs, s_, s_["n"], s_["h"], s_["w"], s_["bp"], grads, s_["key"], need_dx=i > 0)
+        gq = bottleneck_backward(gq, sq, sq["n"], sq["h"], sq["w"], sq["bp"], grads, sq["key"], need_dx=i > 0,
+                                 g_masked=i < nblk - 1)
+        gs = bottleneck_backward(gs, s_, s_["n"], s_["h"], s_["w"], s_["bp"], grads, s_["key"], need_dx=i > 0,
+                                 g_masked=i < nblk - 1)
         grads.finish_all(model, sq["key"] + ".")
         _ready(model, _block_convs(sq["key"], sq["bp"]))
     assert not grads.packed

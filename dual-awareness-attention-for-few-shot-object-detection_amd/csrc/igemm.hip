@@ -46,6 +46,8 @@ struct IgemmParams {
   const float* scale;     // [N] or null
   const float* shift;     // [N] or null
   const float* residual;  // [M][ldr] or null
+  const float* mask;      // [M][ldm] or null: out = act > 0 ? out : 0 (ReLU adjoint fused into a data-gradient conv)
+  long ldm;
   int M, N, K;
   int IH, IW, OH, OW, Cin, KH, KW, stride, pad;
   // optional second geometry segment: rows m >= M0 are pixels of images IH1 x IW1 that start `pix1`
@@ -294,6 +296,13 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
       }
+      if (p.mask) {
+        const float4 k4 = *(const float4*)(p.mask + (long)m * p.ldm + n);
+        v[0] = k4.x > 0.f ? v[0] : 0.f;
+        v[1] = k4.y > 0.f ? v[1] : 0.f;
+        v[2] = k4.z > 0.f ? v[2] : 0.f;
+        v[3] = k4.w > 0.f ? v[3] : 0.f;
+      }
       *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
@@ -302,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
           float x = v[q];
           if (p.residual) x += rp[q];
           if (p.relu) x = fmaxf(x, 0.f);
+          if (p.mask && !(p.mask[(long)m * p.ldm + n + q] > 0.f)) x = 0.f;
           cp[q] = x;
         }
     }
@@ -397,7 +407,8 @@ static int conv2d_impl(const char* who, const float* input, const float* weight,
                        const float* scale, const float* shift, const float* res0, const float* res1, int batch0,
                        int h0, int w0, int batch1, int h1, int w1, int cin, int cout, int kh, int kw, int stride,
                        int pad, long in_pix_stride, long out0_stride, long out1_stride, long res0_stride,
-                       long res1_stride, int flags, dana_stream_t stream) {
+                       long res1_stride, int flags, dana_stream_t stream, const float* mask = nullptr,
+                       long mask_stride = 0) {
   DANA_CHECK_ARG(batch0 >= 0 && batch1 >= 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
                  "%s: bad shape", who);
   DANA_CHECK_ARG((batch0 == 0 || (h0 > 0 && w0 > 0)) && (batch1 == 0 || (h1 > 0 && w1 > 0)), "%s: bad image size", who);
@@ -443,6 +454,10 @@ static int conv2d_impl(const char* who, const float* input, const float* weight,
   p.pad = pad;
   p.alpha = 1.f;
   p.relu = (flags & DANA_EPI_RELU) ? 1 : 0;
+  p.mask = mask;
+  p.ldm = mask_stride > 0 ? mask_stride : cout;
+  DANA_CHECK_ARG(!mask || (batch1 == 0 && p.ldm % 4 == 0 && ((uintptr_t)mask & 15) == 0),
+                 "%s: mask needs a single segment and 16-byte aligned rows", who);
   long lda;
   if (stem) {
     // input is NHWC4 (3 channels + zero pad), weight packed [cout][7][8][4] (K = 224)
@@ -482,6 +497,16 @@ int dana_conv2d_nhwc(const float* input, const float* weight, float* output, con
   return conv2d_impl("dana_conv2d_nhwc", input, weight, output, nullptr, scale, shift, residual, nullptr, batch, in_h,
                      in_w, 0, 0, 0, cin, cout, kh, kw, stride, pad, in_pix_stride, out_pix_stride, 0, res_pix_stride,
                      0, flags, stream);
+}
+
+int dana_conv2d_nhwc_masked(const float* input, const float* weight, float* output, const float* scale,
+                            const float* shift, const float* residual, const float* mask_act, int batch, int in_h,
+                            int in_w, int cin, int cout, int kh, int kw, int stride, int pad, long in_pix_stride,
+                            long out_pix_stride, long res_pix_stride, long mask_pix_stride, int flags,
+                            dana_stream_t stream) {
+  return conv2d_impl("dana_conv2d_nhwc_masked", input, weight, output, nullptr, scale, shift, residual, nullptr, batch,
+                     in_h, in_w, 0, 0, 0, cin, cout, kh, kw, stride, pad, in_pix_stride, out_pix_stride, 0,
+                     res_pix_stride, 0, flags, stream, mask_act, mask_pix_stride);
 }
 
 int dana_conv2d_nhwc_dual(const float* input, const float* weight, float* out0, float* out1, const float* scale,

@@ -148,15 +148,24 @@ dgrad_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale
 
 // strided 1x1 data gradient: g_in[b][2oh*s][2ow*s][:] = compact[b][oh][ow][:], zeros elsewhere (memset by caller)
 __global__ void __launch_bounds__(256)
-upsample_scatter_kernel(const float4* __restrict__ compact, float4* __restrict__ out, int OH, int OW, int IH, int IW,
-                        int C4, int stride, long total) {
+upsample_scatter_kernel(const float4* __restrict__ compact, float4* __restrict__ out, const float4* __restrict__ mask,
+                        int OH, int OW, int IH, int IW, int C4, int stride, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % C4);
   const int ow = (int)((i / C4) % OW);
   const int oh = (int)((i / C4 / OW) % OH);
   const long b = i / C4 / OW / OH;
-  out[((b * IH + (long)oh * stride) * IW + (long)ow * stride) * C4 + c] = compact[i];
+  const long o = ((b * IH + (long)oh * stride) * IW + (long)ow * stride) * C4 + c;
+  float4 v = compact[i];
+  if (mask) {  // ReLU adjoint of the layer that produced the conv's input
+    const float4 k = mask[o];
+    v.x = k.x > 0.f ? v.x : 0.f;
+    v.y = k.y > 0.f ? v.y : 0.f;
+    v.z = k.z > 0.f ? v.z : 0.f;
+    v.w = k.w > 0.f ? v.w : 0.f;
+  }
+  out[o] = v;
 }
 
 int pick_split(int tiles, int M) {
@@ -254,8 +263,8 @@ int dana_conv2d_dgrad_weight(const float* w_packed, const float* scale, float* o
 
 /* Data gradient of a strided 1x1 conv: scatter compact[batch][oh][ow][C] to out[batch][ih][iw][C] at (oh*stride,
  * ow*stride), zero elsewhere (resnet.py:71: the stride-2 1x1 convs of the Caffe bottleneck). */
-int dana_upsample_scatter_nhwc(const float* compact, float* out, int batch, int oh, int ow, int ih, int iw,
-                               int channels, int stride, dana_stream_t stream) {
+int dana_upsample_scatter_nhwc(const float* compact, float* out, const float* mask_act, int batch, int oh, int ow,
+                               int ih, int iw, int channels, int stride, dana_stream_t stream) {
   DANA_CHECK_ARG(batch >= 0 && oh > 0 && ow > 0 && ih >= (oh - 1) * stride + 1 && iw >= (ow - 1) * stride + 1 &&
                      channels % 4 == 0 && stride > 0,
                  "dana_upsample_scatter_nhwc: bad shape");
@@ -267,8 +276,9 @@ int dana_upsample_scatter_nhwc(const float* compact, float* out, int batch, int 
     return DANA_ERR_HIP;
   }
   const long total = (long)batch * oh * ow * (channels / 4);
-  upsample_scatter_kernel<<<dana_ceil_div(total, 256), 256, 0, s>>>((const float4*)compact, (float4*)out, oh, ow, ih,
-                                                                    iw, channels / 4, stride, total);
+  upsample_scatter_kernel<<<dana_ceil_div(total, 256), 256, 0, s>>>((const float4*)compact, (float4*)out,
+                                                                    (const float4*)mask_act, oh, ow, ih, iw,
+                                                                    channels / 4, stride, total);
   DANA_CHECK_LAUNCH("dana_upsample_scatter_nhwc");
   return DANA_OK;
 }

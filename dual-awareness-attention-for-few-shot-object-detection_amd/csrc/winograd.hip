@@ -102,8 +102,8 @@ wino_input_kernel(const float* __restrict__ in, float* __restrict__ V, int H, in
 // one lane = (tile, 4 output channels)
 __global__ void __launch_bounds__(256)
 wino_output_kernel(const float* __restrict__ M, float* __restrict__ out, const float* __restrict__ scale,
-                   const float* __restrict__ shift, int H, int W, int N4, int th, int tw, long tiles, long ldc,
-                   int relu) {
+                   const float* __restrict__ shift, const float* __restrict__ mask, long ldm, int H, int W, int N4,
+                   int th, int tw, long tiles, long ldc, int relu) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= tiles * N4) return;
   const int n4 = (int)(idx % N4);
@@ -139,6 +139,10 @@ wino_output_kernel(const float* __restrict__ M, float* __restrict__ out, const f
       if (x >= W) break;
       float4 v = make_float4(o[c].x * sc.x + sh.x, o[c].y * sc.y + sh.y, o[c].z * sc.z + sh.z, o[c].w * sc.w + sh.w);
       if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (mask) {  // ReLU adjoint (data-gradient use): zero where the masking activation is <= 0
+        const float4 k = *(const float4*)(mask + ((img * H + y) * W + x) * ldm + n4 * 4);
+        v = make_float4(k.x > 0.f ? v.x : 0.f, k.y > 0.f ? v.y : 0.f, k.z > 0.f ? v.z : 0.f, k.w > 0.f ? v.w : 0.f);
+      }
       *(float4*)(out + ((img * H + y) * W + x) * ldc + n4 * 4) = v;
     }
   }
@@ -181,12 +185,23 @@ int dana_conv3x3_winograd_nhwc(const float* input, const float* u, float* output
                                const float* shift, int batch, int h, int w, int cin, int cout, long in_pix_stride,
                                long out_pix_stride, int flags, void* workspace, size_t workspace_bytes,
                                dana_stream_t stream) {
+  return dana_conv3x3_winograd_nhwc_masked(input, u, output, scale, shift, nullptr, batch, h, w, cin, cout, in_pix_stride,
+                                           out_pix_stride, 0, flags, workspace, workspace_bytes, stream);
+}
+
+int dana_conv3x3_winograd_nhwc_masked(const float* input, const float* u, float* output, const float* scale,
+                                      const float* shift, const float* mask_act, int batch, int h, int w, int cin,
+                                      int cout, long in_pix_stride, long out_pix_stride, long mask_pix_stride,
+                                      int flags, void* workspace, size_t workspace_bytes, dana_stream_t stream) {
   DANA_CHECK_ARG(batch >= 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 4 == 0 && cout % 4 == 0,
                  "dana_conv3x3_winograd_nhwc: bad shape");
   if (batch == 0) return DANA_OK;
   DANA_CHECK_ARG(input && u && output, "dana_conv3x3_winograd_nhwc: null pointer");
   const long lda = in_pix_stride > 0 ? in_pix_stride : cin;
   const long ldc = out_pix_stride > 0 ? out_pix_stride : cout;
+  const long ldm = mask_pix_stride > 0 ? mask_pix_stride : cout;
+  DANA_CHECK_ARG(!mask_act || (ldm % 4 == 0 && ((uintptr_t)mask_act & 15) == 0),
+                 "dana_conv3x3_winograd_nhwc: mask rows must be 16-byte aligned");
   DANA_CHECK_ARG(lda % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)input & 15) == 0 && ((uintptr_t)output & 15) == 0,
                  "dana_conv3x3_winograd_nhwc: strides / pointers must be 16-byte aligned");
   const long in_bytes = (long)batch * h * w * lda * 4;
@@ -206,8 +221,9 @@ int dana_conv3x3_winograd_nhwc(const float* input, const float* u, float* output
   int rc = dana_gemm_nt(V, u, M, nullptr, nullptr, nullptr, (int)p.tiles, cout, cin, cin, cin, cout, 0, 16,
                         p.tiles * cin, (long)cout * cin, p.tiles * cout, 1.f, 0, stream);
   if (rc) return rc;
-  wino_output_kernel<<<dana_ceil_div(p.tiles * N4, 256), 256, 0, s>>>(M, output, scale, shift, h, w, N4, p.th, p.tw,
-                                                                     p.tiles, ldc, (flags & DANA_EPI_RELU) ? 1 : 0);
+  wino_output_kernel<<<dana_ceil_div(p.tiles * N4, 256), 256, 0, s>>>(M, output, scale, shift, mask_act, ldm, h, w, N4,
+                                                                     p.th, p.tw, p.tiles, ldc,
+                                                                     (flags & DANA_EPI_RELU) ? 1 : 0);
   DANA_CHECK_LAUNCH("dana_conv3x3_winograd_nhwc(output transform)");
   return DANA_OK;
 }

@@ -183,6 +183,8 @@ class DAnARCNN(nn.Module):
         self.output_score_layer = FFN(64 * 49, dim_in)
         self._plan = None
         self._consts = {}
+        self._conv_cache = {}     # per-conv plan entries (see _conv_bn)
+        self._epoch = 0           # bumped by the trainer after an in-place (raw pointer) weight update
         self._ctx = None          # saved-for-backward context of the last training forward
         self._grad_anchor = None  # autograd leaf the loss bridge hangs on
 
@@ -239,16 +241,28 @@ class DAnARCNN(nn.Module):
         if cached is None or cached[0] != dev:  # module.to(device) swaps buffers: re-collect the tensor list
             cached = (dev, list(self.state_dict(keep_vars=True).values()))
             self._consts["sig_tensors"] = cached
-        return (dev, self.use_winograd, self.winograd_min_cin) + tuple(t._version for t in cached[1])
+        return (dev, self.use_winograd, self.winograd_min_cin, self._epoch) + tuple(t._version for t in cached[1])
 
     def _conv_bn(self, conv, bn, stem=False):
+        """packed weight + folded frozen BN (+ Winograd filter) of one conv, re-derived only when ITS tensors changed:
+        a training step touches the trainable conv weights only (BN and conv1/layer1 are frozen, dana.py:350-385)"""
+        wsig = (conv.weight.data_ptr(), conv.weight._version, self._epoch if conv.weight.requires_grad else -1,
+                self.use_winograd, self.winograd_min_cin)
+        bsig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        e = self._conv_cache.get(id(conv))
+        if e is not None and e["wsig"] == wsig and e["bsig"] == bsig:
+            return e
+        if e is not None and e["bsig"] == bsig:
+            scale, shift = e["scale"], e["shift"]
+        else:
+            scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         w = ops.pack_conv_weight(conv.weight, stem=stem)
-        scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         d = dict(w=w, scale=scale, shift=shift, cin=conv.in_channels, cout=conv.out_channels,
-                 k=conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0], u=None)
+                 k=conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0], u=None, wsig=wsig, bsig=bsig)
         if (self.use_winograd and d["k"] == 3 and d["stride"] == 1 and d["pad"] == 1 and not stem
                 and d["cin"] >= self.winograd_min_cin):
             d["u"] = ops.winograd_filter_transform(w, d["cout"], d["cin"])
+        self._conv_cache[id(conv)] = d
         return d
 
     def _block_plan(self, blk):
@@ -285,8 +299,8 @@ class DAnARCNN(nn.Module):
         return p
 
     def _stream(self, name, dev):
-        if getattr(self, "_single_stream", False) or getattr(self, "_ctx", None) is not None:
-            return torch.cuda.current_stream()  # bench.py's per-launch timing pass / saved-for-backward runs: no overlap
+        if getattr(self, "_single_stream", False):  # bench.py's per-launch timing pass: no overlap
+            return torch.cuda.current_stream()
         key = ("stream", name, str(dev))
         st = self._consts.get(key)
         if st is None:
@@ -430,8 +444,9 @@ class DAnARCNN(nn.Module):
         ctx = None
         self._bridge = training and torch.is_grad_enabled()  # train.py:141-143 will call loss.backward()
         if training and (self._bridge or getattr(self, "save_for_backward", False)):
-            # everything backward.model_backward needs; the forward then runs on ONE stream (saved tensors are
-            # consumed by the backward on the caller's stream)
+            # everything backward.model_backward needs. The side streams of this forward are all joined into the
+            # caller's stream before it returns, and each of them starts by waiting for an event of the NEXT
+            # forward's caller stream, so the saved tensors are safe for a backward that runs on that stream.
             if self.merge_trunk or self.query_streams != 1:
                 raise RuntimeError("save_for_backward needs merge_trunk=False and query_streams=1")
             ctx = self._ctx = dict(plan=plan, B=B, shot=shot, way=way, q_saved=[], s_saved=[], l4_saved=[], heads=[])
@@ -670,8 +685,7 @@ class DAnARCNN(nn.Module):
             return prob, score
 
         if ctx is not None:
-            ctx.update(rois=rois, R=R, q_pe=q_pe, q2=q2, fc7=fc7, K2=K2, K2p=K2p)
-            cls_prob, cls_score_all = head(0)  # ctx["heads"] order: positive, negative
+            ctx.update(rois=rois, R=R, q_pe=q_pe, q2=q2, K2=K2, K2p=K2p)
         if training:  # the negative-support head (dana.py:190) on its own stream, concurrent with the positive one
             neg_stream = self._stream("neg_head", dev)
             neg_stream.wait_event(q_ready)
@@ -683,12 +697,13 @@ class DAnARCNN(nn.Module):
                     t_.record_stream(neg_stream)
                 neg_done = torch.cuda.Event()
                 neg_done.record()
-        if ctx is None:
-            cls_prob, cls_score_all = head(0)
+        cls_prob, cls_score_all = head(0)
         mark("pos head")
         main.wait_event(l4_done)
         if training:
             main.wait_event(neg_done)
+        if ctx is not None:
+            ctx["fc7"] = fc7
         mark("join layer4 / neg head")
         if tl is not None:
             tl.append(("enqueued roialign..head", _time.perf_counter()))

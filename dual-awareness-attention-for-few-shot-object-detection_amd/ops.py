@@ -373,7 +373,7 @@ def winograd_filter_transform(w_packed, cout, cin):
 
 
 def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=False, in_stride=0, out=None,
-                     out_stride=0):
+                     out_stride=0, mask=None, mask_stride=0):
     """stride-1 pad-1 3x3 conv through Winograd F(2x2,3x3) (u from winograd_filter_transform)."""
     _chk(x, "x")
     _chk(u, "u")
@@ -382,8 +382,8 @@ def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=
         out_stride = cout
     ws = _ws(lib().query("dana_conv3x3_winograd_workspace_bytes", batch, h, w, cin, cout), x.device)
     e0 = _prof_begin()
-    lib().call("dana_conv3x3_winograd_nhwc", _p(x), _p(u), _p(out), _p(scale), _p(shift), batch, h, w, cin, cout,
-               in_stride, out_stride, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
+    lib().call("dana_conv3x3_winograd_nhwc_masked", _p(x), _p(u), _p(out), _p(scale), _p(shift), _p(mask), batch, h, w,
+               cin, cout, in_stride, out_stride, mask_stride, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
     _prof_end(e0, "wino3x3 M=%d N=%d K=%d s1" % (batch * h * w, cout, 9 * cin), 2.0 * batch * h * w * cout * 9 * cin)
     return out, h, w
 
@@ -554,27 +554,54 @@ def conv2d_wgrad(grad_out, x, batch, in_h, in_w, cin, cout, kh, kw, stride, pad,
         out = torch.empty((cout, kh * kw * cin), dtype=torch.float32, device=x.device)
     ws = _ws(lib().query("dana_conv2d_wgrad_workspace_bytes", batch, in_h, in_w, cin, cout, kh, kw, stride, pad),
              x.device)
+    e0 = _prof_begin()
     lib().call("dana_conv2d_wgrad_nhwc", _p(grad_out), _p(x), _p(out), batch, in_h, in_w, cin, cout, kh, kw, stride,
                pad, in_stride, grad_stride, int(accumulate), _p(ws), ws.numel(), _stream())
+    m = batch * ((in_h + 2 * pad - kh) // stride + 1) * ((in_w + 2 * pad - kw) // stride + 1)
+    _prof_end(e0, "wgrad%dx%d M=%d N=%d K=%d s%d" % (kh, kw, m, cout, kh * kw * cin, stride),
+              2.0 * m * cout * kh * kw * cin)
     return out
 
 
-def conv2d_dgrad(grad_out, w_packed, batch, in_h, in_w, cin, cout, kh, kw, stride, pad, scale=None):
-    """grad w.r.t. the NHWC conv input [batch*in_h*in_w][cin]; grad_out [batch*oh*ow][cout]."""
-    _chk(grad_out, "grad_out")
-    wd = torch.empty((cin, kh * kw * cout), dtype=torch.float32, device=grad_out.device)
+def conv2d_dgrad_weight(w_packed, cout, cin, kh, kw, scale=None):
+    """flipped / transposed (and frozen-BN scaled) weights [cin][kh*kw*cout]: the data gradient is a forward conv on them"""
+    wd = torch.empty((cin, kh * kw * cout), dtype=torch.float32, device=w_packed.device)
     lib().call("dana_conv2d_dgrad_weight", _p(_chk(w_packed, "w_packed")), _p(scale), _p(wd), cout, cin, kh, kw,
                _stream())
+    return wd
+
+
+def conv2d_dgrad(grad_out, w_packed, batch, in_h, in_w, cin, cout, kh, kw, stride, pad, scale=None, wd=None, ud=None,
+                 residual=None, mask=None, mask_stride=0, compact_out=False):
+    """grad w.r.t. the NHWC conv input [batch*in_h*in_w][cin]; grad_out [batch*oh*ow][cout].
+    wd / ud: cached conv2d_dgrad_weight() / its Winograd transform. residual: added to the result; mask: activation
+    whose ReLU adjoint is applied last (zero where mask <= 0). For a strided 1x1 conv residual must be COMPACT
+    ([batch*oh*ow][cin], e.g. the downsample branch's compact gradient) and compact_out=True returns the compact
+    result without scattering."""
+    _chk(grad_out, "grad_out")
+    if wd is None:
+        wd = conv2d_dgrad_weight(w_packed, cout, cin, kh, kw, scale)
     oh = (in_h + 2 * pad - kh) // stride + 1
     ow = (in_w + 2 * pad - kw) // stride + 1
     if stride == 1:
-        gx, _, _ = conv2d_nhwc(grad_out, batch, oh, ow, cout, wd, cin, kh, kw, 1, kh - 1 - pad)
+        if ud is not None and residual is None:
+            gx, _, _ = conv3x3_winograd(grad_out, batch, oh, ow, cout, ud, cin, mask=mask, mask_stride=mask_stride)
+            return gx
+        gx = torch.empty((batch * in_h * in_w, cin), dtype=torch.float32, device=grad_out.device)
+        e0 = _prof_begin()
+        lib().call("dana_conv2d_nhwc_masked", _p(grad_out), _p(wd), _p(gx), None, None, _p(residual), _p(mask), batch, oh,
+                   ow, cout, cin, kh, kw, 1, kh - 1 - pad, 0, cin, 0, mask_stride, 0, _stream())
+        _prof_end(e0, "dgrad%dx%d M=%d N=%d K=%d" % (kh, kw, batch * in_h * in_w, cin, kh * kw * cout),
+                  2.0 * batch * in_h * in_w * cin * kh * kw * cout)
         return gx
     if kh != 1 or kw != 1 or pad != 0:
         raise NotImplementedError("strided data gradient only for the 1x1 convs of the Caffe bottleneck")
-    compact, _, _ = conv2d_nhwc(grad_out, batch, oh, ow, cout, wd, cin, 1, 1, 1, 0)
+    compact, _, _ = conv2d_nhwc(grad_out, batch, oh, ow, cout, wd, cin, 1, 1, 1, 0, residual=residual)
+    if compact_out:
+        return compact
     gx = torch.empty((batch * in_h * in_w, cin), dtype=torch.float32, device=grad_out.device)
-    lib().call("dana_upsample_scatter_nhwc", _p(compact), _p(gx), batch, oh, ow, in_h, in_w, cin, stride, _stream())
+    lib().call("dana_upsample_scatter_nhwc", _p(compact), _p(gx), _p(mask), batch, oh, ow, in_h, in_w, cin, stride,
+               _stream())
     return gx
 
 

@@ -138,7 +138,7 @@ class Trainer:
             ops.sgd_momentum_(fb.params, fb.grads, buf, self.lr * lr_mult, self.momentum, wd,
                               grad_scale=1.0 / fb.world, first_step=self.steps == 0)
         self.steps += 1
-        self.model._plan = None  # weights changed under the packed / folded / Winograd-transformed copies
+        self.model._epoch += 1  # weights changed under the packed / Winograd-transformed copies: re-derive those
 
     def step(self, im_data, im_info, gt_boxes, num_boxes, support_ims):
         """one training iteration; returns the model's 8-tuple (losses detached)"""

@@ -122,6 +122,14 @@ int dana_conv2d_nhwc(const float* input, const float* weight, float* output, con
                      int cout, int kh, int kw, int stride, int pad, long in_pix_stride, long out_pix_stride,
                      long res_pix_stride, int flags, dana_stream_t stream);
 
+/* dana_conv2d_nhwc with the ReLU adjoint fused into the epilogue: out = mask_act > 0 ? conv(...) + residual : 0.
+ * Used for data gradients (backward of resnet.py:83-100): mask_act is the activation whose ReLU sits in front of the
+ * differentiated conv's input, [batch*oh*ow][mask_pix_stride]. */
+int dana_conv2d_nhwc_masked(const float* input, const float* weight, float* output, const float* scale,
+                            const float* shift, const float* residual, const float* mask_act, int batch, int in_h,
+                            int in_w, int cin, int cout, int kh, int kw, int stride, int pad, long in_pix_stride,
+                            long out_pix_stride, long res_pix_stride, long mask_pix_stride, int flags,
+                            dana_stream_t stream);
 /* The same conv over TWO image groups in one launch: input rows = batch0 images of h0 x w0 followed by
  * batch1 images of h1 x w1 (same channels / pixel stride); outputs go to out0 / out1 with their own row
  * strides. RCNN_base is applied to the query batch and to the support batch (dana.py:98,100): sharing
@@ -141,6 +149,12 @@ int dana_conv3x3_winograd_nhwc(const float* input, const float* u, float* output
                                const float* shift, int batch, int h, int w, int cin, int cout, long in_pix_stride,
                                long out_pix_stride, int flags, void* workspace, size_t workspace_bytes,
                                dana_stream_t stream);
+/* same, with the ReLU adjoint fused into the output transform (out = mask_act > 0 ? conv : 0): the data gradient of
+ * a 3x3 conv is a 3x3 conv on flipped weights, masked by the activation in front of the differentiated conv */
+int dana_conv3x3_winograd_nhwc_masked(const float* input, const float* u, float* output, const float* scale,
+                                      const float* shift, const float* mask_act, int batch, int h, int w, int cin,
+                                      int cout, long in_pix_stride, long out_pix_stride, long mask_pix_stride,
+                                      int flags, void* workspace, size_t workspace_bytes, dana_stream_t stream);
 
 /* nn.Linear / torch.bmm (dana.py:124,140,142,147,266-290): c[z][m][n] = epi(alpha * sum_k a[z][m][k]*b[z][n][k]).
  * Both operands K-contiguous ("NT"); nn.Linear weights [out][in] are used as stored. k % 4 == 0. */
@@ -258,9 +272,10 @@ int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* gra
  * grad_input = dana_conv2d_nhwc(grad_out, out, cin <-> cout swapped, same kernel size / pad) */
 int dana_conv2d_dgrad_weight(const float* w_packed, const float* scale, float* out, int cout, int cin, int kh, int kw,
                              dana_stream_t stream);
-/* data gradient of a strided 1x1 conv: scatter the compact result to the strided positions, zero elsewhere */
-int dana_upsample_scatter_nhwc(const float* compact, float* out, int batch, int oh, int ow, int ih, int iw,
-                               int channels, int stride, dana_stream_t stream);
+/* data gradient of a strided 1x1 conv: scatter the compact result to the strided positions, zero elsewhere;
+ * mask_act (optional, [batch][ih][iw][channels]): zero the gradient where that activation is <= 0 (ReLU adjoint) */
+int dana_upsample_scatter_nhwc(const float* compact, float* out, const float* mask_act, int batch, int oh, int ow,
+                               int ih, int iw, int channels, int stride, dana_stream_t stream);
 
 /* element-wise / reduction glue of the backward pass */
 int dana_relu_mask(float* grad, const float* act, long rows, int channels, long ld_grad, long ld_act,
