@@ -19,14 +19,29 @@ from .config import cfg
 
 
 class WeightGrads:
-    """Accumulates packed weight gradients per conv (query and support passes share the weights)."""
+    """Accumulates packed weight gradients per conv (query and support passes share the weights).
+    With `stream`, the weight-gradient launches go to that side stream: they only consume (g, x) and nothing on the
+    data-gradient chain waits for them, so their tiles fill the CUs the chain's launches leave idle in their tails."""
 
-    def __init__(self):
+    def __init__(self, stream=None):
         self.packed = {}
         self.convs = {}
+        self.stream = stream
+        self.keep = []  # operands of in-flight side-stream launches (allocated on the caller's stream)
 
     def add_conv(self, key, g, x, n, h, w, c, in_stride=0, grad_stride=0):
         self.convs[key] = c
+        if self.stream is None:
+            self._launch(key, g, x, n, h, w, c, in_stride, grad_stride)
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        self.stream.wait_event(ready)
+        self.keep.append((g, x))
+        with torch.cuda.stream(self.stream):
+            self._launch(key, g, x, n, h, w, c, in_stride, grad_stride)
+
+    def _launch(self, key, g, x, n, h, w, c, in_stride, grad_stride):
         buf = self.packed.get(key)
         if buf is None:
             self.packed[key] = ops.conv2d_wgrad(g, x, n, h, w, c["cin"], c["cout"], c["k"], c["k"], c["stride"],
@@ -34,6 +49,14 @@ class WeightGrads:
         else:
             ops.conv2d_wgrad(g, x, n, h, w, c["cin"], c["cout"], c["k"], c["k"], c["stride"], c["pad"],
                              in_stride=in_stride, grad_stride=grad_stride, out=buf)
+
+    def join(self):
+        """the caller's stream waits for every weight-gradient launch issued so far"""
+        if self.stream is not None and self.keep:
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            torch.cuda.current_stream().wait_event(done)
+            self.keep = []
 
     def finish_conv(self, key, c, param):
         """apply the frozen-BN scale to the rows and add into param.grad (OIHW)"""
@@ -46,6 +69,7 @@ class WeightGrads:
         ops.unpack_conv_weight_grad(buf, param.grad, c["cout"], c["cin"], c["k"], c["k"], accumulate=not fresh)
 
     def finish_all(self, model, prefix=""):
+        self.join()
         for key in list(self.packed):
             if key.startswith(prefix):
                 self.finish_conv(key, self.convs[key], model.get_parameter(key + ".weight"))
@@ -196,7 +220,7 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     g1, g2, g3, g4 = [float(x) for x in grad_losses]
     corr = ctx["corr"]
     dev = corr.device
-    grads = WeightGrads()
+    grads = WeightGrads(None if getattr(model, "_single_stream", False) else model._stream("wgrad", dev))
     ug = model.unary_gamma
 
     # -- seeds: d losses / d (cls_score_all, bbox_pred) (dana.py:203-217; tiny, through torch autograd) --

@@ -13,6 +13,8 @@
 //
 // Replaces what autograd + cuDNN do for nn.Conv2d / nn.Linear weights in the reference's train step
 // (train.py:141-143: loss.backward()); BN is frozen (dana.py:362-385) so dY arrives already scaled.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/dana_hip.h"
 
@@ -115,6 +117,100 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
   }
 }
 
+// 128(n) x 128(k) output tile: 4 waves 2x2, each wave a 64x64 tile = 2x2 MFMA tiles, so every LDS fragment feeds two
+// MFMAs (1 ds_read per MFMA instead of 2: the 64x64 kernel above sits exactly at the LDS-bandwidth limit) and the
+// operands are re-read from L2 half as often. The 128 k-columns may straddle two filter taps (Cin % 64 == 0 only):
+// the tap geometry is per 64-column half, i.e. per staging thread.
+constexpr int WLD2 = 132;
+__global__ void __launch_bounds__(256, 2) wgrad_f32_128_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(16))) float Gs[2][32][WLD2];
+  __shared__ __attribute__((aligned(16))) float Xs[2][32][WLD2];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int m_begin = blockIdx.z * p.m_chunk;
+  const int m_end = min(p.M, m_begin + p.m_chunk);
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, (int)p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)p.x_bytes, 0x00020000);
+  // staging: thread -> rows r0 + 8 j (j = 0..3), float4 column c4 = tid % 32 of a [32][128] slab
+  const int c4 = tid & 31, r0 = tid >> 5;
+  const bool n_ok = (n0 + c4 * 4) < p.N;
+  const int kcol = k0 + c4 * 4;
+  const bool k_ok = kcol < p.K;
+  const int tap = kcol / p.Cin, cin_off = kcol - tap * p.Cin;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int ohw = p.OH * p.OW;
+
+  float4 gy[4], gx[4];
+  auto load_slab = [&](int mb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = mb + r0 + 8 * j;
+      const bool ok = m < m_end;
+      gy[j] = ldg_b128(ysrc, (ok && n_ok) ? (unsigned)((m * p.ldy + n0 + c4 * 4) * 4) : OOB);
+      const int mm = ok ? m : 0;
+      const int img = mm / ohw, rem = mm - img * ohw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+      const bool in = ok && k_ok && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+      gx[j] = ldg_b128(xsrc, in ? (unsigned)((((img * p.IH + ih) * p.IW + iw) * p.ldx + cin_off) * 4) : OOB);
+    }
+  };
+  auto store_slab = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(float4*)&Gs[buf][r0 + 8 * j][c4 * 4] = gy[j];
+      *(float4*)&Xs[buf][r0 + 8 * j][c4 * 4] = gx[j];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int steps = (m_end - m_begin + 31) / 32;
+  if (steps > 0) {
+    load_slab(m_begin);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < steps) load_slab(m_begin + (s + 1) * 32);
+      const float* g = &Gs[buf][lh][wn * 64 + li];
+      const float* x = &Xs[buf][lh][wk * 64 + li];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {  // MFMA step q contracts pixels {2q, 2q+1} of the slab
+        const float g0 = g[2 * q * WLD2], g1 = g[2 * q * WLD2 + 32];
+        const float x0 = x[2 * q * WLD2], x1 = x[2 * q * WLD2 + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x1, acc[1][1], 0, 0, 0);
+      }
+      if (s + 1 < steps) store_slab(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  float* out = p.partial + (long)blockIdx.z * p.N * p.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < p.N && k < p.K) out[(long)n * p.K + k] = acc[i][j][r];
+      }
+    }
+}
+
 // dW[i] = (accumulate ? dW[i] : 0) + sum_s partial[s][i], fixed order
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW, long n4, int S, int accumulate) {
@@ -168,13 +264,38 @@ upsample_scatter_kernel(const float4* __restrict__ compact, float4* __restrict__
   out[o] = v;
 }
 
-int pick_split(int tiles, int M) {
-  int S = (1024 + tiles - 1) / tiles;  // aim for ~4 workgroups per CU
-  const int maxS = (M + 255) / 256;    // at least 8 reduction steps per slice
-  if (S > maxS) S = maxS;
-  if (S < 1) S = 1;
-  if (S > 64) S = 64;
-  return S;
+// tile edge (64 or 128) and pixel split of one weight-gradient launch
+struct WgradShape {
+  int tile, tn, tk, S;
+};
+WgradShape wgrad_shape(int N, int K, int M) {
+  // Pick (tile, S) by a small cost model: `rounds` of workgroups over the chip's slots (2 per CU for the 128x128
+  // tile, 4 for 64x64), each doing chunk/32 slabs, plus the HBM round trip of the S partial tiles. The 128x128
+  // tile sustains ~0.75 of the per-CU MFMA peak (one LDS read per MFMA), the 64x64 tile ~0.5 (two).
+  static const int forced = [] { const char* e = getenv("DANA_WGRAD_TILE"); return e ? atoi(e) : 0; }();
+  WgradShape best = {64, 1, 1, 1};
+  double best_t = 1e30;
+  for (int tile = 64; tile <= 128; tile += 64) {
+    if (forced && tile != forced) continue;
+    const int tn = (N + tile - 1) / tile, tk = (K + tile - 1) / tile;
+    const long tiles = (long)tn * tk;
+    const int slots = tile == 128 ? 512 : 1024;
+    const double cu_flops = 157.3e12 / 256.0 * (tile == 128 ? 0.75 : 0.5);
+    const double wg_flops = cu_flops / (tile == 128 ? 2 : 4);
+    const int maxS = (M + 255) / 256 < 64 ? (M + 255) / 256 : 64;
+    for (int S = 1; S <= (maxS < 1 ? 1 : maxS); ++S) {
+      const int chunk = ((M + S - 1) / S + 31) / 32 * 32;
+      const long rounds = (tiles * S + slots - 1) / slots;
+      const double t_mma = (double)rounds * (chunk / 32) * (2.0 * tile * tile * 32) / wg_flops + rounds * 2e-6;
+      const double t_part = 2.0 * S * (double)N * K * 4.0 / 4e12;
+      const double t = t_mma + t_part;
+      if (t < best_t) {
+        best_t = t;
+        best = {tile, tn, tk, S};
+      }
+    }
+  }
+  return best;
 }
 
 }  // namespace
@@ -186,8 +307,7 @@ size_t dana_conv2d_wgrad_workspace_bytes(int batch, int in_h, int in_w, int cin,
   if (batch <= 0 || cin <= 0 || cout <= 0) return 0;
   const int oh = (in_h + 2 * pad - kh) / stride + 1, ow = (in_w + 2 * pad - kw) / stride + 1;
   const int K = kh * kw * cin, M = batch * oh * ow;
-  const int tiles = ((cout + 63) / 64) * ((K + 63) / 64);
-  return (size_t)pick_split(tiles, M) * cout * K * sizeof(float);
+  return (size_t)wgrad_shape(cout, K, M).S * cout * K * sizeof(float);
 }
 
 /* dW[cout][kh][kw][cin] (the packed layout of dana_conv2d_nhwc) (+)= sum over output pixels of
@@ -228,8 +348,8 @@ int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* gra
   DANA_CHECK_ARG(xb < (long)OOB && yb < (long)OOB, "dana_conv2d_wgrad_nhwc: operand span >= 2 GiB; split the batch");
   p.x_bytes = (unsigned)xb;
   p.y_bytes = (unsigned)yb;
-  const int tn = (cout + 63) / 64, tk = (p.K + 63) / 64;
-  const int S = pick_split(tn * tk, p.M);
+  const WgradShape ws = wgrad_shape(cout, p.K, p.M);
+  const int tn = ws.tn, tk = ws.tk, S = ws.S;
   p.m_chunk = ((p.M + S - 1) / S + 31) / 32 * 32;
   const size_t need = (size_t)S * cout * p.K * sizeof(float);
   if (!workspace || workspace_bytes < need) {
@@ -239,7 +359,10 @@ int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* gra
   p.partial = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(tn, tk, S);
-  wgrad_f32_kernel<<<grid, 256, 0, s>>>(p);
+  if (ws.tile == 128)
+    wgrad_f32_128_kernel<<<grid, 256, 0, s>>>(p);
+  else
+    wgrad_f32_kernel<<<grid, 256, 0, s>>>(p);
   DANA_CHECK_LAUNCH("dana_conv2d_wgrad_nhwc");
   const long n4 = (long)cout * p.K / 4;
   wgrad_reduce_kernel<<<dana_ceil_div(n4, 256), 256, 0, s>>>((const float4*)workspace, (float4*)grad_weight, n4, S,
