@@ -216,15 +216,27 @@ def main():
         launches = len(prof) // args.steps
         achieved = flops / (ms * 1e-3) / 1e12
         by = {}
-        for tag, f, e0, e1 in prof:
+        for tag, f, e0, e1, _nb in prof:
             a = by.setdefault(tag.split(" ")[0], [0.0, 0.0, 0])
             a[0] += f
             a[1] += e0.elapsed_time(e1)
             a[2] += 1
+        # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this very
+        # command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py -> profiles/): bytes per launch,
+        # next to the algorithmic bytes per launch (each operand / result of a launch touched once)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+                traffic = round(json.load(fh)["igemm_f32_kernel<64, 64, 0>"]["hbm_bytes_per_launch_corrected"])
+        except (OSError, KeyError, ValueError):
+            pass
+        mfma = [p for p in prof if not p[0].startswith("conv7x7") and " N=2 " not in p[0] and " N=4 " not in p[0]]
         result["roofline"] = {
             "bound": "mfma", "kernel": "igemm_f32_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)",
             "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per igemm_f32_kernel<64,64,0> launch (PMC, profiles/r1_pmc_traffic.json)",
+            "algorithmic_bytes_per_launch": round(sum(p[4] for p in mfma) / max(len(mfma), 1)),
             "launches_per_step": launches,
             "algorithmic_gflop_per_step": round(flops / args.steps / 1e9, 1),
             "kernel_ms_per_step": round(ms / args.steps, 3),
@@ -233,7 +245,7 @@ def main():
         }
         if args.dump_launches:
             per = {}
-            for i, (tag, f, e0, e1) in enumerate(prof):
+            for i, (tag, f, e0, e1, _nb) in enumerate(prof):
                 a = per.setdefault((i % launches, tag), [f, 0.0])
                 a[1] += e0.elapsed_time(e1) / args.steps
             with open(args.dump_launches, "w") as fh:

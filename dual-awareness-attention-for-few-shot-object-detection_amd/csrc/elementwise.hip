@@ -94,6 +94,40 @@ avgpool_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, i
   }
 }
 
+// stride-1 variant for OW <= 8 (the 20x20 -> 7x7 support pooling): one thread = (image, output row, 4 channels) walks
+// its k input rows once and feeds every pixel to the <= 8 windows that contain it, instead of re-reading each pixel
+// from k*k windows (PMC: the generic kernel fetched 883 MB for a 39 MB input).
+__global__ void __launch_bounds__(256)
+avgpool_rows_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, int W, int OH, int OW, int C4, int k,
+                    long total) {
+  const float cnt = (float)(k * k);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const int oh = (int)((i / C4) % OH);
+    const long b = i / C4 / OH;
+    float4 acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = make_float4(0, 0, 0, 0);
+    for (int dh = 0; dh < k; ++dh) {
+      const float4* row = in + ((b * H + oh + dh) * W) * C4 + c;
+      for (int x = 0; x < W; ++x) {
+        const float4 v = row[(long)x * C4];
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+          if (o <= x && x < o + k) {
+            acc[o].x += v.x;
+            acc[o].y += v.y;
+            acc[o].z += v.z;
+            acc[o].w += v.w;
+          }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < OW) out[((b * OH + oh) * OW + o) * C4 + c] = make_float4(acc[o].x / cnt, acc[o].y / cnt, acc[o].z / cnt, acc[o].w / cnt);
+  }
+}
+
 // out[g][c] = mean_p in[g][p][c]
 __global__ void __launch_bounds__(256)
 spatial_mean_kernel(const float4* __restrict__ in, float4* __restrict__ out, int P, int C4, long ldi4, long total) {
@@ -268,8 +302,14 @@ int dana_avgpool_nhwc(const float* in, float* out, int batch, int height, int wi
   DANA_CHECK_ARG(in && out, "dana_avgpool_nhwc: null pointer");
   const int oh = (height - k) / stride + 1, ow = (width - k) / stride + 1;
   const long total = (long)batch * oh * ow * (channels / 4);
-  avgpool_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)in, (float4*)out, height,
-                                                                        width, oh, ow, channels / 4, k, stride, total);
+  if (stride == 1 && ow <= 8) {
+    const long rows_total = (long)batch * oh * (channels / 4);
+    avgpool_rows_kernel<<<grid_for(rows_total, 256), 256, 0, (hipStream_t)stream>>>(
+        (const float4*)in, (float4*)out, height, width, oh, ow, channels / 4, k, rows_total);
+  } else {
+    avgpool_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)in, (float4*)out, height, width,
+                                                                          oh, ow, channels / 4, k, stride, total);
+  }
   DANA_CHECK_LAUNCH("dana_avgpool_nhwc");
   return DANA_OK;
 }

@@ -24,11 +24,12 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, tag, flops):
+def _prof_end(e0, tag, flops, nbytes=0.0):
+    """nbytes: algorithmic HBM bytes of the launch (every operand and result touched exactly once)"""
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((tag, flops, e0, e1))
+        PROFILE.append((tag, flops, e0, e1, nbytes))
 
 
 def _stream():
@@ -337,7 +338,9 @@ def conv2d_nhwc(x, batch, in_h, in_w, cin, weight, cout, kh, kw, stride, pad, sc
                in_w, cin, cout, kh, kw, stride, pad, in_stride, out_stride, res_stride, flags, _stream())
     # algorithmic flops: the stem counts its 3 real channels x 49 real taps, not the padded K=224
     _prof_end(e0, "conv%dx%d M=%d N=%d K=%d s%d" % (kh, kw, batch * oh * ow, cout, kh * kw * cin, stride),
-              2.0 * batch * oh * ow * cout * kh * kw * (3 if stem else cin))
+              2.0 * batch * oh * ow * cout * kh * kw * (3 if stem else cin),
+              4.0 * (batch * in_h * in_w * cin // (stride * stride if kh == 1 else 1) + cout * kh * kw * cin
+                     + batch * oh * ow * cout * (2 if residual is not None else 1)))
     return out, oh, ow
 
 
@@ -384,7 +387,9 @@ def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=
     e0 = _prof_begin()
     lib().call("dana_conv3x3_winograd_nhwc_masked", _p(x), _p(u), _p(out), _p(scale), _p(shift), _p(mask), batch, h, w,
                cin, cout, in_stride, out_stride, mask_stride, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
-    _prof_end(e0, "wino3x3 M=%d N=%d K=%d s1" % (batch * h * w, cout, 9 * cin), 2.0 * batch * h * w * cout * 9 * cin)
+    _prof_end(e0, "wino3x3 M=%d N=%d K=%d s1" % (batch * h * w, cout, 9 * cin), 2.0 * batch * h * w * cout * 9 * cin,
+              # bytes of the batched GEMM launch itself: V[16][tiles][cin], U[16][cout][cin], M[16][tiles][cout]
+              64.0 * (batch * ((h + 1) // 2) * ((w + 1) // 2) * (cin + cout) + cout * cin))
     return out, h, w
 
 
@@ -402,7 +407,8 @@ def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None
     e0 = _prof_begin()
     lib().call("dana_gemm_nt", _p(a), _p(b), _p(out), _p(scale), _p(shift), _p(residual), m, n, k, lda, ldb, ldc,
                ldr, batch, batch_a, batch_b, batch_c, float(alpha), EPI_RELU if relu else 0, _stream())
-    _prof_end(e0, "gemm M=%d N=%d K=%d b%d" % (m, n, k, batch), 2.0 * batch * m * n * (k_true or k))
+    _prof_end(e0, "gemm M=%d N=%d K=%d b%d" % (m, n, k, batch), 2.0 * batch * m * n * (k_true or k),
+              4.0 * batch * (m * k + n * k + m * n * (2 if residual is not None else 1)))
     return out
 
 
