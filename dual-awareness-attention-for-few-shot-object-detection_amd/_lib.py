@@ -17,6 +17,7 @@ _CTYPES = {
     "int": ctypes.c_int,
     "long": ctypes.c_long,
     "float": ctypes.c_float,
+    "double": ctypes.c_double,
     "size_t": ctypes.c_size_t,
     "dana_stream_t": ctypes.c_void_p,
 }

@@ -325,6 +325,23 @@ int dana_rpn_loss_backward(const float* heads, long head_row_stride, const float
                            const float* losses3, float grad_cls, float grad_box, float* grad_heads,
                            dana_stream_t stream);
 
+/* ---- episode input pipeline: the loaders' per-image cv2 / numpy work ------------------------ */
+
+/* minibatch.py:70-84 + blob.py:35-52 (prep_im_for_blob): RGB uint8 [h][w][3] -> BGR, optional horizontal flip,
+ * fp32 minus cfg.PIXEL_MEANS (3 HOST floats, BGR order), cv2.resize(fx = fy = im_scale, INTER_LINEAR)
+ * -> out [out_h][out_w][3] fp32 (the caller computes out_h/out_w = round(h * im_scale) like cv2 does) */
+int dana_prep_image(const unsigned char* rgb_hwc, int height, int width, long row_stride_bytes, int flipped,
+                    const float* pixel_means_bgr, double im_scale, float* out_hwc, int out_h, int out_w,
+                    dana_stream_t stream);
+/* fs_loader.py:118-139: crop [y_min..y_max] x [x_min..x_max] (inclusive) out of a prepared fp32 HWC image,
+ * cv2.resize(dsize = (resized_w, resized_h), INTER_LINEAR), transpose to CHW, zero-pad to [3][target][target] */
+int dana_crop_resize_pad(const float* im_hwc, int height, int width, int x_min, int y_min, int x_max, int y_max,
+                         int resized_w, int resized_h, int target, float* out_chw, dana_stream_t stream);
+/* fs_loader.py:186-280,318: crop window (start, size) of a prepared fp32 HWC image, zero-padded to [out_h][out_w] and
+ * permuted to CHW: one plane set of the batch holder */
+int dana_crop_pad_chw(const float* im_hwc, int height, int width, int y_start, int x_start, int crop_h, int crop_w,
+                      float* out_chw, int out_h, int out_w, dana_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

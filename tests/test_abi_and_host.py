@@ -22,8 +22,8 @@ def test_library_exports_every_declared_symbol():
     for name in protos:
         assert hasattr(cdll, name), "libdana_hip.so does not export %s" % name
     # and nothing torch-typed leaks into the boundary: only C scalars and raw pointers
-    allowed = {"int", "long", "float", "size_t", "dana_stream_t", "const float*", "float*", "const int*", "int*",
-               "void*"}
+    allowed = {"int", "long", "float", "double", "size_t", "dana_stream_t", "const float*", "float*", "const int*",
+               "int*", "const unsigned char*", "void*"}
     for name, (ret, args) in protos.items():
         assert ret in ("int", "size_t", "const char*"), (name, ret)
         for ty, _ in args:

@@ -102,3 +102,28 @@ def test_oracle_postprocess_matches_reference_detections(golden_dir, tag):
         b = g[key][[i for i in range(len(g[key])) if float(g[key][i, 4]) not in tied]]
         assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4
     assert len(g["dets_t62"]) < len(g["dets_t05"])
+
+
+def test_pipeline_resize_restatement_matches_independent_bilinear():
+    """oracle/pipeline_ref.cv_resize_linear (the cv2.INTER_LINEAR float path restated; cv2 itself is absent here) against
+    torch's F.interpolate(bilinear, align_corners=False), an independent implementation of the same sampling rule"""
+    import torch.nn.functional as F
+    from oracle import pipeline_ref as P
+    rng = np.random.RandomState(0)
+    for h, w, fx in [(48, 64, 0.61), (20, 20, 16.0), (33, 31, 1.0), (40, 50, 2.5)]:
+        src = rng.randn(h, w, 3).astype(np.float32) * 50
+        t = torch.from_numpy(src).permute(2, 0, 1)[None]
+        a = P.cv_resize_linear(src, fx=fx, fy=fx)
+        b = F.interpolate(t, scale_factor=fx, mode="bilinear", align_corners=False, recompute_scale_factor=False)
+        assert tuple(b.shape[2:]) == a.shape[:2]
+        assert np.abs(a - b[0].permute(1, 2, 0).numpy()).max() <= 2e-3  # |values| ~ 50..200: 1e-5 relative
+        d = P.cv_resize_linear(src, dsize=(2 * w + 1, h + 3))
+        b3 = F.interpolate(t, size=(h + 3, 2 * w + 1), mode="bilinear", align_corners=False)
+        assert np.abs(d - b3[0].permute(1, 2, 0).numpy()).max() <= 2e-3
+    # identity scale is exact, and the blob is BGR, mean-subtracted (blob.py:38-39, minibatch.py:76-78)
+    im = rng.randint(0, 256, size=(30, 45, 3)).astype(np.uint8)
+    means = np.array([[[102.9801, 115.9465, 122.7717]]], dtype=np.float32)
+    out, s = P.prep_im_for_blob(im, means, 30)
+    assert s == 1.0 and np.array_equal(out, im[:, :, ::-1].astype(np.float32) - means)
+    sup = P.support_crop(out, (5, 3, 24, 28), 64)  # taller than wide: height fits, width padded with zeros
+    assert sup.shape == (3, 64, 64) and np.all(sup[:, :, 49:] == 0) and np.any(sup[:, :, 48] != 0)
