@@ -126,4 +126,4 @@ def test_pipeline_resize_restatement_matches_independent_bilinear():
     out, s = P.prep_im_for_blob(im, means, 30)
     assert s == 1.0 and np.array_equal(out, im[:, :, ::-1].astype(np.float32) - means)
     sup = P.support_crop(out, (5, 3, 24, 28), 64)  # taller than wide: height fits, width padded with zeros
-    assert sup.shape == (3, 64, 64) and np.all(sup[:, :, 49:] == 0) and np.any(sup[:, :, 48] != 0)
+    assert sup.shape == (3, 64, 64) and np.all(sup[:, :, 48:] == 0) and np.any(sup[:, :, 47] != 0)
