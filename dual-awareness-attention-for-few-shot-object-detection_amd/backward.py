@@ -11,10 +11,8 @@ backward.hip. Frozen BatchNorm (dana.py:362-385) only scales gradients; BN param
 import math
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
-from . import targets as T
 from .config import cfg
 
 
@@ -223,21 +221,15 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     grads = WeightGrads(None if getattr(model, "_single_stream", False) else model._stream("wgrad", dev))
     ug = model.unary_gamma
 
-    # -- seeds: d losses / d (cls_score_all, bbox_pred) (dana.py:203-217; tiny, through torch autograd) --
-    sc = ctx["cls_score_all"].detach().clone().requires_grad_(True)
-    bp_ = ctx["bbox_pred"].detach().clone().requires_grad_(True)
-    with torch.enable_grad():
-        topk = ctx["topk"]
-        seed = (g3 * F.cross_entropy(sc[topk], ctx["rois_label"][topk])
-                + g4 * T._smooth_l1_loss(bp_, ctx["rois_target"], ctx["rois_inside_ws"], ctx["rois_outside_ws"]))
-    seed.backward()
-    d_score, d_bbox = sc.grad.contiguous(), bp_.grad.contiguous()
+    # -- seeds: d RCNN losses / d (scores, bbox_pred) were written by the fused loss kernel (dana_rcnn_loss);
+    #    the upstream scalars g3 / g4 ride as alpha on the first launches that consume them --
+    d_score_pos, d_score_neg, d_bbox = ctx["loss_seeds"]
 
     # -- box branch: RCNN_bbox_pred <- mean <- layer4 (dana.py:246,387-389) --
     wb = model.RCNN_bbox_pred.weight.detach()
-    _acc(model.RCNN_bbox_pred.weight, ops.gemm_small(d_bbox, (1, 4), ctx["fc7"], (2048, 1), 4, 2048, n_roi))
-    _acc(model.RCNN_bbox_pred.bias, ops.colsum(d_bbox, n_roi, 4))
-    d_fc7 = ops.gemm_small(d_bbox, (4, 1), wb, (2048, 1), n_roi, 2048, 4)
+    _acc(model.RCNN_bbox_pred.weight, ops.gemm_small(d_bbox, (1, 4), ctx["fc7"], (2048, 1), 4, 2048, n_roi, alpha=g4))
+    _acc(model.RCNN_bbox_pred.bias, ops.colsum(d_bbox, n_roi, 4, alpha=g4))
+    d_fc7 = ops.gemm_small(d_bbox, (4, 1), wb, (2048, 1), n_roi, 2048, 4, alpha=g4)
     l4 = ctx["l4_saved"]
     npos = l4[-1]["h1"] * l4[-1]["w1"]
     g = ops.broadcast_rows(d_fc7, n_roi, npos, 2048, alpha=1.0 / npos)
@@ -266,10 +258,11 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     for hc in ctx["heads"]:
         off = hc["offset"]
         hi = 0 if off == 0 else 1  # rows of cls_score_all: positive-support scores first (dana.py:194)
-        ds = d_score[hi * n_roi:(hi + 1) * n_roi].contiguous()
-        _acc(model.output_score_layer.linear2.weight, ops.gemm_small(ds, (1, 2), hc["hid"], (nhid, 1), 2, nhid, n_roi))
-        _acc(model.output_score_layer.linear2.bias, ops.colsum(ds, n_roi, 2))
-        d_hid = ops.gemm_small(ds, (2, 1), w2, (nhid, 1), n_roi, nhid, 2)
+        ds = d_score_pos if hi == 0 else d_score_neg
+        _acc(model.output_score_layer.linear2.weight,
+             ops.gemm_small(ds, (1, 2), hc["hid"], (nhid, 1), 2, nhid, n_roi, alpha=g3))
+        _acc(model.output_score_layer.linear2.bias, ops.colsum(ds, n_roi, 2, alpha=g3))
+        d_hid = ops.gemm_small(ds, (2, 1), w2, (nhid, 1), n_roi, nhid, 2, alpha=g3)
         ops.relu_mask_(d_hid, hc["hid"], n_roi, nhid)
         dw1, db1, d_tr = ops.linear_backward(d_hid, hc["tr"], w1, n_roi, nhid, P2 * rd)
         _acc(model.output_score_layer.linear1.weight, dw1)

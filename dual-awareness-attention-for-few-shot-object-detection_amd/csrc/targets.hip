@@ -444,9 +444,181 @@ rpn_loss_reduce_kernel(const float* __restrict__ partial, int nblocks, int B, fl
   }
 }
 
+// ---- RCNN losses (dana.py:199-217): 2-way cross-entropy with the 1:2:1 hard-negative mining + box smooth-L1 ----------
+// Rows 0..n-1 are the positive-support head's scores (labels from the proposal-target layer), rows n..2n-1 the
+// negative-support head's (labels 0). fg = label 1; the background rows are ranked by their foreground probability
+// (descending; ties by row index) separately in each half, the first bg_num_0 of the first half and the first bg_num_1
+// of the second are kept (dana.py:204-213), and the cross-entropy is the mean over fg + kept rows.
+//   phase A  per row: p1 = softmax(score)[1], ce, fg flag; per block: fg count, smooth-L1 partial
+//   phase B  per row: rank among the background rows of its half -> selected?; per block: CE sum / count partials
+//   phase C  reduce -> losses; scale the gradient seeds by 1 / count
+struct RcnnLossWs {
+  float* p1;       // [2n]
+  float* ce;       // [2n]
+  float* partial;  // [blocks][4]: fg count, smooth-L1 sum, ce sum, selected count
+};
+
+__global__ void __launch_bounds__(256)
+rcnn_loss_a_kernel(const float* __restrict__ sp, const float* __restrict__ sn, const float* __restrict__ labels,
+                   const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ w_in,
+                   const float* __restrict__ w_out, int n, float sigma, RcnnLossWs ws, float* __restrict__ gbox) {
+  __shared__ float red[2][4];
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float fg = 0.f, sl1 = 0.f;
+  if (r < 2 * n) {
+    const float* s = r < n ? sp + (long)r * 2 : sn + (long)(r - n) * 2;
+    const float lab = r < n ? labels[r] : 0.f;
+    const float m = fmaxf(s[0], s[1]);
+    const float e0 = expf(s[0] - m), e1 = expf(s[1] - m);
+    ws.p1[r] = e1 / (e0 + e1);
+    ws.ce[r] = (m + logf(e0 + e1)) - (lab == 1.f ? s[1] : s[0]);
+    fg = lab == 1.f ? 1.f : 0.f;
+    if (r < n) {  // net_utils.py:71-85 with sigma, dim=[1]; the mean over rows is applied in phase C
+      const float s2 = sigma * sigma;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = w_in[r * 4 + j] * (pred[r * 4 + j] - tgt[r * 4 + j]);
+        const float ad = fabsf(d);
+        sl1 += w_out[r * 4 + j] * (ad < 1.f / s2 ? d * d * (s2 / 2.f) : ad - 0.5f / s2);
+        if (gbox) {
+          const float dl = ad < 1.f / s2 ? d * s2 : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+          gbox[r * 4 + j] = w_out[r * 4 + j] * w_in[r * 4 + j] * dl / (float)n;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    fg += __shfl_xor(fg, o);
+    sl1 += __shfl_xor(sl1, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = fg;
+    red[1][threadIdx.x >> 6] = sl1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    ws.partial[blockIdx.x * 4 + threadIdx.x] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void __launch_bounds__(256)
+rcnn_loss_b_kernel(const float* __restrict__ sp, const float* __restrict__ sn, const float* __restrict__ labels, int n,
+                   int blocks, RcnnLossWs ws, float* __restrict__ gsp, float* __restrict__ gsn) {
+  __shared__ float red[2][4];
+  __shared__ int s_fg;
+  if (threadIdx.x == 0) {
+    float c = 0.f;
+    for (int i = 0; i < blocks; ++i) c += ws.partial[i * 4];
+    s_fg = (int)c;
+  }
+  __syncthreads();
+  const int n_all = 2 * n, nfg = s_fg;
+  const int bg0 = max(1, min(nfg * 2, (int)(n_all * 0.25)));  // dana.py:207-208
+  const int bg1 = max(1, min(nfg, bg0));
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float ce = 0.f, cnt = 0.f;
+  if (r < n_all) {
+    const float lab = r < n ? labels[r] : 0.f;
+    bool sel = lab == 1.f;
+    if (lab == 0.f) {
+      const int h0 = r < n ? 0 : n, h1 = r < n ? n : n_all;
+      const float mine = ws.p1[r];
+      int rank = 0;
+      for (int j = h0; j < h1; ++j) {
+        const float lj = j < n ? labels[j] : 0.f;
+        const float pj = ws.p1[j];
+        rank += (lj == 0.f && (pj > mine || (pj == mine && j < r))) ? 1 : 0;
+      }
+      sel = rank < (r < n ? bg0 : bg1);
+    }
+    if (sel) {
+      ce = ws.ce[r];
+      cnt = 1.f;
+    }
+    float* g = r < n ? (gsp ? gsp + (long)r * 2 : nullptr) : (gsn ? gsn + (long)(r - n) * 2 : nullptr);
+    if (g) {  // unscaled seed (softmax - onehot) on kept rows; phase C divides by the count
+      const float p1 = ws.p1[r];
+      g[0] = sel ? (1.f - p1) - (lab == 1.f ? 0.f : 1.f) : 0.f;
+      g[1] = sel ? p1 - (lab == 1.f ? 1.f : 0.f) : 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ce += __shfl_xor(ce, o);
+    cnt += __shfl_xor(cnt, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = ce;
+    red[1][threadIdx.x >> 6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    ws.partial[blockIdx.x * 4 + 2 + threadIdx.x] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void __launch_bounds__(256)
+rcnn_loss_c_kernel(int n, int blocks, RcnnLossWs ws, float* __restrict__ losses, float* __restrict__ gsp,
+                   float* __restrict__ gsn) {
+  float sl1 = 0.f, ce = 0.f, cnt = 0.f;
+  for (int i = 0; i < blocks; ++i) {  // fixed order: deterministic
+    sl1 += ws.partial[i * 4 + 1];
+    ce += ws.partial[i * 4 + 2];
+    cnt += ws.partial[i * 4 + 3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    losses[0] = ce / cnt;        // F.cross_entropy mean over the kept rows (dana.py:215)
+    losses[1] = sl1 / (float)n;  // _smooth_l1_loss(...).mean() over the rois (dana.py:217)
+    losses[2] = cnt;
+  }
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < 2 * n) {
+    float* g = r < n ? (gsp ? gsp + (long)r * 2 : nullptr) : (gsn ? gsn + (long)(r - n) * 2 : nullptr);
+    if (g) {
+      g[0] /= cnt;
+      g[1] /= cnt;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t dana_rcnn_loss_workspace_bytes(int n) {
+  if (n <= 0) return 0;
+  const int blocks = (2 * n + 255) / 256;
+  return ((size_t)4 * n + (size_t)blocks * 4) * sizeof(float);
+}
+
+int dana_rcnn_loss(const float* score_pos, const float* score_neg, const float* labels, const float* bbox_pred,
+                   const float* bbox_targets, const float* inside_weights, const float* outside_weights, int n,
+                   float sigma, float* losses3, float* grad_score_pos, float* grad_score_neg, float* grad_bbox,
+                   void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(n > 0, "dana_rcnn_loss: bad shape");
+  DANA_CHECK_ARG(score_pos && score_neg && labels && bbox_pred && bbox_targets && inside_weights && outside_weights &&
+                     losses3,
+                 "dana_rcnn_loss: null pointer");
+  if (!workspace || workspace_bytes < dana_rcnn_loss_workspace_bytes(n)) {
+    dana_set_error("dana_rcnn_loss: workspace too small");
+    return DANA_ERR_WORKSPACE;
+  }
+  const int blocks = (2 * n + 255) / 256;
+  RcnnLossWs ws;
+  ws.p1 = (float*)workspace;
+  ws.ce = ws.p1 + 2 * n;
+  ws.partial = ws.ce + 2 * n;
+  hipStream_t s = (hipStream_t)stream;
+  rcnn_loss_a_kernel<<<blocks, 256, 0, s>>>(score_pos, score_neg, labels, bbox_pred, bbox_targets, inside_weights,
+                                            outside_weights, n, sigma, ws, grad_bbox);
+  DANA_CHECK_LAUNCH("dana_rcnn_loss(a)");
+  rcnn_loss_b_kernel<<<blocks, 256, 0, s>>>(score_pos, score_neg, labels, n, blocks, ws, grad_score_pos, grad_score_neg);
+  DANA_CHECK_LAUNCH("dana_rcnn_loss(b)");
+  rcnn_loss_c_kernel<<<blocks, 256, 0, s>>>(n, blocks, ws, losses3, grad_score_pos, grad_score_neg);
+  DANA_CHECK_LAUNCH("dana_rcnn_loss(c)");
+  return DANA_OK;
+}
 
 int dana_proposal_target_prepare(const float* rois, const float* gt_boxes, int B, int n_rois, int n_gt,
                                  float fg_thresh, float bg_thresh_hi, float bg_thresh_lo, float* max_overlaps,

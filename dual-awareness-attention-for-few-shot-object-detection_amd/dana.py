@@ -610,7 +610,8 @@ class DAnARCNN(nn.Module):
                 tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)
             if tl is not None:
                 tl.append(("rpn losses + proposal targets (waits for rois)", _time.perf_counter()))
-            rois_label = rois_label.view(-1).long()
+            labels_f = rois_label.reshape(-1).contiguous()
+            rois_label = labels_f.long()
             rois_target = rois_target.view(-1, 4)
             rois_inside_ws = rois_inside_ws.view(-1, 4)
             rois_outside_ws = rois_outside_ws.view(-1, 4)
@@ -710,25 +711,15 @@ class DAnARCNN(nn.Module):
         RCNN_loss_cls = RCNN_loss_bbox = 0
         if training:
             cls_prob = torch.cat([cls_prob, neg_prob], 0)
-            cls_score_all = torch.cat([cls_score_all, neg_score], 0)
             rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
-            RCNN_loss_bbox = T._smooth_l1_loss(bbox_pred, rois_target, rois_inside_ws, rois_outside_ws)
-            # 2-way classification loss with 1:2:1 hard-negative mining (dana.py:203-215)
-            fg_inds = (rois_label == 1).nonzero().squeeze(-1)
-            bg_inds = (rois_label == 0).nonzero().squeeze(-1)
-            bg_soft = F.softmax(cls_score_all, dim=1)[bg_inds, :]
-            n_all = rois_label.shape[0]
-            bg_num_0 = max(1, min(fg_inds.shape[0] * 2, int(n_all * 0.25)))
-            bg_num_1 = max(1, min(fg_inds.shape[0], bg_num_0))
-            _, order = torch.sort(bg_soft[:, 1], descending=True)
-            real_bg = bg_inds[order]
-            top0 = real_bg[real_bg < int(n_all * 0.5)][:bg_num_0]
-            top1 = real_bg[real_bg >= int(n_all * 0.5)][:bg_num_1]
-            topk = torch.cat([fg_inds, top0, top1], dim=0)
-            RCNN_loss_cls = F.cross_entropy(cls_score_all[topk], rois_label[topk])
+            # box smooth-L1 + 2-way cross-entropy with the 1:2:1 hard-negative mining (dana.py:203-217): one fused
+            # pass on the device, no host sync (the nonzero / sort / index chain of the reference has three)
+            rl, seeds = ops.rcnn_losses(cls_score_all, neg_score, labels_f, bbox_pred,
+                                        rois_target.contiguous(), rois_inside_ws.contiguous(),
+                                        rois_outside_ws.contiguous(), with_grad=ctx is not None)
+            RCNN_loss_cls, RCNN_loss_bbox = rl[0], rl[1]
             if ctx is not None:
-                ctx.update(cls_score_all=cls_score_all, bbox_pred=bbox_pred, rois_label=rois_label, topk=topk,
-                           rois_target=rois_target, rois_inside_ws=rois_inside_ws, rois_outside_ws=rois_outside_ws)
+                ctx.update(loss_seeds=seeds)
         mark("rcnn losses")
         if tl is not None:
             tl.append(("rcnn losses", _time.perf_counter()))

@@ -319,6 +319,26 @@ def rpn_losses(heads, head_row_stride, h, sigma=3.0, inside_weight=1.0):
     return out
 
 
+def rcnn_losses(score_pos, score_neg, labels, bbox_pred, bbox_targets, inside_ws, outside_ws, sigma=1.0,
+                with_grad=False):
+    """(RCNN_loss_cls, RCNN_loss_bbox) of dana.py:199-217 in one fused pass, no host sync -> (float32[3] tensor
+    (cls, box, rows kept), seeds) with seeds = (d cls / d score_pos, d cls / d score_neg, d box / d bbox_pred) or None"""
+    n = score_pos.shape[0]
+    dev = score_pos.device
+    out = torch.empty((3,), dtype=torch.float32, device=dev)
+    seeds = None
+    if with_grad:
+        seeds = (torch.empty((n, 2), dtype=torch.float32, device=dev), torch.empty((n, 2), dtype=torch.float32, device=dev),
+                 torch.empty((n, 4), dtype=torch.float32, device=dev))
+    ws = _ws(lib().query("dana_rcnn_loss_workspace_bytes", n), dev)
+    lib().call("dana_rcnn_loss", _p(_chk(score_pos, "score_pos")), _p(_chk(score_neg, "score_neg")),
+               _p(_chk(labels, "labels")), _p(_chk(bbox_pred, "bbox_pred")), _p(_chk(bbox_targets, "bbox_targets")),
+               _p(_chk(inside_ws, "inside_ws")), _p(_chk(outside_ws, "outside_ws")), n, float(sigma), _p(out),
+               _p(seeds[0]) if seeds else None, _p(seeds[1]) if seeds else None, _p(seeds[2]) if seeds else None,
+               _p(ws), ws.numel(), _stream())
+    return out, seeds
+
+
 # ------------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------------

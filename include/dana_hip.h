@@ -249,6 +249,17 @@ int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, c
                                int feat_stride, int n_gt, float inside_weight, float outside_weight,
                                float* labels_out, float* bbox_targets, float* inside_weights,
                                float* outside_weights, dana_stream_t stream);
+/* RCNN losses of the training forward (dana.py:199-217), fused: rows 0..n-1 = positive-support head scores
+ * [n][2] with the proposal-target labels [n] (0 / 1), rows n..2n-1 = negative-support head scores (labels 0).
+ * losses3[0] = cross-entropy over fg + hard-negative-mined bg rows (1:2:1: bg ranked by fg probability, descending, per
+ * half; dana.py:204-215), losses3[1] = _smooth_l1_loss(bbox_pred, targets, in, out) (net_utils.py:71-85, sigma,
+ * mean over rois), losses3[2] = number of rows kept. Optional gradient seeds (may be NULL): d losses3[0] / d scores
+ * and d losses3[1] / d bbox_pred. No host sync (the reference's nonzero / sort / index chain has three). */
+size_t dana_rcnn_loss_workspace_bytes(int n);
+int dana_rcnn_loss(const float* score_pos, const float* score_neg, const float* labels, const float* bbox_pred,
+                   const float* bbox_targets, const float* inside_weights, const float* outside_weights, int n,
+                   float sigma, float* losses3, float* grad_score_pos, float* grad_score_neg, float* grad_bbox,
+                   void* workspace, size_t workspace_bytes, dana_stream_t stream);
 /* losses3[0] = F.cross_entropy over labels >= 0 (rpn.py:97-105), losses3[1] = _smooth_l1_loss(sigma, dims 1,2,3)
  * (rpn.py:114), losses3[2] = number of labels >= 0; fused over heads[B*H*W][row stride] = (2A cls | 4A bbox) without materialising the targets. */
 size_t dana_rpn_loss_workspace_bytes(void);

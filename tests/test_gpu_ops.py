@@ -263,3 +263,46 @@ def test_anchor_targets_and_rpn_losses_hip_match_host_logic_same_rng(dev):
     out = ops.rpn_losses(heads.to(dev), 6 * A, h, sigma=3.0).cpu()
     assert abs(float(out[0]) - float(l_cls)) <= 1e-5 * max(1.0, abs(float(l_cls)))
     assert abs(float(out[1]) - float(l_box)) <= 1e-5 * max(1.0, abs(float(l_box)))
+
+
+def test_rcnn_losses_fused_vs_reference_formulation(dev):
+    """dana.py:199-217: smooth-L1 + hard-negative-mined 2-way cross-entropy, and their gradient seeds vs autograd"""
+    import torch.nn.functional as F
+    from dana_amd import ops, targets as T
+    torch.manual_seed(8)
+    for n, nfg in [(256, 40), (512, 0), (128, 100), (64, 1)]:
+        sp = (torch.randn(n, 2) * 2).double().requires_grad_(True)
+        sn = (torch.randn(n, 2) * 2).double().requires_grad_(True)
+        lab = torch.zeros(n)
+        lab[torch.randperm(n)[:nfg]] = 1
+        pred = torch.randn(n, 4).double().requires_grad_(True)
+        tgt = torch.randn(n, 4) * 0.5
+        w_in = (lab.view(-1, 1) * torch.ones(1, 4)).contiguous()
+        w_out = w_in.clone()
+        # reference formulation (dana.py:199-217)
+        score = torch.cat([sp, sn], 0)
+        label = torch.cat([lab, torch.zeros(n)], 0).long()
+        fg = (label == 1).nonzero().squeeze(-1)
+        bg = (label == 0).nonzero().squeeze(-1)
+        soft = F.softmax(score, 1)[bg, :]
+        n_all = label.shape[0]
+        b0 = max(1, min(fg.shape[0] * 2, int(n_all * 0.25)))
+        b1 = max(1, min(fg.shape[0], b0))
+        _, order = torch.sort(soft[:, 1], descending=True, stable=True)
+        real = bg[order]
+        top0 = real[real < int(n_all * 0.5)][:b0]
+        top1 = real[real >= int(n_all * 0.5)][:b1]
+        idx = torch.cat([fg, top0, top1], 0)
+        l_cls = F.cross_entropy(score[idx], label[idx])
+        l_box = T._smooth_l1_loss(pred, tgt.double(), w_in.double(), w_out.double())
+        (l_cls + l_box).backward()
+        out, seeds = ops.rcnn_losses(sp.detach().float().to(dev), sn.detach().float().to(dev), lab.to(dev),
+                                     pred.detach().float().to(dev), tgt.to(dev), w_in.to(dev), w_out.to(dev),
+                                     with_grad=True)
+        o = out.cpu()
+        assert int(o[2]) == idx.numel()
+        assert abs(float(o[0]) - float(l_cls.detach())) <= 2e-6 * max(1.0, abs(float(l_cls.detach())))
+        assert abs(float(o[1]) - float(l_box.detach())) <= 2e-6 * max(1.0, abs(float(l_box.detach())))
+        assert (seeds[0].cpu().double() - sp.grad).abs().max() <= 1e-7
+        assert (seeds[1].cpu().double() - sn.grad).abs().max() <= 1e-7
+        assert (seeds[2].cpu().double() - pred.grad).abs().max() <= 1e-7
