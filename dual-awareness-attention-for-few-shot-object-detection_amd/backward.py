@@ -215,7 +215,12 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     P2, L = 49, 400
     n_roi = B * R
     d, dq = model.rpn_reduce_dim, model.rcnn_reduce_dim
-    g1, g2, g3, g4 = [float(x) for x in grad_losses]
+    g_dev = None
+    if isinstance(grad_losses, torch.Tensor):  # upstream gradients stay on the device: no host sync in the backward
+        g_dev = grad_losses.detach().to(torch.float32).contiguous()
+        g1 = g2 = g3 = g4 = 1.0
+    else:
+        g1, g2, g3, g4 = [float(x) for x in grad_losses]
     corr = ctx["corr"]
     dev = corr.device
     grads = WeightGrads(None if getattr(model, "_single_stream", False) else model._stream("wgrad", dev))
@@ -224,6 +229,10 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     # -- seeds: d RCNN losses / d (scores, bbox_pred) were written by the fused loss kernel (dana_rcnn_loss);
     #    the upstream scalars g3 / g4 ride as alpha on the first launches that consume them --
     d_score_pos, d_score_neg, d_bbox = ctx["loss_seeds"]
+    if g_dev is not None:
+        ops.scale_by_device_scalar_(d_score_pos, g_dev[2:])
+        ops.scale_by_device_scalar_(d_score_neg, g_dev[2:])
+        ops.scale_by_device_scalar_(d_bbox, g_dev[3:])
 
     # -- box branch: RCNN_bbox_pred <- mean <- layer4 (dana.py:246,387-389) --
     wb = model.RCNN_bbox_pred.weight.detach()
@@ -308,7 +317,7 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     rpn = model.RCNN_rpn
     nh = ctx["nh"]
     d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
-                                    inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0])
+                                    inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0], grad_dev=g_dev)
     dwh, dbh, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512)
     ns = rpn.nc_score_out
     _acc(rpn.RPN_cls_score.weight, dwh[:ns])

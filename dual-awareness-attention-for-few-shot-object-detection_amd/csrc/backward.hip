@@ -271,6 +271,12 @@ int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const floa
 // ---- attention adjoints ---------------------------------------------------------------------------------
 namespace {
 
+// x[i] *= s[0] with the scalar in device memory (upstream loss gradients never visit the host)
+__global__ void __launch_bounds__(256) scale_by_dev_kernel(float* __restrict__ x, long n, const float* __restrict__ s) {
+  const float v = s[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)blockDim.x * gridDim.x) x[i] *= v;
+}
+
 // torch.optim.SGD(momentum) over a flat parameter segment (train.py:86-87): g' = g + wd * p;
 // buf = first ? g' : momentum * buf + g';  p -= lr * buf.  grad_scale folds the 1/world_size of the gradient mean.
 __global__ void __launch_bounds__(256)
@@ -405,7 +411,11 @@ __global__ void __launch_bounds__(256)
 rpn_loss_bwd_kernel(const float* __restrict__ heads, long hs, const float* __restrict__ labels,
                     const int* __restrict__ assign, const float* __restrict__ gt, const float* __restrict__ base,
                     AnchorGeomB g, int B, float sigma, float inside_w, float outside_w, const float* __restrict__ losses3,
-                    float g_cls, float g_box, float* __restrict__ dheads) {
+                    float g_cls, float g_box, const float* __restrict__ g_dev, float* __restrict__ dheads) {
+  if (g_dev) {  // upstream gradients of (rpn_loss_cls, rpn_loss_bbox) read on the device: no host round trip
+    g_cls = g_dev[0];
+    g_box = g_dev[1];
+  }
   const int total = g.H * g.W * g.A;
   const long n = (long)B * total;
   const float s2 = sigma * sigma;
@@ -445,6 +455,15 @@ rpn_loss_bwd_kernel(const float* __restrict__ heads, long hs, const float* __res
 }  // namespace
 
 extern "C" {
+
+int dana_scale_by_device_scalar(float* x, long n, const float* scalar_dev, dana_stream_t stream) {
+  DANA_CHECK_ARG(n >= 0, "dana_scale_by_device_scalar: bad size");
+  if (n == 0) return DANA_OK;
+  DANA_CHECK_ARG(x && scalar_dev, "dana_scale_by_device_scalar: null pointer");
+  scale_by_dev_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(x, n, scalar_dev);
+  DANA_CHECK_LAUNCH("dana_scale_by_device_scalar");
+  return DANA_OK;
+}
 
 int dana_sgd_momentum(float* params, const float* grads, float* momentum_buf, long n, float lr, float momentum,
                       float weight_decay, float grad_scale, int first_step, dana_stream_t stream) {
@@ -525,8 +544,8 @@ int dana_attn_softmax_unary_backward(float* grad_a, const float* a, const float*
 int dana_rpn_loss_backward(const float* heads, long head_row_stride, const float* labels, const int* argmax,
                            const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
                            int feat_stride, int n_gt, float sigma, float inside_weight, float outside_weight,
-                           const float* losses3, float grad_cls, float grad_box, float* grad_heads,
-                           dana_stream_t stream) {
+                           const float* losses3, float grad_cls, float grad_box, const float* grad_scales_dev,
+                           float* grad_heads, dana_stream_t stream) {
   DANA_CHECK_ARG(B > 0 && A > 0 && H > 0 && W > 0 && n_gt > 0 && losses3, "dana_rpn_loss_backward: bad shape");
   DANA_CHECK_ARG(heads && labels && argmax && gt_boxes && base_anchors && grad_heads,
                  "dana_rpn_loss_backward: null pointer");
@@ -540,7 +559,8 @@ int dana_rpn_loss_backward(const float* heads, long head_row_stride, const float
   int blocks = dana_ceil_div(n, 256);
   if (blocks > 2048) blocks = 2048;
   rpn_loss_bwd_kernel<<<blocks, 256, 0, s>>>(heads, head_row_stride, labels, argmax, gt_boxes, base_anchors, g, B, sigma,
-                                             inside_weight, outside_weight, losses3, grad_cls, grad_box, grad_heads);
+                                             inside_weight, outside_weight, losses3, grad_cls, grad_box, grad_scales_dev,
+                                             grad_heads);
   DANA_CHECK_LAUNCH("dana_rpn_loss_backward");
   return DANA_OK;
 }

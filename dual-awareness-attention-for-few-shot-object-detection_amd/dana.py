@@ -126,7 +126,7 @@ class _LossBridge(torch.autograd.Function):
     def backward(fctx, g1, g2, g3, g4):
         from . import backward as BW
         gs = [torch.zeros((), device=fctx.model._grad_anchor.device) if g is None else g.reshape(()) for g in (g1, g2, g3, g4)]
-        BW.model_backward(fctx.model, torch.stack(gs).tolist())  # one D2H read of the four upstream scalars
+        BW.model_backward(fctx.model, torch.stack(gs))  # the four upstream scalars stay in device memory
         return None, None, None, None, None, None
 
 

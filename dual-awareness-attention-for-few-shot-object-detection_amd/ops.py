@@ -729,14 +729,21 @@ def attn_softmax_unary_backward_(grad_a, a, unary, rows, rows_per_batch, nseg, l
     return grad_a
 
 
-def rpn_loss_backward(heads, head_row_stride, h, losses3, grad_cls=1.0, grad_box=1.0, sigma=3.0, inside_weight=1.0):
-    """d(grad_cls * rpn_loss_cls + grad_box * rpn_loss_bbox) / d heads, same [B*H*W][row stride] layout"""
+def scale_by_device_scalar_(x, scalar_dev):
+    lib().call("dana_scale_by_device_scalar", _p(_chk(x, "x")), x.numel(), _p(_chk(scalar_dev, "scalar")), _stream())
+    return x
+
+
+def rpn_loss_backward(heads, head_row_stride, h, losses3, grad_cls=1.0, grad_box=1.0, sigma=3.0, inside_weight=1.0,
+                      grad_dev=None):
+    """d(grad_cls * rpn_loss_cls + grad_box * rpn_loss_bbox) / d heads, same [B*H*W][row stride] layout;
+    grad_dev: the two upstream scalars as a device tensor instead"""
     _chk(heads, "heads")
     g = torch.empty_like(heads)
     lib().call("dana_rpn_loss_backward", _p(heads), head_row_stride, _p(h["labels"]), _p(h["argmax"]), _p(h["gt_boxes"]),
                _p(h["base_anchors"]), h["B"], h["A"], h["H"], h["W"], h["stride"], h["n_gt"], float(sigma),
                float(inside_weight), 1.0 / h["num_examples"], _p(_chk(losses3, "losses3")), float(grad_cls),
-               float(grad_box), _p(g), _stream())
+               float(grad_box), _p(grad_dev), _p(g), _stream())
     return g
 
 

@@ -329,12 +329,15 @@ int dana_attn_softmax_unary_backward(float* grad_a, const float* a, const float*
                                      long unary_batch_stride, int nseg, int length, long ld, int kpad,
                                      float unary_gamma, float out_scale, float alpha, dana_stream_t stream);
 /* adjoint of dana_rpn_loss w.r.t. the head buffer: grad_heads[B*H*W][row stride] (zero-filled here);
- * losses3 = dana_rpn_loss's DEVICE output (its [2] is the cross-entropy's divisor); grad_cls / grad_box = upstream scalars */
+ * losses3 = dana_rpn_loss's DEVICE output (its [2] is the cross-entropy's divisor); grad_cls / grad_box = upstream scalars,
+ * or grad_scales_dev (2 floats in device memory) when given */
 int dana_rpn_loss_backward(const float* heads, long head_row_stride, const float* labels, const int* argmax,
                            const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
                            int feat_stride, int n_gt, float sigma, float inside_weight, float outside_weight,
-                           const float* losses3, float grad_cls, float grad_box, float* grad_heads,
-                           dana_stream_t stream);
+                           const float* losses3, float grad_cls, float grad_box, const float* grad_scales_dev,
+                           float* grad_heads, dana_stream_t stream);
+/* x[0..n) *= scalar_dev[0]: applies an upstream loss gradient that lives in device memory (no host sync) */
+int dana_scale_by_device_scalar(float* x, long n, const float* scalar_dev, dana_stream_t stream);
 
 /* ---- episode input pipeline: the loaders' per-image cv2 / numpy work ------------------------ */
 

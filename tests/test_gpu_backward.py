@@ -96,6 +96,8 @@ def test_rpn_loss_backward_vs_autograd(dev):
     hg = heads.to(dev)
     l3 = ops.rpn_losses(hg, 6 * A, h, sigma=3.0)
     g = ops.rpn_loss_backward(hg, 6 * A, h, l3, 0.7, 1.3, sigma=3.0)
+    g2 = ops.rpn_loss_backward(hg, 6 * A, h, l3, sigma=3.0, grad_dev=torch.tensor([0.7, 1.3], device=dev))
+    assert torch.equal(g, g2)
     assert float(l3[2]) == float(keep.numel())
     _close(g.cpu(), hd.grad, 1e-5)
 
