@@ -21,11 +21,27 @@ class WeightGrads:
     With `stream`, the weight-gradient launches go to that side stream: they only consume (g, x) and nothing on the
     data-gradient chain waits for them, so their tiles fill the CUs the chain's launches leave idle in their tails."""
 
-    def __init__(self, stream=None):
+    def __init__(self, stream=None, model=None):
         self.packed = {}
         self.convs = {}
         self.stream = stream
-        self.keep = []  # operands of in-flight side-stream launches (allocated on the caller's stream)
+        self.model = model
+        self.direct = {}  # key -> packed VIEW of param.grad (trainer layout): weight gradients land there directly
+        self.keep = []    # operands of in-flight side-stream launches (allocated on the caller's stream)
+
+    def _direct_view(self, key):
+        """the parameter's gradient as a packed [cout][kh*kw*cin] view, if the trainer stores it that way"""
+        if key in self.direct:
+            return self.direct[key]
+        v = None
+        if self.model is not None:
+            g = self.model.get_parameter(key + ".weight").grad
+            if g is not None:
+                v = ops.packed_view(g)
+                if v is not None and v.data_ptr() != g.data_ptr():
+                    v = None
+        self.direct[key] = v
+        return v
 
     def add_conv(self, key, g, x, n, h, w, c, in_stride=0, grad_stride=0):
         self.convs[key] = c
@@ -40,6 +56,11 @@ class WeightGrads:
             self._launch(key, g, x, n, h, w, c, in_stride, grad_stride)
 
     def _launch(self, key, g, x, n, h, w, c, in_stride, grad_stride):
+        view = self._direct_view(key)
+        if view is not None:  # scale by the frozen BN and accumulate straight into param.grad: nothing to finish
+            ops.conv2d_wgrad(g, x, n, h, w, c["cin"], c["cout"], c["k"], c["k"], c["stride"], c["pad"],
+                             in_stride=in_stride, grad_stride=grad_stride, out=view, row_scale=c.get("scale"))
+            return
         buf = self.packed.get(key)
         if buf is None:
             self.packed[key] = ops.conv2d_wgrad(g, x, n, h, w, c["cin"], c["cout"], c["k"], c["k"], c["stride"],
@@ -223,7 +244,7 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
         g1, g2, g3, g4 = [float(x) for x in grad_losses]
     corr = ctx["corr"]
     dev = corr.device
-    grads = WeightGrads(None if getattr(model, "_single_stream", False) else model._stream("wgrad", dev))
+    grads = WeightGrads(None if getattr(model, "_single_stream", False) else model._stream("wgrad", dev), model)
     ug = model.unary_gamma
 
     # -- seeds: d RCNN losses / d (scores, bbox_pred) were written by the fused loss kernel (dana_rcnn_loss);

@@ -211,18 +211,34 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_128_kernel(WgradParams p) {
     }
 }
 
-// dW[i] = (accumulate ? dW[i] : 0) + sum_s partial[s][i], fixed order
+// dW[i] = (accumulate ? dW[i] : 0) + row_scale[row(i)] * sum_s partial[s][i], fixed order. row_scale (optional) is the
+// frozen-BN scale of the output channel: with it the launch writes straight into the parameter's gradient.
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW, long n4, int S, int accumulate) {
+wgrad_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW, const float* __restrict__ row_scale,
+                    long n4, int K4, int S, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  float4 a = accumulate ? dW[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int s = 0; s < S; ++s) {
     const float4 v = partial[(long)s * n4 + i];
     a.x += v.x;
     a.y += v.y;
     a.z += v.z;
     a.w += v.w;
+  }
+  if (row_scale) {
+    const float sc = row_scale[i / K4];
+    a.x *= sc;
+    a.y *= sc;
+    a.z *= sc;
+    a.w *= sc;
+  }
+  if (accumulate) {
+    const float4 o = dW[i];
+    a.x += o.x;
+    a.y += o.y;
+    a.z += o.z;
+    a.w += o.w;
   }
   dW[i] = a;
 }
@@ -315,8 +331,8 @@ size_t dana_conv2d_wgrad_workspace_bytes(int batch, int in_h, int in_w, int cin,
  * frozen-BN scale and the ReLU mask by the caller); cin % 64 == 0, cout % 4 == 0. */
 int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* grad_weight, int batch, int in_h,
                            int in_w, int cin, int cout, int kh, int kw, int stride, int pad, long in_pix_stride,
-                           long grad_pix_stride, int accumulate, void* workspace, size_t workspace_bytes,
-                           dana_stream_t stream) {
+                           long grad_pix_stride, const float* row_scale, int accumulate, void* workspace,
+                           size_t workspace_bytes, dana_stream_t stream) {
   DANA_CHECK_ARG(batch >= 0 && in_h > 0 && in_w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
                  "dana_conv2d_wgrad_nhwc: bad shape");
   if (batch == 0) return DANA_OK;
@@ -365,8 +381,8 @@ int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* gra
     wgrad_f32_kernel<<<grid, 256, 0, s>>>(p);
   DANA_CHECK_LAUNCH("dana_conv2d_wgrad_nhwc");
   const long n4 = (long)cout * p.K / 4;
-  wgrad_reduce_kernel<<<dana_ceil_div(n4, 256), 256, 0, s>>>((const float4*)workspace, (float4*)grad_weight, n4, S,
-                                                             accumulate);
+  wgrad_reduce_kernel<<<dana_ceil_div(n4, 256), 256, 0, s>>>((const float4*)workspace, (float4*)grad_weight, row_scale,
+                                                             n4, p.K / 4, S, accumulate);
   DANA_CHECK_LAUNCH("dana_conv2d_wgrad_nhwc(reduce)");
   return DANA_OK;
 }

@@ -514,7 +514,23 @@ def transpose_batched(x, groups, rows, cols, ldi=0, out=None, ldo=0, in_batch=0,
     return out
 
 
+def packed_view(w):
+    """the [O][KH*KW*I] kernel layout of a conv weight / gradient as a VIEW, when the tensor is stored that way
+    (channels-last strides: the trainer keeps trainable conv weights and their gradients in the kernels' own layout);
+    None otherwise"""
+    if w.dim() != 4:
+        return None
+    O, I, KH, KW = w.shape
+    if w.stride() != (I * KH * KW, 1, KW * I, I) and not (KH == 1 and KW == 1 and w.is_contiguous()):
+        return None
+    return w.detach().permute(0, 2, 3, 1).reshape(O, KH * KW * I) if (KH, KW) != (1, 1) else w.detach().reshape(O, I)
+
+
 def pack_conv_weight(w, stem=False):
+    if not stem:
+        v = packed_view(w)
+        if v is not None and v.data_ptr() == w.data_ptr():
+            return _chk(v, "weight")
     w = _chk(w.detach().contiguous(), "weight")
     O, I, KH, KW = w.shape
     out = torch.empty((O, 7 * 8 * 4) if stem else (O, KH * KW * I), dtype=torch.float32, device=w.device)
@@ -571,8 +587,9 @@ def attn_softmax_unary_(scores, unary, rows, rows_per_batch, nseg, length, ld, k
 # backward building blocks (groundwork for the training step)
 # ------------------------------------------------------------------------------------------------
 def conv2d_wgrad(grad_out, x, batch, in_h, in_w, cin, cout, kh, kw, stride, pad, in_stride=0, grad_stride=0,
-                 out=None):
-    """dW in the packed layout [cout][kh*kw*cin] = sum over output pixels of grad_out^T . im2col(x)."""
+                 out=None, row_scale=None):
+    """dW in the packed layout [cout][kh*kw*cin] = row_scale * sum over output pixels of grad_out^T . im2col(x);
+    accumulated into `out` when that is given."""
     _chk(grad_out, "grad_out")
     _chk(x, "x")
     accumulate = out is not None
@@ -582,7 +599,7 @@ def conv2d_wgrad(grad_out, x, batch, in_h, in_w, cin, cout, kh, kw, stride, pad,
              x.device)
     e0 = _prof_begin()
     lib().call("dana_conv2d_wgrad_nhwc", _p(grad_out), _p(x), _p(out), batch, in_h, in_w, cin, cout, kh, kw, stride,
-               pad, in_stride, grad_stride, int(accumulate), _p(ws), ws.numel(), _stream())
+               pad, in_stride, grad_stride, _p(row_scale), int(accumulate), _p(ws), ws.numel(), _stream())
     m = batch * ((in_h + 2 * pad - kh) // stride + 1) * ((in_w + 2 * pad - kw) // stride + 1)
     _prof_end(e0, "wgrad%dx%d M=%d N=%d K=%d s%d" % (kh, kw, m, cout, kh * kw * cin, stride),
               2.0 * m * cout * kh * kw * cin)

@@ -53,9 +53,18 @@ class FlatBuckets:
         self.launch_order = []
         for n, p in named_params:  # re-point parameter and gradient storage into the flat buffers
             o, k = self.offsets[n]
-            self.params[o:o + k].copy_(p.detach().reshape(-1))
-            p.data = self.params[o:o + k].view(p.shape)
-            p.grad = self.grads[o:o + k].view(p.shape)
+            if p.dim() == 4:
+                # conv weights live in the kernels' own layout [O][KH][KW][I] (= channels-last strides of the OIHW
+                # parameter): the forward reads them in place, the weight-gradient kernel accumulates into .grad in
+                # place -- no pack / unpack launches per step; state_dict / load_state_dict see the logical OIHW tensor
+                O, I, KH, KW = p.shape
+                pv = self.params[o:o + k].view(O, KH, KW, I).permute(0, 3, 1, 2)
+                gv = self.grads[o:o + k].view(O, KH, KW, I).permute(0, 3, 1, 2)
+            else:
+                pv, gv = self.params[o:o + k].view(p.shape), self.grads[o:o + k].view(p.shape)
+            pv.copy_(p.detach())
+            p.data = pv
+            p.grad = gv
 
     def zero_grad(self):
         self.grads.zero_()

@@ -271,13 +271,14 @@ int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels,
 /* ---- backward building blocks of the conv / Linear layers (training step, SURVEY.md 8d variant S) --------
  * what autograd + cuDNN compute for nn.Conv2d in the reference's loss.backward() (train.py:141-143) */
 
-/* grad_weight[cout][kh][kw][cin] (+)= sum_m grad_out[m][cout] * im2col(input)[m][...]; deterministic split-M
- * reduction through the workspace. cin % 64 == 0, cout % 4 == 0. */
+/* grad_weight[cout][kh][kw][cin] (+)= row_scale[cout] * sum_m grad_out[m][cout] * im2col(input)[m][...]; deterministic
+ * split-M reduction through the workspace. row_scale (optional) = the frozen-BN scale of each output channel, so the
+ * launch can accumulate straight into a parameter gradient kept in this layout. cin % 64 == 0, cout % 4 == 0. */
 size_t dana_conv2d_wgrad_workspace_bytes(int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride,
                                          int pad);
 int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* grad_weight, int batch, int in_h,
                            int in_w, int cin, int cout, int kh, int kw, int stride, int pad, long in_pix_stride,
-                           long grad_pix_stride, int accumulate, void* workspace, size_t workspace_bytes,
+                           long grad_pix_stride, const float* row_scale, int accumulate, void* workspace, size_t workspace_bytes,
                            dana_stream_t stream);
 /* weights for the data gradient of a stride-1 conv: out[cin][kh][kw][cout] = w[cout][KH-1-kh][KW-1-kw][cin]*scale[cout];
  * grad_input = dana_conv2d_nhwc(grad_out, out, cin <-> cout swapped, same kernel size / pad) */
