@@ -45,6 +45,9 @@ def parse():
                     help="train: train-mode forward (variant F, the headline); eval: inference forward; step: the full "
                          "training iteration fwd+bwd+gradient all-reduce+SGD (variant S) as the headline")
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary variant-S measurement")
+    ap.add_argument("--device-rng", action="store_true",
+                    help="sample the training targets with the device Philox RNG (no host sync; NOT the reference's "
+                         "np.random stream, which is the default and what the parity tests pin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
@@ -102,6 +105,7 @@ def main():
     model.to(dev)
     model.train() if training else model.eval()
     model._single_stream = bool(args.single_stream)
+    model.device_rng = bool(args.device_rng)
     # every rank gets its own episodes (weak scaling), already resident in HBM before the timed region
     inputs = [t.to(dev) for t in S.episode_inputs(args.batch, way, args.shot, args.height, args.width,
                                                   seed=1996 + rank)]
@@ -162,7 +166,8 @@ def main():
                                "supports/episode, %s, %s" % (
                                    2 if args.ba else 1, args.way, args.shot, args.batch, args.height, args.width,
                                    way * args.shot, "BA+CISA" if args.ba else "CISA only", what),
-                   "global_batch": world * args.batch, "parallelism": "episodes sharded, %d rank(s)" % world},
+                   "global_batch": world * args.batch, "parallelism": "episodes sharded, %d rank(s)" % world,
+                   "target_sampling": "device Philox RNG" if args.device_rng else "host np.random (reference stream)"},
     }
 
     if args.mode == "train" and not args.no_train_step:

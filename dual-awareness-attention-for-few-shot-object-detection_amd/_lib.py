@@ -18,6 +18,7 @@ _CTYPES = {
     "long": ctypes.c_long,
     "float": ctypes.c_float,
     "double": ctypes.c_double,
+    "unsigned long long": ctypes.c_ulonglong,
     "size_t": ctypes.c_size_t,
     "dana_stream_t": ctypes.c_void_p,
 }

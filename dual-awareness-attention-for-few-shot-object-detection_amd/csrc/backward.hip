@@ -410,8 +410,10 @@ __device__ __forceinline__ float4 anchor_box_b(const float* __restrict__ base, c
 __global__ void __launch_bounds__(256)
 rpn_loss_bwd_kernel(const float* __restrict__ heads, long hs, const float* __restrict__ labels,
                     const int* __restrict__ assign, const float* __restrict__ gt, const float* __restrict__ base,
-                    AnchorGeomB g, int B, float sigma, float inside_w, float outside_w, const float* __restrict__ losses3,
+                    AnchorGeomB g, int B, float sigma, float inside_w, float outside_w,
+                    const float* __restrict__ outside_w_dev, const float* __restrict__ losses3,
                     float g_cls, float g_box, const float* __restrict__ g_dev, float* __restrict__ dheads) {
+  if (outside_w_dev) outside_w = outside_w_dev[0];
   if (g_dev) {  // upstream gradients of (rpn_loss_cls, rpn_loss_bbox) read on the device: no host round trip
     g_cls = g_dev[0];
     g_box = g_dev[1];
@@ -544,6 +546,7 @@ int dana_attn_softmax_unary_backward(float* grad_a, const float* a, const float*
 int dana_rpn_loss_backward(const float* heads, long head_row_stride, const float* labels, const int* argmax,
                            const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
                            int feat_stride, int n_gt, float sigma, float inside_weight, float outside_weight,
+                           const float* outside_weight_dev,
                            const float* losses3, float grad_cls, float grad_box, const float* grad_scales_dev,
                            float* grad_heads, dana_stream_t stream) {
   DANA_CHECK_ARG(B > 0 && A > 0 && H > 0 && W > 0 && n_gt > 0 && losses3, "dana_rpn_loss_backward: bad shape");
@@ -559,7 +562,8 @@ int dana_rpn_loss_backward(const float* heads, long head_row_stride, const float
   int blocks = dana_ceil_div(n, 256);
   if (blocks > 2048) blocks = 2048;
   rpn_loss_bwd_kernel<<<blocks, 256, 0, s>>>(heads, head_row_stride, labels, argmax, gt_boxes, base_anchors, g, B, sigma,
-                                             inside_weight, outside_weight, losses3, grad_cls, grad_box, grad_scales_dev,
+                                             inside_weight, outside_weight, outside_weight_dev, losses3, grad_cls, grad_box,
+                                             grad_scales_dev,
                                              grad_heads);
   DANA_CHECK_LAUNCH("dana_rpn_loss_backward");
   return DANA_OK;

@@ -349,8 +349,10 @@ __global__ void __launch_bounds__(256)
 anchor_target_outputs_kernel(const float* __restrict__ labels, const float* __restrict__ max_ov,
                              const int* __restrict__ assign, const float* __restrict__ gt,
                              const float* __restrict__ base, AnchorGeom g, float inside_w, float outside_w,
+                             const float* __restrict__ outside_w_dev,
                              float* __restrict__ labels_out, float* __restrict__ targets, float* __restrict__ w_in,
                              float* __restrict__ w_out) {
+  if (outside_w_dev) outside_w = outside_w_dev[0];  // 1 / num_examples computed on the device (device-RNG mode)
   const int b = blockIdx.y;
   const int total = g.H * g.W * g.A, hw = g.H * g.W;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -375,7 +377,9 @@ anchor_target_outputs_kernel(const float* __restrict__ labels, const float* __re
 __global__ void __launch_bounds__(256)
 rpn_loss_kernel(const float* __restrict__ heads, long head_row_stride, const float* __restrict__ labels,
                 const int* __restrict__ assign, const float* __restrict__ gt, const float* __restrict__ base,
-                AnchorGeom g, int B, float sigma, float inside_w, float outside_w, float* __restrict__ partial) {
+                AnchorGeom g, int B, float sigma, float inside_w, float outside_w, const float* __restrict__ outside_w_dev,
+                float* __restrict__ partial) {
+  if (outside_w_dev) outside_w = outside_w_dev[0];
   __shared__ float red[3][4];
   const int total = g.H * g.W * g.A;
   const long n = (long)B * total;
@@ -690,6 +694,7 @@ int dana_anchor_target_disable(float* labels, const int* fg_list, const int* bg_
 int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, const int* argmax,
                                const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
                                int feat_stride, int n_gt, float inside_weight, float outside_weight,
+                               const float* outside_weight_dev,
                                float* labels_out, float* bbox_targets, float* inside_weights,
                                float* outside_weights, dana_stream_t stream) {
   DANA_CHECK_ARG(B >= 0 && A > 0 && H > 0 && W > 0 && n_gt > 0, "dana_anchor_target_outputs: bad shape");
@@ -700,7 +705,7 @@ int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, c
   AnchorGeom g = {A, H, W, feat_stride, n_gt};
   dim3 grid(dana_ceil_div((long)H * W * A, 256), B);
   anchor_target_outputs_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(labels, max_overlaps, argmax, gt_boxes,
-                                                                      base_anchors, g, inside_weight, outside_weight,
+                                                                      base_anchors, g, inside_weight, outside_weight, outside_weight_dev,
                                                                       labels_out, bbox_targets, inside_weights,
                                                                       outside_weights);
   DANA_CHECK_LAUNCH("dana_anchor_target_outputs");
@@ -711,7 +716,8 @@ size_t dana_rpn_loss_workspace_bytes(void) { return 512 * 3 * sizeof(float); }
 
 int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels, const int* argmax,
                   const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W, int feat_stride,
-                  int n_gt, float sigma, float inside_weight, float outside_weight, float* losses3, void* workspace,
+                  int n_gt, float sigma, float inside_weight, float outside_weight, const float* outside_weight_dev,
+                  float* losses3, void* workspace,
                   size_t workspace_bytes, dana_stream_t stream) {
   DANA_CHECK_ARG(B > 0 && A > 0 && H > 0 && W > 0 && n_gt > 0 && head_row_stride >= 6 * A, "dana_rpn_loss: bad shape");
   DANA_CHECK_ARG(heads && labels && argmax && gt_boxes && base_anchors && losses3, "dana_rpn_loss: null pointer");
@@ -724,7 +730,7 @@ int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels,
   int blocks = dana_ceil_div(n, 256);
   if (blocks > 512) blocks = 512;
   rpn_loss_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(heads, head_row_stride, labels, argmax, gt_boxes,
-                                                           base_anchors, g, B, sigma, inside_weight, outside_weight,
+                                                           base_anchors, g, B, sigma, inside_weight, outside_weight, outside_weight_dev,
                                                            (float*)workspace);
   DANA_CHECK_LAUNCH("dana_rpn_loss");
   rpn_loss_reduce_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, blocks, B, losses3);

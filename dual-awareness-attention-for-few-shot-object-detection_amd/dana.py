@@ -183,6 +183,9 @@ class DAnARCNN(nn.Module):
         self.output_score_layer = FFN(64 * 49, dim_in)
         self._plan = None
         self._consts = {}
+        self.device_rng = False   # True: the target layers sample with the device Philox RNG (no host sync, not the
+        self.rng_seed = 1996      #       reference's np.random stream); seed as train.py:33
+        self._rng_calls = 0
         self._conv_cache = {}     # per-conv plan entries (see _conv_bn)
         self._epoch = 0           # bumped by the trainer after an in-place (raw pointer) weight update
         self._ctx = None          # saved-for-backward context of the last training forward
@@ -585,13 +588,17 @@ class DAnARCNN(nn.Module):
         if training:
             # anchor targets depend on the inputs only: they are computed on a side stream so that their
             # host syncs (np.random needs the counts) never drain the main stream's kernel queue
+            rng = None
+            if self.device_rng:  # counter-based device RNG (opt-in): (seed, 2 * forward counter [+ 1])
+                rng = (int(self.rng_seed), 2 * self._rng_calls)
+                self._rng_calls += 1
             side = self._stream("targets", dev)
             side.wait_event(inputs_ready)  # NOT wait_stream(main): the trunk is already queued there
             tr_ = cfg.TRAIN
             with torch.cuda.stream(side):
                 at = ops.anchor_target_assign(gt_boxes.float(), im_info, plan["anchors"], fh, fw, rpn.feat_stride,
                                               tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP, tr_.RPN_BATCHSIZE,
-                                              tr_.RPN_FG_FRACTION)
+                                              tr_.RPN_FG_FRACTION, device_rng=rng and (rng[0], rng[1]))
             at["ibuf"].record_stream(main)
             at["labels"].record_stream(main)
             main.wait_stream(side)
@@ -607,7 +614,7 @@ class DAnARCNN(nn.Module):
             rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_layer(
                 rois, gt_boxes.float(), int(tr_.BATCH_SIZE), fg_per, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
                 tr_.BBOX_NORMALIZE_MEANS, tr_.BBOX_NORMALIZE_STDS, tr_.BBOX_INSIDE_WEIGHTS,
-                tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)
+                tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED, device_rng=rng and (rng[0], rng[1] + 1))
             if tl is not None:
                 tl.append(("rpn losses + proposal targets (waits for rois)", _time.perf_counter()))
             labels_f = rois_label.reshape(-1).contiguous()

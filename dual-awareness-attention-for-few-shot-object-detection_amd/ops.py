@@ -196,9 +196,10 @@ def rpn_decode(cls, cls_strides, cls_is_prob, bbox, bbox_strides, im_info, base_
 
 
 def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_thresh, bg_hi, bg_lo, means, stds,
-                          inside_w, normalize=True):
+                          inside_w, normalize=True, device_rng=None):
     """_ProposalTargetLayer.forward (proposal_target_layer_cascade.py:33-213): two HIP launches around one
-    D2H read of the fg/bg counts; the sampling draws np.random exactly like the reference (:143-175)."""
+    D2H read of the fg/bg counts; the sampling draws np.random exactly like the reference (:143-175).
+    device_rng = (seed, offset): draw on the device instead (Philox), no host sync, a different random stream."""
     import ctypes
     import numpy as np
     rois = _chk(rois.contiguous(), "rois")
@@ -212,8 +213,13 @@ def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_
     counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
     lib().call("dana_proposal_target_prepare", _p(rois), _p(gt_boxes), B, n_rois, n_gt, float(fg_thresh), float(bg_hi),
                float(bg_lo), _p(max_ov), _p(ibuf[0]), _p(ibuf[1]), _p(ibuf[2]), _p(counts), _stream())
-    cnt = counts.cpu().numpy()  # the one host sync: np.random needs the counts
     R = rois_per_image
+    if device_rng is not None:
+        host = torch.empty((B * R + B,), dtype=torch.int32, device=dev)
+        lib().call("dana_proposal_target_sample", _p(counts), B, n_all, R, fg_rois_per_image, int(device_rng[0]),
+                   int(device_rng[1]), _p(host), host.data_ptr() + B * R * 4, _stream())
+        return _proposal_target_gather(rois, gt_boxes, B, n_rois, n_gt, ibuf, host, R, means, stds, inside_w, normalize)
+    cnt = counts.cpu().numpy()  # the one host sync: np.random needs the counts
     picks = np.zeros((B, R), dtype=np.int32)
     taken = np.zeros((B,), dtype=np.int32)
     for i in range(B):
@@ -232,7 +238,13 @@ def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_
             raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
         taken[i] = fg_n
     host = torch.from_numpy(np.concatenate([picks.reshape(-1), taken])).to(dev, non_blocking=True)
-    out = torch.empty((B, R, 18), dtype=torch.float32, device=dev)  # rois 5 | label 1 | tgt 4 | w_in 4 | w_out 4
+    return _proposal_target_gather(rois, gt_boxes, B, n_rois, n_gt, ibuf, host, R, means, stds, inside_w, normalize)
+
+
+def _proposal_target_gather(rois, gt_boxes, B, n_rois, n_gt, ibuf, host, R, means, stds, inside_w, normalize):
+    """host: int32 [B*R picks | B fg_taken] on the device"""
+    import ctypes
+    dev = rois.device
     rois_out = torch.empty((B, R, 5), dtype=torch.float32, device=dev)
     labels = torch.empty((B, R), dtype=torch.float32, device=dev)
     tgt = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
@@ -244,12 +256,11 @@ def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_
                ctypes.cast(f4(*means), ctypes.c_void_p), ctypes.cast(f4(*stds), ctypes.c_void_p),
                ctypes.cast(f4(*inside_w), ctypes.c_void_p), int(bool(normalize)), _p(rois_out), _p(labels), _p(tgt),
                _p(w_in), _p(w_out), _stream())
-    del out
     return rois_out, labels, tgt, w_in, w_out
 
 
 def anchor_target_assign(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_stride, negative_overlap,
-                         positive_overlap, rpn_batchsize, fg_fraction):
+                         positive_overlap, rpn_batchsize, fg_fraction, device_rng=None):
     """_AnchorTargetLayer (anchor_target_layer.py:48-193) up to the sampled labels: one HIP launch, one D2H
     read of the fg/bg counts, the reference's np.random.permutation draws (:137-156), one scatter launch.
     Returns a dict consumed by rpn_losses() / anchor_target_outputs()."""
@@ -268,8 +279,15 @@ def anchor_target_assign(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_s
     lib().call("dana_anchor_target_prepare", _p(gt_boxes), _p(im_info), _p(base_anchors), B, A, feat_h, feat_w,
                feat_stride, n_gt, float(negative_overlap), float(positive_overlap), _p(labels), _p(max_ov), _p(ibuf[0]),
                _p(ibuf[1]), _p(ibuf[2]), _p(counts), _stream())
-    cnt = counts.cpu().numpy()
     num_fg = int(fg_fraction * rpn_batchsize)
+    if device_rng is not None:  # subsample on the device (Philox): no host sync, a different random stream
+        inv_ne = torch.empty((1,), dtype=torch.float32, device=dev)
+        lib().call("dana_anchor_target_subsample", _p(labels), _p(ibuf[1]), _p(ibuf[2]), _p(counts), B, total,
+                   int(rpn_batchsize), num_fg, int(device_rng[0]), int(device_rng[1]), _p(inv_ne), _stream())
+        return dict(labels=labels, max_ov=max_ov, argmax=ibuf[0], ibuf=ibuf, gt_boxes=gt_boxes,
+                    base_anchors=base_anchors, B=B, A=A, H=feat_h, W=feat_w, stride=feat_stride, n_gt=n_gt,
+                    num_examples=1, inv_ne_dev=inv_ne)
+    cnt = counts.cpu().numpy()
     which, pos = [], []
     num_examples = 0
     for i in range(B):
@@ -304,7 +322,7 @@ def anchor_target_outputs(h, inside_weight=1.0):
     w_in, w_out = torch.empty_like(tgt), torch.empty_like(tgt)
     lib().call("dana_anchor_target_outputs", _p(h["labels"]), _p(h["max_ov"]), _p(h["argmax"]), _p(h["gt_boxes"]),
                _p(h["base_anchors"]), B, A, H, W, h["stride"], h["n_gt"], float(inside_weight),
-               1.0 / h["num_examples"], _p(labels), _p(tgt), _p(w_in), _p(w_out), _stream())
+               1.0 / h["num_examples"], _p(h.get("inv_ne_dev")), _p(labels), _p(tgt), _p(w_in), _p(w_out), _stream())
     return labels, tgt, w_in, w_out
 
 
@@ -315,7 +333,8 @@ def rpn_losses(heads, head_row_stride, h, sigma=3.0, inside_weight=1.0):
     ws = _ws(lib().query("dana_rpn_loss_workspace_bytes"), heads.device)
     lib().call("dana_rpn_loss", _p(heads), head_row_stride, _p(h["labels"]), _p(h["argmax"]), _p(h["gt_boxes"]),
                _p(h["base_anchors"]), h["B"], h["A"], h["H"], h["W"], h["stride"], h["n_gt"], float(sigma),
-               float(inside_weight), 1.0 / h["num_examples"], _p(out), _p(ws), ws.numel(), _stream())
+               float(inside_weight), 1.0 / h["num_examples"], _p(h.get("inv_ne_dev")), _p(out), _p(ws), ws.numel(),
+               _stream())
     return out
 
 
@@ -759,7 +778,8 @@ def rpn_loss_backward(heads, head_row_stride, h, losses3, grad_cls=1.0, grad_box
     g = torch.empty_like(heads)
     lib().call("dana_rpn_loss_backward", _p(heads), head_row_stride, _p(h["labels"]), _p(h["argmax"]), _p(h["gt_boxes"]),
                _p(h["base_anchors"]), h["B"], h["A"], h["H"], h["W"], h["stride"], h["n_gt"], float(sigma),
-               float(inside_weight), 1.0 / h["num_examples"], _p(_chk(losses3, "losses3")), float(grad_cls),
+               float(inside_weight), 1.0 / h["num_examples"], _p(h.get("inv_ne_dev")), _p(_chk(losses3, "losses3")),
+               float(grad_cls),
                float(grad_box), _p(grad_dev), _p(g), _stream())
     return g
 

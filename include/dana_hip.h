@@ -246,7 +246,7 @@ int dana_anchor_target_disable(float* labels, const int* fg_list, const int* bg_
  * bbox_targets / inside / outside weights [B][4A][H*W] (:171-191). */
 int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, const int* argmax,
                                const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
-                               int feat_stride, int n_gt, float inside_weight, float outside_weight,
+                               int feat_stride, int n_gt, float inside_weight, float outside_weight, const float* outside_weight_dev,
                                float* labels_out, float* bbox_targets, float* inside_weights,
                                float* outside_weights, dana_stream_t stream);
 /* RCNN losses of the training forward (dana.py:199-217), fused: rows 0..n-1 = positive-support head scores
@@ -261,11 +261,11 @@ int dana_rcnn_loss(const float* score_pos, const float* score_neg, const float* 
                    float sigma, float* losses3, float* grad_score_pos, float* grad_score_neg, float* grad_bbox,
                    void* workspace, size_t workspace_bytes, dana_stream_t stream);
 /* losses3[0] = F.cross_entropy over labels >= 0 (rpn.py:97-105), losses3[1] = _smooth_l1_loss(sigma, dims 1,2,3)
- * (rpn.py:114), losses3[2] = number of labels >= 0; fused over heads[B*H*W][row stride] = (2A cls | 4A bbox) without materialising the targets. */
+ * (rpn.py:114), losses3[2] = number of labels >= 0; outside_weight_dev (optional, device) overrides outside_weight; fused over heads[B*H*W][row stride] = (2A cls | 4A bbox) without materialising the targets. */
 size_t dana_rpn_loss_workspace_bytes(void);
 int dana_rpn_loss(const float* heads, long head_row_stride, const float* labels, const int* argmax,
                   const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W, int feat_stride,
-                  int n_gt, float sigma, float inside_weight, float outside_weight, float* losses3, void* workspace,
+                  int n_gt, float sigma, float inside_weight, float outside_weight, const float* outside_weight_dev, float* losses3, void* workspace,
                   size_t workspace_bytes, dana_stream_t stream);
 
 /* ---- backward building blocks of the conv / Linear layers (training step, SURVEY.md 8d variant S) --------
@@ -334,7 +334,7 @@ int dana_attn_softmax_unary_backward(float* grad_a, const float* a, const float*
  * or grad_scales_dev (2 floats in device memory) when given */
 int dana_rpn_loss_backward(const float* heads, long head_row_stride, const float* labels, const int* argmax,
                            const float* gt_boxes, const float* base_anchors, int B, int A, int H, int W,
-                           int feat_stride, int n_gt, float sigma, float inside_weight, float outside_weight,
+                           int feat_stride, int n_gt, float sigma, float inside_weight, float outside_weight, const float* outside_weight_dev,
                            const float* losses3, float grad_cls, float grad_box, const float* grad_scales_dev,
                            float* grad_heads, dana_stream_t stream);
 /* x[0..n) *= scalar_dev[0]: applies an upstream loss gradient that lives in device memory (no host sync) */
@@ -356,6 +356,22 @@ int dana_crop_resize_pad(const float* im_hwc, int height, int width, int x_min, 
  * permuted to CHW: one plane set of the batch holder */
 int dana_crop_pad_chw(const float* im_hwc, int height, int width, int y_start, int x_start, int crop_h, int crop_w,
                       float* out_chw, int out_h, int out_w, dana_stream_t stream);
+
+/* ---- counter-based device RNG for the training target layers (opt-in) ---------------------------
+ * Philox-4x32-10 keyed by (seed, offset, image): the draws of anchor_target_layer.py:137-156 and
+ * proposal_target_layer_cascade.py:143-175 without reading the fg / bg counts back to the host. */
+
+/* counts[B][2] (fg, bg) from dana_proposal_target_prepare -> picks[B][rois_per_image] (positions in the fg list for
+ * the first fg_taken[b] slots, in the bg list for the rest) for dana_proposal_target_gather */
+int dana_proposal_target_sample(const int* counts, int B, int n_candidates, int rois_per_image, int fg_rois_per_image,
+                                unsigned long long seed, unsigned long long offset, int* picks, int* fg_taken,
+                                dana_stream_t stream);
+/* labels[B][anchors_per_image] from dana_anchor_target_prepare: keep a uniform random num_fg-subset of the positives and
+ * (rpn_batchsize - kept) of the negatives, label the rest -1; inv_num_examples[0] = 1 / (examples of the LAST image)
+ * for the outside_weight_dev argument of dana_rpn_loss / dana_rpn_loss_backward / dana_anchor_target_outputs */
+int dana_anchor_target_subsample(float* labels, const int* fg_list, const int* bg_list, const int* counts, int B,
+                                 int anchors_per_image, int rpn_batchsize, int num_fg, unsigned long long seed,
+                                 unsigned long long offset, float* inv_num_examples, dana_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -306,3 +306,114 @@ def test_rcnn_losses_fused_vs_reference_formulation(dev):
         assert (seeds[0].cpu().double() - sp.grad).abs().max() <= 1e-7
         assert (seeds[1].cpu().double() - sn.grad).abs().max() <= 1e-7
         assert (seeds[2].cpu().double() - pred.grad).abs().max() <= 1e-7
+
+
+def _anchor_prepare(dev, gt, im_info, anchors, H, W):
+    from dana_amd import ops
+    from dana_amd._lib import lib
+    from dana_amd.config import cfg
+    B, n_gt, _ = gt.shape
+    A = anchors.shape[0]
+    total = H * W * A
+    labels = torch.empty((B, total), dtype=torch.float32, device=dev)
+    max_ov = torch.empty((B, total), dtype=torch.float32, device=dev)
+    ibuf = torch.empty((3, B, total), dtype=torch.int32, device=dev)
+    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    lib().call("dana_anchor_target_prepare", gt.data_ptr(), im_info.data_ptr(), anchors.data_ptr(), B, A, H, W, 16, n_gt,
+               float(cfg.TRAIN.RPN_NEGATIVE_OVERLAP), float(cfg.TRAIN.RPN_POSITIVE_OVERLAP), labels.data_ptr(),
+               max_ov.data_ptr(), ibuf[0].data_ptr(), ibuf[1].data_ptr(), ibuf[2].data_ptr(), counts.data_ptr(),
+               torch.cuda.current_stream().cuda_stream)
+    return labels, counts
+
+
+def test_device_rng_target_sampling_is_valid_deterministic_and_uniform(dev):
+    """opt-in Philox sampling of the two target layers (no host sync): same distributions as the reference's
+    np.random draws (anchor_target_layer.py:137-156, proposal_target_layer_cascade.py:143-175), checked by their
+    invariants, by determinism in (seed, offset) and by first moments"""
+    from dana_amd import ops, targets as T
+    from dana_amd.config import cfg
+    np.random.seed(2)
+    B, H, W, n_gt = 3, 20, 30, 8
+    gt = torch.zeros(B, n_gt, 5)
+    for b in range(B):
+        for k in range(2 + 2 * b):
+            x1, y1 = np.random.uniform(0, 300), np.random.uniform(0, 180)
+            gt[b, k] = torch.tensor([x1, y1, x1 + np.random.uniform(40, 160), y1 + np.random.uniform(40, 130), 1.0])
+    im_info = torch.tensor([[H * 16.0, W * 16.0, 1.0]] * B)
+    anchors = torch.from_numpy(T.generate_anchors(scales=np.array(cfg.ANCHOR_SCALES),
+                                                  ratios=np.array(cfg.ANCHOR_RATIOS))).float()
+    gt_d, ii_d, an_d = gt.to(dev), im_info.to(dev), anchors.to(dev)
+    pre, counts = _anchor_prepare(dev, gt_d, ii_d, an_d, H, W)
+    pre, cnt = pre.cpu().numpy(), counts.cpu().numpy()
+    tr = cfg.TRAIN
+    num_fg = int(tr.RPN_FG_FRACTION * tr.RPN_BATCHSIZE)
+
+    def run(seed, off):
+        h = ops.anchor_target_assign(gt_d, ii_d, an_d, H, W, 16, tr.RPN_NEGATIVE_OVERLAP, tr.RPN_POSITIVE_OVERLAP,
+                                     tr.RPN_BATCHSIZE, tr.RPN_FG_FRACTION, device_rng=(seed, off))
+        return h["labels"].cpu().numpy(), float(h["inv_ne_dev"].cpu())
+
+    lab, inv = run(7, 0)
+    for b in range(B):
+        nf, nb = int(cnt[b, 0]), int(cnt[b, 1])
+        assert nf == int((pre[b] == 1).sum()) and nb == int((pre[b] == 0).sum())
+        keep_f = min(nf, num_fg)
+        keep_b = min(nb, tr.RPN_BATCHSIZE - keep_f)
+        assert int((lab[b] == 1).sum()) == keep_f and int((lab[b] == 0).sum()) == keep_b
+        changed = lab[b] != pre[b]
+        assert np.all(lab[b][changed] == -1) and np.all(pre[b][changed] >= 0)
+        if b == B - 1:
+            assert abs(inv - 1.0 / (keep_f + keep_b)) < 1e-9
+    assert int(cnt[:, 1].max()) > tr.RPN_BATCHSIZE  # the subsampling really had something to drop
+    lab2, _ = run(7, 0)
+    lab3, _ = run(7, 1)
+    lab4, _ = run(8, 0)
+    assert np.array_equal(lab, lab2) and not np.array_equal(lab, lab3) and not np.array_equal(lab, lab4)
+    # uniformity: every background anchor of image 0 survives with probability keep_b / nb
+    nb0 = int(cnt[0, 1])
+    keep0 = min(nb0, tr.RPN_BATCHSIZE - min(int(cnt[0, 0]), num_fg))
+    hits = np.zeros(pre.shape[1])
+    trials = 300
+    for t in range(trials):
+        hits += run(11, 100 + t)[0][0] == 0
+    p = keep0 / nb0
+    freq = hits[pre[0] == 0] / trials
+    assert abs(freq.mean() - p) < 1e-9  # exactly keep0 survivors per draw
+    assert np.abs(freq - p).max() < 6 * np.sqrt(p * (1 - p) / trials) + 1e-3
+    # a rpn loss computed from the device handle works and is finite
+    heads = torch.randn(B * H * W, 6 * anchors.shape[0], device=dev) * 0.5
+    h = ops.anchor_target_assign(gt_d, ii_d, an_d, H, W, 16, tr.RPN_NEGATIVE_OVERLAP, tr.RPN_POSITIVE_OVERLAP,
+                                 tr.RPN_BATCHSIZE, tr.RPN_FG_FRACTION, device_rng=(7, 0))
+    l3 = ops.rpn_losses(heads, 6 * anchors.shape[0], h, sigma=3.0).cpu()
+    assert torch.isfinite(l3).all() and int(l3[2]) == int((lab >= 0).sum())
+
+    # ---- proposal targets ----
+    from dana_amd._lib import lib
+    n_rois = 400
+    rois = torch.zeros(B, n_rois, 5)
+    for b in range(B):
+        rois[b, :, 0] = b
+        x1 = torch.rand(n_rois) * 350
+        y1 = torch.rand(n_rois) * 200
+        rois[b, :, 1], rois[b, :, 2] = x1, y1
+        rois[b, :, 3], rois[b, :, 4] = x1 + 30 + torch.rand(n_rois) * 120, y1 + 30 + torch.rand(n_rois) * 100
+        rois[b, :40, 1:] = gt[b, b % 2, :4] + torch.randn(40, 4) * 3  # some foreground candidates
+    rois_d = rois.to(dev)
+    R, fg_per = 128, 32
+    args = (rois_d, gt_d, R, fg_per, tr.FG_THRESH, tr.BG_THRESH_HI, tr.BG_THRESH_LO, tr.BBOX_NORMALIZE_MEANS,
+            tr.BBOX_NORMALIZE_STDS, tr.BBOX_INSIDE_WEIGHTS, True)
+    o1 = ops.proposal_target_layer(*args, device_rng=(5, 0))
+    o2 = ops.proposal_target_layer(*args, device_rng=(5, 0))
+    o3 = ops.proposal_target_layer(*args, device_rng=(5, 2))
+    assert all(torch.equal(a, b_) for a, b_ in zip(o1, o2)) and not torch.equal(o1[0], o3[0])
+    rois_out, labels, tgt, w_in, w_out = [t.cpu() for t in o1]
+    cand = torch.cat([rois[:, :, 1:], gt[:, :, :4]], 1)  # the layer appends the gt boxes to the proposals (:47-52)
+    for b in range(B):
+        nfg = int((labels[b] == 1).sum())
+        assert 0 < nfg <= fg_per and torch.all(labels[b, :nfg] == 1) and torch.all(labels[b, nfg:] == 0)
+        assert torch.all(rois_out[b, :, 0] == b)
+        d = (rois_out[b, :, None, 1:] - cand[b][None]).abs().sum(-1).min(1).values
+        assert torch.all(d == 0)  # every sampled roi is one of the candidates
+        fgb = rois_out[b, :nfg, 1:]
+        assert len({tuple(r.tolist()) for r in fgb}) == nfg  # foreground picks are drawn without replacement
+        assert torch.all((w_in[b] > 0).any(1) == (labels[b] == 1))
