@@ -209,3 +209,35 @@ def test_train_forward_and_step_with_device_rng(dev):
     tr.step(*inputs)
     torch.cuda.synchronize()
     assert not torch.equal(before, m.RCNN_rpn.RPN_Conv.weight.detach())
+
+
+def test_train_forward_full_size_vs_oracle(dev):
+    """BASELINE.json's query size (600x1000, way 2, shot 3, CISA only = configs[1]) in train mode, B = 2: same sampled
+    rois / labels as the oracle under the same np.random stream, losses within 1e-4"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    from oracle import model_ref as O
+    torch.set_num_threads(min(64, torch.get_num_threads() * 8))
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=2, shot=3, classes=["fg", "bg"])
+    sd = S.fill_state_dict(m.state_dict(), seed=11, profile="test")
+    m.load_state_dict(sd)
+    m.to(dev).train()
+    inputs = S.episode_inputs(2, 2, 3, 600, 1000, seed=1996)
+    np.random.seed(5)
+    with torch.no_grad():
+        out = m(*[t.to(dev) for t in inputs])
+    np.random.seed(5)
+    with torch.no_grad():
+        ref = O.forward(sd, *inputs, True, 2, 3, False, nms_inclusive=False)
+    r, rg = out[0].cpu().numpy().reshape(-1, 5), ref[0].numpy().reshape(-1, 5)
+    matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
+    assert matched.mean() >= 0.97, "sampled rois diverge from the oracle: %.1f%% match" % (100 * matched.mean())
+    assert abs(float(out[3]) - float(ref[3])) <= 1e-4 * max(1.0, abs(float(ref[3])))  # rpn_loss_cls
+    assert abs(float(out[4]) - float(ref[4])) <= 1e-4 * max(1.0, abs(float(ref[4])))  # rpn_loss_bbox
+    if matched.all():
+        assert np.array_equal(out[7].cpu().numpy(), ref[7].numpy())
+        m2 = np.concatenate([matched, matched])
+        assert np.abs(out[1].cpu().numpy() - ref[1].numpy())[m2].max() <= 1e-4
+        assert np.abs(out[2].cpu().numpy() - ref[2].numpy()).max() <= 1e-4
+        for a, b in zip(out[5:7], ref[5:7]):
+            assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b)))
