@@ -1,0 +1,125 @@
+"""Sibling model `frcnn` of the reference's factory (utils.py:109-110): the plain class-agnostic Faster R-CNN of
+lib/model/framework/faster_rcnn.py:17-203 on the SAME HIP operators as the DAnA path --
+Caffe ResNet-50 trunk -> RPN -> proposal layer -> (train) anchor / proposal targets -> RoIAlign or RoIPool ->
+layer4 -> RCNN_cls_score / RCNN_bbox_pred -> losses. Same parameter tree and state_dict keys as the reference class.
+Forward only: its losses are not connected to the HIP backward (that covers the DAnA path)."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from . import targets as T
+from .config import cfg
+from .dana import DAnARCNN, _RPNParams
+
+
+class FasterRCNN(DAnARCNN):
+    def __init__(self, classes, num_layers=50, pretrained=False):
+        nn.Module.__init__(self)
+        self.model_path = "data/pretrained_model/resnet50_caffe.pth"
+        self.dout_base_model = 1024
+        self.pretrained = pretrained
+        self.classes = classes
+        self.n_classes = len(classes)
+        self.class_agnostic = True
+        self.semantic_enhance = False
+        self.use_winograd = True
+        self.winograd_min_cin = int(__import__("os").environ.get("DANA_WINO_MIN_CIN", 256))
+        self.query_streams, self.query_sequential, self.merge_trunk = 1, False, False
+        self.nms_inclusive = False
+        self.device_rng, self.rng_seed, self._rng_calls = False, 1996, 0
+        self.RCNN_rpn = _RPNParams(self.dout_base_model)
+        self._plan, self._consts, self._conv_cache, self._epoch = None, {}, {}, 0
+        self._ctx = self._grad_anchor = None
+        self._init_modules()
+        self._init_weights()
+
+    def _init_modules(self):
+        DAnARCNN._init_modules(self)  # trunk, RCNN_top, RCNN_bbox_pred, the freezing rules (faster_rcnn.py:129-160)
+        self.RCNN_cls_score = nn.Linear(2048, self.n_classes)
+
+    def _init_weights(self):
+        DAnARCNN._init_weights(self)
+        self.RCNN_cls_score.weight.data.normal_(0, 0.01)
+        self.RCNN_cls_score.bias.data.zero_()
+
+    def forward(self, im_data, im_info, gt_boxes, num_boxes):
+        plan = self._get_plan()
+        dev = im_data.device
+        training = self.training
+        B = im_data.size(0)
+        im_info = im_info.data.float().contiguous()
+        gt_boxes = gt_boxes.data
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record()
+        main = torch.cuda.current_stream()
+        base, fh, fw = self._rcnn_base(im_data, plan)  # [B*fh*fw][1024] NHWC (faster_rcnn.py:43)
+        hw = fh * fw
+        # -- RPN (rpn.py:58-115) on base_feat --
+        rpn = self.RCNN_rpn
+        if plan["rpn_conv_u"] is not None:
+            x, _, _ = ops.conv3x3_winograd(base, B, fh, fw, rpn.din, plan["rpn_conv_u"], 512, shift=plan["rpn_conv_b"],
+                                           relu=True)
+        else:
+            x, _, _ = ops.conv2d_nhwc(base, B, fh, fw, rpn.din, plan["rpn_conv_w"], 512, 3, 3, 1, 1,
+                                      shift=plan["rpn_conv_b"], relu=True)
+        nh = rpn.nc_score_out + rpn.nc_bbox_out
+        heads = ops.gemm_nt(x, plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])
+        A = plan["anchors"].size(0)
+        key = "TRAIN" if training else "TEST"
+        rois = ops.proposal_layer(heads, (hw * nh, 1, nh), False, heads.view(-1)[rpn.nc_score_out:], (hw * nh, 1, nh),
+                                  im_info, plan["anchors"], B, A, fh, fw, rpn.feat_stride, cfg[key].RPN_PRE_NMS_TOP_N,
+                                  cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH, self.nms_inclusive)
+        rpn_loss_cls = rpn_loss_bbox = 0
+        rois_label = None
+        if training:
+            tr_ = cfg.TRAIN
+            side = self._stream("targets", dev)
+            side.wait_event(inputs_ready)
+            with torch.cuda.stream(side):
+                at = ops.anchor_target_assign(gt_boxes.float(), im_info, plan["anchors"], fh, fw, rpn.feat_stride,
+                                              tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP, tr_.RPN_BATCHSIZE,
+                                              tr_.RPN_FG_FRACTION)
+            at["ibuf"].record_stream(main)
+            at["labels"].record_stream(main)
+            main.wait_stream(side)
+            rpn_l = ops.rpn_losses(heads, nh, at, sigma=3.0, inside_weight=tr_.RPN_BBOX_INSIDE_WEIGHTS[0])
+            rpn_loss_cls, rpn_loss_bbox = rpn_l[0], rpn_l[1]
+            fg_per = int(np.round(tr_.FG_FRACTION * tr_.BATCH_SIZE)) or 1
+            rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_layer(
+                rois, gt_boxes.float(), int(tr_.BATCH_SIZE), fg_per, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
+                tr_.BBOX_NORMALIZE_MEANS, tr_.BBOX_NORMALIZE_STDS, tr_.BBOX_INSIDE_WEIGHTS,
+                tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)
+            rois_label = rois_label.view(-1).long()
+            rois_target = rois_target.view(-1, 4)
+            rois_inside_ws = rois_inside_ws.view(-1, 4)
+            rois_outside_ws = rois_outside_ws.view(-1, 4)
+        R = rois.size(1)
+        n_roi = B * R
+        P = cfg.POOLING_SIZE
+        # -- RoI pooling (faster_rcnn.py:70-73): both modes of the reference --
+        if cfg.POOLING_MODE == "align":
+            pooled, _ = ops.roi_align_forward_nhwc(base, B, fh, fw, 1024, 1024, rois.view(-1, 5), 1.0 / 16.0, P, 0)
+        elif cfg.POOLING_MODE == "pool":
+            nchw = ops.nhwc_to_nchw(base, B, 1024, fh, fw)
+            pooled_nchw, _ = ops.roi_pool_forward(nchw, rois.view(-1, 5).contiguous(), 1.0 / 16.0, P, P)
+            pooled = ops.nchw_to_nhwc(pooled_nchw)
+        else:
+            raise NotImplementedError("POOLING_MODE '%s'" % cfg.POOLING_MODE)
+        # -- head: layer4 -> mean -> two Linear layers (faster_rcnn.py:76-88,183-185) --
+        y, h4, w4 = pooled, P, P
+        for bp in plan["layer4"]:
+            y, h4, w4 = self._bottleneck(y, n_roi, h4, w4, bp)
+        fc7 = ops.spatial_mean(y, n_roi, h4 * w4, 2048)
+        wb, bb = self._w(self.RCNN_bbox_pred)
+        wc, bc = self._w(self.RCNN_cls_score)
+        bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
+        cls_score = ops.gemm_nt(fc7, wc, n_roi, self.n_classes, 2048, shift=bc)
+        cls_prob = ops.softmax_rows_(cls_score.clone(), n_roi, self.n_classes)
+        RCNN_loss_cls = RCNN_loss_bbox = 0
+        if training:  # faster_rcnn.py:93-98
+            RCNN_loss_cls = F.cross_entropy(cls_score, rois_label)
+            RCNN_loss_bbox = T._smooth_l1_loss(bbox_pred, rois_target, rois_inside_ws, rois_outside_ws)
+        return (rois, cls_prob.view(B, R, -1), bbox_pred.view(B, R, -1), rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls,
+                RCNN_loss_bbox, rois_label)

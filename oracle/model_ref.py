@@ -535,6 +535,43 @@ def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_
 
 
 # ------------------------------------------------------------------------------------------------
+# sibling model on the same ops: plain Faster R-CNN, lib/model/framework/faster_rcnn.py:35-103
+# ------------------------------------------------------------------------------------------------
+def frcnn_forward(sd, im_data, im_info, gt_boxes, num_boxes, training, nms_inclusive=True, pooling="align"):
+    B = im_data.shape[0]
+    base_feat = rcnn_base(im_data, sd)
+    cls, prob, bbox = rpn_head(base_feat, sd)
+    rois = proposal_layer(prob.detach(), bbox.detach(), im_info, "TRAIN" if training else "TEST", nms_inclusive)
+    rpn_loss_cls = rpn_loss_bbox = 0
+    rois_label = None
+    if training:
+        H, W = cls.shape[2:]
+        lab, tg, w_in, w_out = anchor_target_layer((H, W), gt_boxes, im_info)
+        sc = cls.view(B, 2, -1, W).permute(0, 2, 3, 1).reshape(-1, 2)
+        keep = lab.view(-1).ne(-1).nonzero().view(-1)
+        rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
+        rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
+        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        rois_label = rois_label.view(-1).long()
+        rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
+    r5 = rois.view(-1, 5).numpy()
+    if pooling == "align":
+        pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), r5, 1.0 / 16.0, 7, 7, 0))
+    else:
+        pooled = torch.from_numpy(native.roi_pool_forward(base_feat.detach().numpy(), r5, 1.0 / 16.0, 7, 7)[0])
+    fc7 = rcnn_top(pooled, sd)
+    bbox_pred = _lin(fc7, sd, "RCNN_bbox_pred")
+    cls_score = _lin(fc7, sd, "RCNN_cls_score")
+    cls_prob = F.softmax(cls_score, 1)
+    loss_cls = loss_bbox = 0
+    if training:
+        loss_cls = F.cross_entropy(cls_score, rois_label)
+        loss_bbox = smooth_l1(bbox_pred, rois_target, rw_in, rw_out)
+    return (rois, cls_prob.view(B, rois.size(1), -1), bbox_pred.view(B, rois.size(1), -1), rpn_loss_cls, rpn_loss_bbox,
+            loss_cls, loss_bbox, rois_label)
+
+
+# ------------------------------------------------------------------------------------------------
 # inference post-processing: inference.py:106-140, utils.py:312-317
 # ------------------------------------------------------------------------------------------------
 def postprocess(rois, cls_prob, bbox_pred, im_info, thresh=0.05, nms_thresh=0.3, nms_inclusive=True):

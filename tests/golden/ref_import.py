@@ -100,3 +100,12 @@ def build_model(use_ba, way, shot):
                            num_way=way, num_shot=shot)
     m.create_architecture()
     return m
+
+
+def build_frcnn():
+    """the reference's plain Faster R-CNN sibling (lib/model/framework/faster_rcnn.py:122-203), class-agnostic, 2 classes"""
+    load()
+    from model.framework import faster_rcnn
+    m = faster_rcnn.FasterRCNN(["fg", "bg"], pretrained=False)
+    m.create_architecture()
+    return m

@@ -241,3 +241,60 @@ def test_train_forward_full_size_vs_oracle(dev):
         assert np.abs(out[2].cpu().numpy() - ref[2].numpy()).max() <= 1e-4
         for a, b in zip(out[5:7], ref[5:7]):
             assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b)))
+
+
+@pytest.mark.parametrize("tag", ["eval_small", "train_small"])
+def test_frcnn_sibling_matches_reference_golden(golden_dir, dev, tag):
+    """get_model('frcnn') (utils.py:109-110) on the same HIP operators vs the reference's own outputs"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    g = _load(golden_dir, "frcnn_" + tag)
+    training, B, H, W, wseed, iseed, nseed = [int(v) for v in g["meta"]]
+    m = dana_amd.get_model("frcnn", pretrained=False, classes=["fg", "bg"])
+    m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=wseed, profile="test"))
+    m.to(dev)
+    m.nms_inclusive = True
+    m.train() if training else m.eval()
+    im_data, im_info, gt, nb, _ = S.episode_inputs(B, 1, 1, H, W, seed=iseed)
+    np.random.seed(nseed)
+    with torch.no_grad():
+        out = m(im_data.to(dev), im_info.to(dev), gt.to(dev), nb.to(dev))
+    r, rg = out[0].cpu().numpy().reshape(-1, 5), g["rois"].reshape(-1, 5)
+    matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
+    assert matched.mean() >= 0.97
+    if matched.all():
+        assert np.abs(out[1].cpu().numpy() - g["cls_prob"]).max() <= 1e-4
+        assert np.abs(out[2].cpu().numpy() - g["bbox_pred"]).max() <= 1e-4
+        if training:
+            assert np.array_equal(out[7].cpu().numpy(), g["rois_label"])
+            for i, name in ((3, "rpn_loss_cls"), (4, "rpn_loss_bbox"), (5, "RCNN_loss_cls"), (6, "RCNN_loss_bbox")):
+                assert abs(float(out[i]) - float(g[name])) <= 1e-4 * max(1.0, abs(float(g[name]))), name
+    else:
+        assert not training  # eval rois are deterministic: a mismatch there is a real difference
+        raise AssertionError("eval rois differ from the reference: %.1f%% match" % (100 * matched.mean()))
+
+
+def test_frcnn_roi_pool_mode_vs_oracle(dev):
+    """cfg.POOLING_MODE = 'pool' (faster_rcnn.py:72-73): the RoIPool kernel inside a model, vs the oracle"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    from dana_amd.config import cfg
+    from oracle import model_ref as O
+    m = dana_amd.get_model("frcnn", pretrained=False, classes=["fg", "bg"])
+    sd = S.fill_state_dict(m.state_dict(), seed=13, profile="test")
+    m.load_state_dict(sd)
+    m.to(dev).eval()
+    im_data, im_info, gt, nb, _ = S.episode_inputs(1, 1, 1, 160, 224, seed=3)
+    old = cfg.POOLING_MODE
+    cfg.POOLING_MODE = "pool"
+    try:
+        with torch.no_grad():
+            out = m(im_data.to(dev), im_info.to(dev), gt.to(dev), nb.to(dev))
+            ref = O.frcnn_forward(sd, im_data, im_info, gt, nb, False, nms_inclusive=False, pooling="pool")
+    finally:
+        cfg.POOLING_MODE = old
+    r, rg = out[0].cpu().numpy().reshape(-1, 5), ref[0].numpy().reshape(-1, 5)
+    matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
+    assert matched.mean() >= 0.99
+    assert np.abs(out[1].cpu().numpy() - ref[1].numpy()).reshape(-1, 2)[matched].max() <= 1e-4
+    assert np.abs(out[2].cpu().numpy() - ref[2].numpy()).reshape(-1, 4)[matched].max() <= 1e-4

@@ -1,6 +1,6 @@
 """Tile sweep for the igemm kernel on the trunk's layer shapes (run with DANA_IGEMM_TILE=0..3)."""
 import os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import dana_amd
 from dana_amd import ops
 dev = torch.device('cuda:0')

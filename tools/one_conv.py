@@ -1,6 +1,6 @@
 """Run one conv shape repeatedly (for rocprofv3 --pmc): tools/one_conv.py N H W Cin Cout k stride res iters"""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import dana_amd
 from dana_amd import ops
 n, h, w, ci, co, k, st, res, iters = [int(v) for v in sys.argv[1:10]]
