@@ -131,6 +131,18 @@ class Trainer:
         model._grad_ready_cb = self._on_ready
         for fb, _, _ in self.groups:
             fb.broadcast_params(0)  # one-time parameter broadcast (replicas start identical)
+        if self.weights.world > 1:
+            # ... and the frozen parameters / BatchNorm buffers, which nn.DataParallel re-replicates from GPU 0 on every
+            # step (train.py:104-105): one coalesced broadcast of everything outside the flat buffers
+            flat = set(w_names) | set(b_names)
+            rest = [t for k, t in model.state_dict(keep_vars=True).items() if k not in flat and t.dtype.is_floating_point]
+            if rest:
+                buf = torch.cat([t.detach().reshape(-1) for t in rest])
+                dist.broadcast(buf, 0, group=process_group)
+                off = 0
+                for t in rest:
+                    t.detach().copy_(buf[off:off + t.numel()].view_as(t))
+                    off += t.numel()
 
     def _on_ready(self, names):
         for fb, _, _ in self.groups:
