@@ -88,11 +88,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # test hook (1-GPU boxes): DANA_BENCH_BACKEND=gloo runs every rank on cuda:0 and exchanges over gloo, to exercise
+    # the multi-rank control flow where RCCL (one rank per device) cannot; the driver's runs use nccl = RCCL
+    backend = os.environ.get("DANA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def dist_barrier():
+        if backend == "nccl":
+            dist.barrier(device_ids=[local])
+        else:
+            dist.barrier()
 
     import dana_amd
     from dana_amd import ops, synthetic as S
@@ -132,7 +146,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local])
+            dist_barrier()
         torch.cuda.synchronize()
 
     barrier()
@@ -196,7 +210,8 @@ def main():
         tr = trainer[0]
         result["train_step"] = {
             "what": "train.py:125-143 iteration: forward + backward (HIP kernels) + bucketed gradient all-reduce "
-                    "(%s) + fused SGD" % ("RCCL, %d ranks" % world if world > 1 else "single rank: no exchange"),
+                    "(%s) + fused SGD" % ("%s, %d ranks" % ("RCCL" if backend == "nccl" else backend, world) if world > 1
+                                       else "single rank: no exchange"),
             "value": round(world * args.batch * ks / dts, 3), "unit": "query-images/sec", "steps": ks, "warmup": kw,
             "ms_per_step": round(1000.0 * dts / ks, 3),
             "gradient_mbytes": round(4e-6 * sum(fb.numel for fb, _, _ in tr.groups), 1),
@@ -261,7 +276,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local])  # the other ranks wait for rank 0's roofline pass before tearing down
+        dist_barrier()  # the other ranks wait for rank 0's roofline pass before tearing down
         dist.destroy_process_group()
 
 
