@@ -148,6 +148,33 @@ gemm_small_kernel(const float* __restrict__ a, long sam, long sak, const float* 
   *o = (accumulate ? *o : 0.f) + alpha * s;
 }
 
+// long-K variant (K >= 64, e.g. the [2 x n_roi] x [n_roi x 1024] weight gradients of the skinny heads): a block =
+// 64 output columns of one output row x 4 K-slices; the slices are summed through LDS in a fixed order
+__global__ void __launch_bounds__(256)
+gemm_small_ksplit_kernel(const float* __restrict__ a, long sam, long sak, const float* __restrict__ b, long sbk, long sbn,
+                         float* __restrict__ c, long scm, long scn, int N, int K, float alpha, int accumulate) {
+  __shared__ float part[4][64];
+  const int nl = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + nl;
+  const long m = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f;
+  if (n < N) {
+    int k = ks;
+    for (; k + 4 < K; k += 8) {  // two independent chains per lane
+      s0 += a[m * sam + k * sak] * b[k * sbk + n * sbn];
+      s1 += a[m * sam + (k + 4) * sak] * b[(k + 4) * sbk + n * sbn];
+    }
+    for (; k < K; k += 4) s0 += a[m * sam + k * sak] * b[k * sbk + n * sbn];
+  }
+  part[ks][nl] = s0 + s1;
+  __syncthreads();
+  if (ks == 0 && n < N) {
+    const float s = (part[0][nl] + part[1][nl]) + (part[2][nl] + part[3][nl]);
+    float* o = c + m * scm + n * scn;
+    *o = (accumulate ? *o : 0.f) + alpha * s;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -260,8 +287,14 @@ int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const floa
   if (m == 0 || n == 0) return DANA_OK;
   DANA_CHECK_ARG(a && b && c, "dana_gemm_small: null pointer");
   const long total = (long)m * n;
-  gemm_small_kernel<<<dana_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(
-      a, a_stride_m, a_stride_k, b, b_stride_k, b_stride_n, c, c_stride_m, c_stride_n, m, n, k, alpha, accumulate);
+  if (k >= 64 && m <= 65535) {
+    dim3 grid(dana_ceil_div(n, 64), m);
+    gemm_small_ksplit_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, a_stride_m, a_stride_k, b, b_stride_k, b_stride_n, c,
+                                                                   c_stride_m, c_stride_n, n, k, alpha, accumulate);
+  } else {
+    gemm_small_kernel<<<dana_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(
+        a, a_stride_m, a_stride_k, b, b_stride_k, b_stride_n, c, c_stride_m, c_stride_n, m, n, k, alpha, accumulate);
+  }
   DANA_CHECK_LAUNCH("dana_gemm_small");
   return DANA_OK;
 }

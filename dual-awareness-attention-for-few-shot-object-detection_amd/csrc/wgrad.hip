@@ -243,19 +243,29 @@ wgrad_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW,
   dW[i] = a;
 }
 
-// packed weight [cout][kh][kw][cin] (* scale[cout]) -> data-gradient weight [cin][kh'][kw'][cout], spatially flipped
+// packed weight [cout][kh][kw][cin] (* scale[cout]) -> data-gradient weight [cin][kh'][kw'][cout], spatially flipped.
+// One 32x32 (cout x cin) tile of one tap per block through LDS: reads coalesced along cin, writes along cout.
 __global__ void __launch_bounds__(256)
 dgrad_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int cout,
                     int cin, int KH, int KW) {
-  const long total = (long)cout * cin * KH * KW;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int co = (int)(i % cout);
-  const int kw = (int)((i / cout) % KW);
-  const int kh = (int)((i / cout / KW) % KH);
-  const long ci = i / cout / KW / KH;
-  const float s = scale ? scale[co] : 1.f;
-  out[i] = w[(((long)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * cin + ci] * s;
+  __shared__ float tile[32][33];
+  const int taps = KH * KW;
+  const int tap = blockIdx.z, ftap = taps - 1 - tap;  // (KH-1-kh, KW-1-kw) of the source
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < cout && ci < cin) v = w[((long)co * taps + ftap) * cin + ci] * (scale ? scale[co] : 1.f);
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < cin && co < cout) out[((long)ci * taps + tap) * cout + co] = tile[tx][r];
+  }
 }
 
 // strided 1x1 data gradient: g_in[b][2oh*s][2ow*s][:] = compact[b][oh][ow][:], zeros elsewhere (memset by caller)
@@ -393,9 +403,9 @@ int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* gra
 int dana_conv2d_dgrad_weight(const float* w_packed, const float* scale, float* out, int cout, int cin, int kh, int kw,
                              dana_stream_t stream) {
   DANA_CHECK_ARG(w_packed && out && cout > 0 && cin > 0 && kh > 0 && kw > 0, "dana_conv2d_dgrad_weight: bad args");
-  const long total = (long)cout * cin * kh * kw;
-  dgrad_weight_kernel<<<dana_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(w_packed, scale, out, cout, cin, kh,
-                                                                                   kw);
+  DANA_CHECK_ARG(kh * kw <= 65535, "dana_conv2d_dgrad_weight: too many taps");
+  dim3 grid(dana_ceil_div(cin, 32), dana_ceil_div(cout, 32), kh * kw);
+  dgrad_weight_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w_packed, scale, out, cout, cin, kh, kw);
   DANA_CHECK_LAUNCH("dana_conv2d_dgrad_weight");
   return DANA_OK;
 }
