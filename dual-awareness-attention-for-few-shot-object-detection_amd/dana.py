@@ -294,10 +294,14 @@ class DAnARCNN(nn.Module):
         p["rpn_head_w"] = torch.cat([rpn.RPN_cls_score.weight.detach().view(rpn.nc_score_out, -1),
                                      rpn.RPN_bbox_pred.weight.detach().view(rpn.nc_bbox_out, -1)], 0).contiguous()
         p["rpn_head_b"] = torch.cat([rpn.RPN_cls_score.bias.detach(), rpn.RPN_bbox_pred.bias.detach()], 0).contiguous()
-        anchors = T.generate_anchors(scales=np.array(cfg.ANCHOR_SCALES), ratios=np.array(cfg.ANCHOR_RATIOS))
-        p["anchors"] = torch.from_numpy(anchors).float().to(dev)
-        p["pe400"] = positional_encoding_table(400).to(dev)
-        p["pe49"] = positional_encoding_table(49).to(dev)
+        ck = ("tables", str(dev), tuple(cfg.ANCHOR_SCALES), tuple(cfg.ANCHOR_RATIOS))
+        tables = self._consts.get(ck)
+        if tables is None:  # weight-independent constants: built once per device, not per weight update
+            anchors = T.generate_anchors(scales=np.array(cfg.ANCHOR_SCALES), ratios=np.array(cfg.ANCHOR_RATIOS))
+            tables = self._consts[ck] = dict(anchors=torch.from_numpy(anchors).float().to(dev),
+                                             pe400=positional_encoding_table(400).to(dev),
+                                             pe49=positional_encoding_table(49).to(dev))
+        p.update(tables)
         self._plan = p
         return p
 
