@@ -50,6 +50,32 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_PINNED = {"ring": [], "next": 0}
+
+
+def _h2d_int32(arr, device):
+    """numpy int32 -> device tensor through a small ring of reusable PINNED staging buffers: a true asynchronous DMA on
+    the current stream. (A pageable source goes through the runtime's shared staging pool, whose recycling drains the
+    stream every few MB -- measured as periodic 10-50 ms stalls of the training iteration.)"""
+    n = int(arr.size)
+    ring = _PINNED["ring"]
+    if len(ring) < 4:
+        ring.append([torch.empty((max(n, 1 << 16),), dtype=torch.int32, pin_memory=True), None])
+    i = _PINNED["next"] % len(ring)
+    _PINNED["next"] += 1
+    buf, ev = ring[i]
+    if ev is not None:
+        ev.synchronize()  # the copy that last used this buffer (4 uploads ago) has long finished
+    if buf.numel() < n:
+        buf = ring[i][0] = torch.empty((n * 2,), dtype=torch.int32, pin_memory=True)
+    buf[:n].numpy()[...] = arr.reshape(-1)
+    out = buf[:n].to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ring[i][1] = ev
+    return out
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -237,7 +263,7 @@ def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_
         else:
             raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
         taken[i] = fg_n
-    host = torch.from_numpy(np.concatenate([picks.reshape(-1), taken])).to(dev, non_blocking=True)
+    host = _h2d_int32(np.concatenate([picks.reshape(-1), taken]), dev)
     return _proposal_target_gather(rois, gt_boxes, B, n_rois, n_gt, ibuf, host, R, means, stds, inside_w, normalize)
 
 
@@ -305,7 +331,7 @@ def anchor_target_assign(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_s
         num_examples = fg_after + min(nb, num_bg)  # the LAST image's count is used for all (:156)
     if which:
         w_np, p_np = np.concatenate(which), np.concatenate(pos)
-        host = torch.from_numpy(np.concatenate([w_np, p_np])).to(dev, non_blocking=True)
+        host = _h2d_int32(np.concatenate([w_np, p_np]), dev)
         n = int(w_np.size)
         lib().call("dana_anchor_target_disable", _p(labels), _p(ibuf[1]), _p(ibuf[2]), _p(host),
                    host.data_ptr() + 4 * n, n, total, _stream())
