@@ -529,22 +529,12 @@ class DAnARCNN(nn.Module):
             unary = ops.rowdot(s_pe, wu, bu, B * shot * L, 1024)
             ops.softmax_rows_(unary, B * shot, L)
             s_t = ops.transpose_batched(s_pe, B, K1, 1024)  # [B][1024][K1]
-            # RoI-level support side (dana.py:105-108,258,271-277): K / unary projections once per support
-            # (the reference recomputes them for every RoI)
-            sp = ops.avgpool(sup, Ns, 20, 20, 1024, 14, 1)  # [Ns][49][1024]
-            sp_pe = ops.add_pe(sp, plan["pe49"], Ns * P2, P2, 1024)
-            wk2, bk2 = self._w(self.rcnn_adapt_k_layer)
-            k2 = ops.gemm_nt(sp_pe, wk2, Ns * P2, dq, 1024, shift=bk2)
-            ops.colmean_sub_(k2, Ns, P2, dq)
-            wu2, bu2 = self._w(self.rcnn_unary_layer)
-            un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
-            ops.softmax_rows_(un2, Ns, P2)
-            for t_ in (kp, unary, s_t, sp_pe, k2, un2):
+            for t_ in (kp, unary, s_t):
                 t_.record_stream(main)
             support_done = torch.cuda.Event()
             support_done.record()
             if ctx is not None:
-                ctx.update(sup=sup, s_pe=s_pe, kp=kp, unary=unary, sp_pe=sp_pe, k2=k2, un2=un2, Ns=Ns)
+                ctx.update(sup=sup, s_pe=s_pe, kp=kp, unary=unary, Ns=Ns)
 
         # -- RPN-level dual-awareness attention, query side (dana.py:118-154) --
         wq, bq = self._w(self.rpn_adapt_q_layer)
@@ -574,6 +564,28 @@ class DAnARCNN(nn.Module):
         nh = rpn.nc_score_out + rpn.nc_bbox_out
         heads = ops.gemm_nt(x, plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])  # [B*hw][2A | 4A]
         mark("rpn conv + heads")
+        # -- RoI-level support side (dana.py:105-108,258,271-277): K / unary projections once per support (the
+        #    reference recomputes them for every RoI). Only the RoI heads need them, so they are queued behind the RPN
+        #    head: they run while the proposal layer (sort / NMS: a handful of workgroups) leaves the CUs idle,
+        #    instead of competing with the query trunk. --
+        proposals_start = torch.cuda.Event()
+        proposals_start.record()
+        with torch.cuda.stream(sup_stream):
+            sup_stream.wait_event(proposals_start)
+            sp = ops.avgpool(sup, Ns, 20, 20, 1024, 14, 1)  # [Ns][49][1024]
+            sp_pe = ops.add_pe(sp, plan["pe49"], Ns * P2, P2, 1024)
+            wk2, bk2 = self._w(self.rcnn_adapt_k_layer)
+            k2 = ops.gemm_nt(sp_pe, wk2, Ns * P2, dq, 1024, shift=bk2)
+            ops.colmean_sub_(k2, Ns, P2, dq)
+            wu2, bu2 = self._w(self.rcnn_unary_layer)
+            un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
+            ops.softmax_rows_(un2, Ns, P2)
+            for t_ in (sp_pe, k2, un2):
+                t_.record_stream(main)
+            support_roi_done = torch.cuda.Event()
+            support_roi_done.record()
+            if ctx is not None:
+                ctx.update(sp_pe=sp_pe, k2=k2, un2=un2)
         A = plan["anchors"].size(0)
         key = "TRAIN" if training else "TEST"
         rois = ops.proposal_layer(heads, (hw * nh, 1, nh), False, heads.view(-1)[rpn.nc_score_out:], (hw * nh, 1, nh),
@@ -662,6 +674,7 @@ class DAnARCNN(nn.Module):
         # -- RoI-level CISA (dana.py:248-292). Query side once: Q projection and the q half of
         #    rcnn_transform_layer (cat([q, attended]) @ Wt^T = q @ Wt[:, :1024]^T + attended @ Wt[:, 1024:]^T,
         #    so the [n*49][2048] concat of dana.py:284 is never materialised). --
+        main.wait_event(support_roi_done)
         wq2, bq2 = self._w(self.rcnn_adapt_q_layer)
         q2 = ops.gemm_nt(q_pe, wq2, n_roi * P2, dq, 1024, shift=bq2)
         ops.colmean_sub_(q2, n_roi, P2, dq)
