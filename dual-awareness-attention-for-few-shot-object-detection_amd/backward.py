@@ -255,21 +255,33 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
         ops.scale_by_device_scalar_(d_score_neg, g_dev[2:])
         ops.scale_by_device_scalar_(d_bbox, g_dev[3:])
 
-    # -- box branch: RCNN_bbox_pred <- mean <- layer4 (dana.py:246,387-389) --
-    wb = model.RCNN_bbox_pred.weight.detach()
-    _acc(model.RCNN_bbox_pred.weight, ops.gemm_small(d_bbox, (1, 4), ctx["fc7"], (2048, 1), 4, 2048, n_roi, alpha=g4))
-    _acc(model.RCNN_bbox_pred.bias, ops.colsum(d_bbox, n_roi, 4, alpha=g4))
-    d_fc7 = ops.gemm_small(d_bbox, (4, 1), wb, (2048, 1), n_roi, 2048, 4, alpha=g4)
-    l4 = ctx["l4_saved"]
-    npos = l4[-1]["h1"] * l4[-1]["w1"]
-    g = ops.broadcast_rows(d_fc7, n_roi, npos, 2048, alpha=1.0 / npos)
-    for i, sv in enumerate(reversed(l4)):  # the first block's input is the RoIAlign output: no ReLU in front of it
-        g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"],
-                                mask_dx=i < len(l4) - 1, g_masked=i > 0)
-    d_pooled = g  # [n_roi*49][1024]
-    grads.finish_all(model, "RCNN_top")
+    # -- box branch: RCNN_bbox_pred <- mean <- layer4 (dana.py:246,387-389). Independent of the attention heads until
+    #    the two gradients of the pooled features meet, so it runs on the forward's layer4 stream: the heads' backward
+    #    (many small launches) fills the CUs its big launches leave idle in their tails. --
+    main = torch.cuda.current_stream()
+    l4_stream = main if getattr(model, "_single_stream", False) else model._stream("layer4", dev)
+    seeds_ready = torch.cuda.Event()
+    seeds_ready.record()
     stages = grad_stages(model)
-    _ready(model, stages[0][1])
+    with torch.cuda.stream(l4_stream):
+        l4_stream.wait_event(seeds_ready)
+        wb = model.RCNN_bbox_pred.weight.detach()
+        _acc(model.RCNN_bbox_pred.weight,
+             ops.gemm_small(d_bbox, (1, 4), ctx["fc7"], (2048, 1), 4, 2048, n_roi, alpha=g4))
+        _acc(model.RCNN_bbox_pred.bias, ops.colsum(d_bbox, n_roi, 4, alpha=g4))
+        d_fc7 = ops.gemm_small(d_bbox, (4, 1), wb, (2048, 1), n_roi, 2048, 4, alpha=g4)
+        l4 = ctx["l4_saved"]
+        npos = l4[-1]["h1"] * l4[-1]["w1"]
+        g = ops.broadcast_rows(d_fc7, n_roi, npos, 2048, alpha=1.0 / npos)
+        for i, sv in enumerate(reversed(l4)):  # the first block's input is the RoIAlign output: no ReLU in front of it
+            g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"],
+                                    mask_dx=i < len(l4) - 1, g_masked=i > 0)
+        d_pooled = g  # [n_roi*49][1024]
+        d_pooled.record_stream(main)
+        grads.finish_all(model, "RCNN_top")
+        _ready(model, stages[0][1])
+        box_done = torch.cuda.Event()
+        box_done.record()
 
     # -- RoI-level attention heads (dana.py:248-292), positive then negative supports --
     q_pe, q2, sp_pe, k2, un2 = ctx["q_pe"], ctx["q2"], ctx["sp_pe"], ctx["k2"], ctx["un2"]
@@ -317,6 +329,7 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     ops.axpy_rows_(d_wt, dwt_q, rd, 1024, ld_y=2048)
     _acc(model.rcnn_transform_layer.weight, d_wt)
     _acc(model.rcnn_transform_layer.bias, dbt)
+    main.wait_event(box_done)
     ops.axpy_rows_(d_pooled, d_q_pe, n_roi * P2, 1024)
     d_bf = ops.roi_align_backward(d_pooled.view(n_roi, 7, 7, 1024), ctx["rois"].view(-1, 5), 1.0 / 16.0, 7, 7, B, 1024,
                                   fh, fw, 0, layout=ops.NHWC)  # [B][fh][fw][1024]
