@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--shot", type=int, default=3)
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
+    ap.add_argument("--support-size", type=int, default=320,
+                    help="support image side. 320 = the only size the reference can run (it hard-codes the 20x20 map); "
+                         "224 (BASELINE.json's wording) runs the opt-in generalised pooling: NO oracle, no parity claim")
     ap.add_argument("--ba", action="store_true", help="full BA+CISA (configs[2]); default CISA only (configs[1])")
     ap.add_argument("--mode", default="train", choices=["train", "eval", "step"],
                     help="train: train-mode forward (variant F, the headline); eval: inference forward; step: the full "
@@ -120,9 +123,10 @@ def main():
     model.train() if training else model.eval()
     model._single_stream = bool(args.single_stream)
     model.device_rng = bool(args.device_rng)
+    model.generalised_support = args.support_size != 320
     # every rank gets its own episodes (weak scaling), already resident in HBM before the timed region
     inputs = [t.to(dev) for t in S.episode_inputs(args.batch, way, args.shot, args.height, args.width,
-                                                  seed=1996 + rank)]
+                                                  seed=1996 + rank, support_size=args.support_size)]
 
     trainer = [None]
 
@@ -187,10 +191,12 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (seeded N(0,64^2) query/support pixels, 3 gt boxes/image, random-init weights)",
-        "config": {"workload": "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d 320x320 "
-                               "supports/episode, %s, %s" % (
+        "config": {"workload": "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d %dx%d "
+                               "supports/episode%s, %s, %s" % (
                                    2 if args.ba else 1, args.way, args.shot, args.batch, args.height, args.width,
-                                   way * args.shot, "BA+CISA" if args.ba else "CISA only", what),
+                                   way * args.shot, args.support_size, args.support_size,
+                                   "" if args.support_size == 320 else " (generalised support pooling: NOT a reference "
+                                   "configuration, no oracle)", "BA+CISA" if args.ba else "CISA only", what),
                    "global_batch": world * args.batch, "parallelism": "episodes sharded, %d rank(s)" % world,
                    "target_sampling": "device Philox RNG" if args.device_rng else "host np.random (reference stream)"},
     }
@@ -279,8 +285,8 @@ def main():
             with open(args.dump_launches, "w") as fh:
                 for (i, tag), (f, t) in sorted(per.items()):
                     fh.write("%3d %-40s %9.2f GF %9.1f us %7.2f TF/s\n" % (i, tag, f / 1e9, t * 1e3, f / t / 1e9))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, sd)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.support_size == 320:
+        result["cpu_baseline"] = cpu_baseline(args, sd)  # (the oracle, like the reference, only runs 320x320 supports)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

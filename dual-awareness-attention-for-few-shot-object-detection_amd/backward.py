@@ -233,7 +233,8 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     B, shot, way, R, Ns = ctx["B"], ctx["shot"], ctx["way"], ctx["R"], ctx["Ns"]
     fh, fw = ctx["fh"], ctx["fw"]
     hw = fh * fw
-    P2, L = 49, 400
+    P2 = 49
+    L = ctx["s_pe"].size(1) // shot  # positions of a support map (400 for the reference's 320x320 supports)
     n_roi = B * R
     d, dq = model.rpn_reduce_dim, model.rcnn_reduce_dim
     g_dev = None
@@ -344,7 +345,8 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     wu2 = model.rcnn_unary_layer.weight.detach()
     _acc(model.rcnn_unary_layer.weight, ops.rowdot_backward(sp_pe, d_un2, wu2, Ns * P2, 1024, grad_x=d_sp_pe))
     _acc(model.rcnn_unary_layer.bias, ops.colsum(d_un2, Ns * P2, 1))
-    d_sup = ops.avgpool_backward(d_sp_pe, Ns, 20, 20, 1024, 14, 1)  # [Ns][400][1024]
+    (sh_, sw_), pool = ctx["sup_map"], ctx["sup_pool"]
+    d_sup = ops.avgpool_backward(d_sp_pe, Ns, sh_, sw_, 1024, pool[0], pool[1])  # [Ns][L][1024]
     _ready(model, stages[1][1])
 
     # -- RPN: losses -> heads -> 3x3 conv (rpn.py:58-115) --

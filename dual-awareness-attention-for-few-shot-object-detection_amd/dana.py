@@ -183,6 +183,7 @@ class DAnARCNN(nn.Module):
         self.output_score_layer = FFN(64 * 49, dim_in)
         self._plan = None
         self._consts = {}
+        self.generalised_support = False  # True: accept support maps other than the reference's 20x20 (no oracle)
         self.device_rng = False   # True: the target layers sample with the device Philox RNG (no host sync, not the
         self.rng_seed = 1996      #       reference's np.random stream); seed as train.py:33
         self._rng_calls = 0
@@ -304,6 +305,15 @@ class DAnARCNN(nn.Module):
         p.update(tables)
         self._plan = p
         return p
+
+    def _pe_table(self, length, dev):
+        if length == 400:
+            return self._plan["pe400"]
+        key = ("pe", length, str(dev))
+        t = self._consts.get(key)
+        if t is None:
+            t = self._consts[key] = positional_encoding_table(length).to(dev)
+        return t
 
     def _stream(self, name, dev):
         if getattr(self, "_single_stream", False):  # bench.py's per-launch timing pass: no overlap
@@ -471,7 +481,9 @@ class DAnARCNN(nn.Module):
         Ns = sup_ims.size(0)
         if Ns != B * way * shot:
             raise RuntimeError("support_ims must hold batch*way*shot = %d images, got %d" % (B * way * shot, Ns))
-        L = 400
+        # positions of a support map: 20 x 20 = 400 for the reference's 320 x 320 supports (dana.py:105 hard-codes it)
+        sh0, sw0 = self._feat_size(sup_ims.size(2), sup_ims.size(3))
+        L = sh0 * sw0
         d = self.rpn_reduce_dim
         P = cfg.POOLING_SIZE
         P2 = P * P
@@ -505,8 +517,13 @@ class DAnARCNN(nn.Module):
                     main.wait_stream(st_i)
         hw = fh * fw
         if (sh_, sw_) != (20, 20):
-            raise RuntimeError("support images must be 320x320 (20x20 stride-16 map), as the reference "
-                               "hard-codes (dana.py:105); got a %dx%d map" % (sh_, sw_))
+            # NOT a reference configuration (no oracle, no parity claim): the reference cannot run it at all. Opt-in
+            # generalisation for BASELINE.json's "224x224 supports": all L = sh*sw positions are attention keys and the
+            # 14/1 average pool becomes the (sh/7 x sw/7)-window pool that also ends in a 7x7 map.
+            if not self.generalised_support or sh_ % 7 or sw_ % 7:
+                raise RuntimeError("support images must be 320x320 (20x20 stride-16 map), as the reference hard-codes "
+                                   "(dana.py:105); got a %dx%d map%s" % (sh_, sw_, "" if self.generalised_support else
+                                   " (set model.generalised_support = True for maps whose sides are multiples of 7)"))
         mark("trunk (query + support)")
         with torch.cuda.stream(sup_stream):
             sup.record_stream(sup_stream)
@@ -514,7 +531,7 @@ class DAnARCNN(nn.Module):
             s_pe = torch.empty((B, shot * L, 1024), dtype=torch.float32, device=dev)
             sup3 = sup.view(Ns, L * 1024)
             for b in range(B):  # positives = the first `shot` supports of each image (dana.py:103)
-                ops.add_pe(sup3[b * way * shot], plan["pe400"], shot * L, L, 1024, out=s_pe[b])
+                ops.add_pe(sup3[b * way * shot], self._pe_table(L, dev), shot * L, L, 1024, out=s_pe[b])
             if self.semantic_enhance:  # BA block (dana.py:133-137)
                 wc, bc = self._w(self.rpn_channel_k_layer)
                 wgt = ops.rowdot(s_pe, wc, bc, B * shot * L, 1024)
@@ -572,7 +589,13 @@ class DAnARCNN(nn.Module):
         proposals_start.record()
         with torch.cuda.stream(sup_stream):
             sup_stream.wait_event(proposals_start)
-            sp = ops.avgpool(sup, Ns, 20, 20, 1024, 14, 1)  # [Ns][49][1024]
+            if (sh_, sw_) == (20, 20):
+                pool = (14, 1)  # nn.AvgPool2d(14, stride=1) (dana.py:42): 20x20 -> 7x7
+            else:
+                if sh_ != sw_:
+                    raise RuntimeError("generalised supports must be square")
+                pool = (sh_ // 7, sh_ // 7)
+            sp = ops.avgpool(sup, Ns, sh_, sw_, 1024, pool[0], pool[1])  # [Ns][49][1024]
             sp_pe = ops.add_pe(sp, plan["pe49"], Ns * P2, P2, 1024)
             wk2, bk2 = self._w(self.rcnn_adapt_k_layer)
             k2 = ops.gemm_nt(sp_pe, wk2, Ns * P2, dq, 1024, shift=bk2)
@@ -585,7 +608,7 @@ class DAnARCNN(nn.Module):
             support_roi_done = torch.cuda.Event()
             support_roi_done.record()
             if ctx is not None:
-                ctx.update(sp_pe=sp_pe, k2=k2, un2=un2)
+                ctx.update(sp_pe=sp_pe, k2=k2, un2=un2, sup_map=(sh_, sw_), sup_pool=pool)
         A = plan["anchors"].size(0)
         key = "TRAIN" if training else "TEST"
         rois = ops.proposal_layer(heads, (hw * nh, 1, nh), False, heads.view(-1)[rpn.nc_score_out:], (hw * nh, 1, nh),

@@ -298,3 +298,28 @@ def test_frcnn_roi_pool_mode_vs_oracle(dev):
     assert matched.mean() >= 0.99
     assert np.abs(out[1].cpu().numpy() - ref[1].numpy()).reshape(-1, 2)[matched].max() <= 1e-4
     assert np.abs(out[2].cpu().numpy() - ref[2].numpy()).reshape(-1, 4)[matched].max() <= 1e-4
+
+
+def test_generalised_support_size_is_opt_in_and_runs(dev):
+    """224x224 supports (BASELINE.json's wording): the reference cannot run them (dana.py:105 hard-codes the 20x20 map);
+    opt-in generalisation, no oracle -- only checked to be refused by default, to run, to be finite and trainable"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    from dana_amd.trainer import Trainer
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=2, shot=2, classes=["fg", "bg"])
+    m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=3, profile="test"))
+    m.to(dev).train()
+    inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=5, support_size=224)]
+    with pytest.raises(RuntimeError, match="320x320"):
+        with torch.no_grad():
+            m(*inputs)
+    m.generalised_support = True
+    np.random.seed(1)
+    with torch.no_grad():
+        out = m(*inputs)
+    assert out[0].shape == (1, 128, 5) and all(bool(torch.isfinite(x)) for x in out[3:7])
+    tr = Trainer(m, 1e-3)
+    np.random.seed(1)
+    tr.step(*inputs)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in m.parameters())
