@@ -171,6 +171,34 @@ class Trainer:
         self.optimizer_step()
         return out
 
+    # ---- checkpoint / resume (train.py:92-101,181-189 save and restore model + optimizer state) -----------------
+    def _views(self, flat_of):
+        """name -> logical-shape view of a flat buffer (conv weights are stored [O][KH][KW][I])"""
+        out = {}
+        params = dict(self.model.named_parameters())
+        for fb, flat in flat_of:
+            for n in fb.names:
+                o, k = fb.offsets[n]
+                p = params[n]
+                if p.dim() == 4:
+                    O, I, KH, KW = p.shape
+                    out[n] = flat[o:o + k].view(O, KH, KW, I).permute(0, 3, 1, 2)
+                else:
+                    out[n] = flat[o:o + k].view(p.shape)
+        return out
+
+    def state_dict(self):
+        """optimizer state in the parameters' logical (OIHW) shapes, like torch.optim.SGD's momentum_buffer entries"""
+        mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
+        return {"lr": self.lr, "momentum": self.momentum, "steps": self.steps,
+                "momentum_buffer": {n: v.detach().clone().contiguous() for n, v in mom.items()}}
+
+    def load_state_dict(self, state):
+        self.lr, self.momentum, self.steps = float(state["lr"]), float(state["momentum"]), int(state["steps"])
+        mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
+        for n, v in mom.items():
+            v.copy_(state["momentum_buffer"][n])
+
     def adjust_learning_rate(self, decay=0.1):
         """net_utils.adjust_learning_rate (train.py:118-120)"""
         self.lr *= decay

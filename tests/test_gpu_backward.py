@@ -210,3 +210,41 @@ def test_trainer_step_matches_reference_loop_with_torch_sgd(dev):
     moved = [k for k in pa if pa[k].requires_grad and not torch.equal(pa[k].detach().cpu(), sd0[k])]
     # the 7 biases in front of a mean subtraction / softmax have zero gradient (and no weight decay): they stay
     assert len(moved) == sum(p.requires_grad for p in pa.values()) - 7
+
+
+def test_checkpoint_resume_reproduces_the_next_iteration(dev):
+    """train.py:92-101,181-189: save model + optimizer state after one iteration, restore into a FRESH model / trainer
+    (reference OIHW layout in, kernel layout inside), and the next iteration gives the same parameters"""
+    import io
+    import dana_amd
+    from dana_amd import synthetic as S
+    from dana_amd.trainer import Trainer
+
+    def build(seed):
+        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=2, shot=2, classes=["fg", "bg"])
+        m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=seed, profile="test"))
+        return m.to(dev).train()
+
+    inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=6)]
+    ma = build(5)
+    ta = Trainer(ma, 0.01)
+    np.random.seed(1)
+    ta.step(*inputs)
+    buf = io.BytesIO()
+    torch.save({"model": ma.state_dict(), "optimizer": ta.state_dict()}, buf)  # train.py:181-189
+    np.random.seed(2)
+    ta.step(*inputs)
+    buf.seek(0)
+    ck = torch.load(buf, map_location=dev)
+    mb = build(99)  # different initial weights: everything must come from the checkpoint
+    mb.load_state_dict(ck["model"])
+    tb = Trainer(mb, 0.5)
+    tb.load_state_dict(ck["optimizer"])
+    assert tb.lr == 0.01 and tb.steps == 1
+    np.random.seed(2)
+    tb.step(*inputs)
+    torch.cuda.synchronize()
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    for k in pa:  # (RoIAlign backward accumulates with float atomics, like the reference's: equal up to summation order)
+        d = (pa[k].detach() - pb[k].detach()).abs().max().item()
+        assert d <= 1e-6 + 1e-5 * pa[k].detach().abs().max().item(), (k, d)
