@@ -61,19 +61,21 @@ class _Lib:
                 "or `make -C %s/csrc`. There is no CPU fallback." % (LIB_PATH, _HERE))
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
+        self.fn = {}  # name -> bound foreign function (one dict lookup per launch on the hot path)
         for name, (ret, args) in self.protos.items():
             fn = getattr(self.cdll, name)
             fn.argtypes = [_ctype(t) for t, _ in args]
             fn.restype = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret]
+            self.fn[name] = fn
 
     def call(self, name, *args):
         """Call an `int dana_*` entry point; raise DanaError with dana_last_error() on failure."""
-        rc = getattr(self.cdll, name)(*args)
+        rc = self.fn[name](*args)
         if rc != 0:
             raise DanaError("%s failed (%d): %s" % (name, rc, self.cdll.dana_last_error().decode()))
 
     def query(self, name, *args):
-        return getattr(self.cdll, name)(*args)
+        return self.fn[name](*args)
 
 
 _lib = None

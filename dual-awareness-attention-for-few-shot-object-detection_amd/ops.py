@@ -25,11 +25,12 @@ def _prof_begin():
 
 
 def _prof_end(e0, tag, flops, nbytes=0.0):
-    """nbytes: algorithmic HBM bytes of the launch (every operand and result touched exactly once)"""
+    """tag: (format, args) -- formatted only when profiling; nbytes: algorithmic HBM bytes of the launch (every operand
+    and result touched exactly once)"""
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((tag, flops, e0, e1, nbytes))
+        PROFILE.append((tag[0] % tag[1], flops, e0, e1, nbytes))
 
 
 def _stream():
@@ -402,7 +403,7 @@ def conv2d_nhwc(x, batch, in_h, in_w, cin, weight, cout, kh, kw, stride, pad, sc
     lib().call("dana_conv2d_nhwc", _p(x), _p(weight), _p(out), _p(scale), _p(shift), _p(residual), batch, in_h,
                in_w, cin, cout, kh, kw, stride, pad, in_stride, out_stride, res_stride, flags, _stream())
     # algorithmic flops: the stem counts its 3 real channels x 49 real taps, not the padded K=224
-    _prof_end(e0, "conv%dx%d M=%d N=%d K=%d s%d" % (kh, kw, batch * oh * ow, cout, kh * kw * cin, stride),
+    _prof_end(e0, ("conv%dx%d M=%d N=%d K=%d s%d", (kh, kw, batch * oh * ow, cout, kh * kw * cin, stride)),
               2.0 * batch * oh * ow * cout * kh * kw * (3 if stem else cin),
               4.0 * (batch * in_h * in_w * cin // (stride * stride if kh == 1 else 1) + cout * kh * kw * cin
                      + batch * oh * ow * cout * (2 if residual is not None else 1)))
@@ -428,7 +429,7 @@ def conv2d_nhwc_dual(x, n0, h0, w0, n1, h1, w1, cin, weight, cout, kh, kw, strid
     lib().call("dana_conv2d_nhwc_dual", _p(x), _p(weight), _p(out0), _p(out1), _p(scale), _p(shift), _p(res0),
                _p(res1), n0, h0, w0, n1, h1, w1, cin, cout, kh, kw, stride, pad, in_stride, out0_stride, out1_stride,
                res0_stride, res1_stride, flags, _stream())
-    _prof_end(e0, "conv%dx%d M=%d N=%d K=%d s%d" % (kh, kw, m0 + m1, cout, kh * kw * cin, stride),
+    _prof_end(e0, ("conv%dx%d M=%d N=%d K=%d s%d", (kh, kw, m0 + m1, cout, kh * kw * cin, stride)),
               2.0 * (m0 + m1) * cout * kh * kw * (3 if stem else cin))
     return out0, out1, (oh0, ow0), (oh1, ow1)
 
@@ -452,7 +453,7 @@ def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=
     e0 = _prof_begin()
     lib().call("dana_conv3x3_winograd_nhwc_masked", _p(x), _p(u), _p(out), _p(scale), _p(shift), _p(mask), batch, h, w,
                cin, cout, in_stride, out_stride, mask_stride, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
-    _prof_end(e0, "wino3x3 M=%d N=%d K=%d s1" % (batch * h * w, cout, 9 * cin), 2.0 * batch * h * w * cout * 9 * cin,
+    _prof_end(e0, ("wino3x3 M=%d N=%d K=%d s1", (batch * h * w, cout, 9 * cin)), 2.0 * batch * h * w * cout * 9 * cin,
               # bytes of the batched GEMM launch itself: V[16][tiles][cin], U[16][cout][cin], M[16][tiles][cout]
               64.0 * (batch * ((h + 1) // 2) * ((w + 1) // 2) * (cin + cout) + cout * cin))
     return out, h, w
@@ -472,7 +473,7 @@ def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None
     e0 = _prof_begin()
     lib().call("dana_gemm_nt", _p(a), _p(b), _p(out), _p(scale), _p(shift), _p(residual), m, n, k, lda, ldb, ldc,
                ldr, batch, batch_a, batch_b, batch_c, float(alpha), EPI_RELU if relu else 0, _stream())
-    _prof_end(e0, "gemm M=%d N=%d K=%d b%d" % (m, n, k, batch), 2.0 * batch * m * n * (k_true or k),
+    _prof_end(e0, ("gemm M=%d N=%d K=%d b%d", (m, n, k, batch)), 2.0 * batch * m * n * (k_true or k),
               4.0 * batch * (m * k + n * k + m * n * (2 if residual is not None else 1)))
     return out
 
@@ -646,7 +647,7 @@ def conv2d_wgrad(grad_out, x, batch, in_h, in_w, cin, cout, kh, kw, stride, pad,
     lib().call("dana_conv2d_wgrad_nhwc", _p(grad_out), _p(x), _p(out), batch, in_h, in_w, cin, cout, kh, kw, stride,
                pad, in_stride, grad_stride, _p(row_scale), int(accumulate), _p(ws), ws.numel(), _stream())
     m = batch * ((in_h + 2 * pad - kh) // stride + 1) * ((in_w + 2 * pad - kw) // stride + 1)
-    _prof_end(e0, "wgrad%dx%d M=%d N=%d K=%d s%d" % (kh, kw, m, cout, kh * kw * cin, stride),
+    _prof_end(e0, ("wgrad%dx%d M=%d N=%d K=%d s%d", (kh, kw, m, cout, kh * kw * cin, stride)),
               2.0 * m * cout * kh * kw * cin)
     return out
 
@@ -679,7 +680,7 @@ def conv2d_dgrad(grad_out, w_packed, batch, in_h, in_w, cin, cout, kh, kw, strid
         e0 = _prof_begin()
         lib().call("dana_conv2d_nhwc_masked", _p(grad_out), _p(wd), _p(gx), None, None, _p(residual), _p(mask), batch, oh,
                    ow, cout, cin, kh, kw, 1, kh - 1 - pad, 0, cin, 0, mask_stride, 0, _stream())
-        _prof_end(e0, "dgrad%dx%d M=%d N=%d K=%d" % (kh, kw, batch * in_h * in_w, cin, kh * kw * cout),
+        _prof_end(e0, ("dgrad%dx%d M=%d N=%d K=%d", (kh, kw, batch * in_h * in_w, cin, kh * kw * cout)),
                   2.0 * batch * in_h * in_w * cin * kh * kw * cout)
         return gx
     if kh != 1 or kw != 1 or pad != 0:
