@@ -44,8 +44,9 @@ def parse():
                     help="support image side. 320 = the only size the reference can run (it hard-codes the 20x20 map); "
                          "224 (BASELINE.json's wording) runs the opt-in generalised pooling: NO oracle, no parity claim")
     ap.add_argument("--ba", action="store_true", help="full BA+CISA (configs[2]); default CISA only (configs[1])")
-    ap.add_argument("--mode", default="train", choices=["train", "eval", "step"],
-                    help="train: train-mode forward (variant F, the headline); eval: inference forward; step: the full "
+    ap.add_argument("--mode", default="train", choices=["train", "eval", "infer", "step"],
+                    help="train: train-mode forward (variant F, the headline); eval: inference forward; infer: inference "
+                         "forward + per-image detection post-processing (the loop of inference.py:96-142); step: the full "
                          "training iteration fwd+bwd+gradient all-reduce+SGD (variant S) as the headline")
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary variant-S measurement")
     ap.add_argument("--device-rng", action="store_true",
@@ -142,7 +143,16 @@ def main():
         with torch.no_grad():
             return model(*inputs)
 
-    step = train_step if args.mode == "step" else fwd_step
+    def infer_step():
+        # inference.py:96-142: forward, then per image de-normalise / decode / clip / threshold / sort / NMS (one C call)
+        from dana_amd.postprocess import detections
+        with torch.no_grad():
+            rois, cls_prob, bbox_pred = model(*inputs)[:3]
+            return [detections(rois[i:i + 1], cls_prob[i * rois.size(1):(i + 1) * rois.size(1)],
+                               bbox_pred[i * rois.size(1):(i + 1) * rois.size(1)], inputs[1][i:i + 1])
+                    for i in range(rois.size(0))]
+
+    step = {"step": train_step, "infer": infer_step}.get(args.mode, fwd_step)
     np.random.seed(1996 + rank)
     for _ in range(args.warmup):
         step()
@@ -174,7 +184,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    what = "training step fwd+bwd+allreduce+SGD" if args.mode == "step" else "%s-mode forward" % args.mode
+    what = {"step": "training step fwd+bwd+allreduce+SGD",
+            "infer": "eval-mode forward + detection post-processing per image"}.get(args.mode, "%s-mode forward" % args.mode)
     result = {
         "metric": "query-images/sec (res50, way=%d, shot=%d, bs=%d per GPU, %s)" % (
             args.way, args.shot, args.batch, what),
