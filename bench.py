@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--shot", type=int, default=3)
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
+    ap.add_argument("--model", default="DAnA", choices=["DAnA", "frcnn"],
+                    help="DAnA: the hot path (default); frcnn: the sibling plain Faster R-CNN (utils.py:109-110, row N4) "
+                         "on the same operators -- forward modes only")
     ap.add_argument("--support-size", type=int, default=320,
                     help="support image side. 320 = the only size the reference can run (it hard-codes the 20x20 map); "
                          "224 (BASELINE.json's wording) runs the opt-in generalised pooling: NO oracle, no parity claim")
@@ -116,7 +119,9 @@ def main():
     from dana_amd import ops, synthetic as S
     training = args.mode in ("train", "step")
     way = args.way if training else 1
-    model = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=args.ba, way=args.way, shot=args.shot,
+    if args.model != "DAnA" and args.mode not in ("train", "eval"):
+        raise SystemExit("--model %s supports --mode train / eval only" % args.model)
+    model = dana_amd.get_model(args.model, pretrained=False, use_BA_block=args.ba, way=args.way, shot=args.shot,
                                classes=["fg", "bg"])
     sd = S.fill_state_dict(model.state_dict(), seed=11, profile="test")  # random init, O(1) activations
     model.load_state_dict(sd)
@@ -138,6 +143,10 @@ def main():
             from dana_amd.trainer import Trainer
             trainer[0] = Trainer(model, lr=1e-5)
         return trainer[0].step(*inputs)
+
+    if args.model == "frcnn":
+        inputs = inputs[:4]  # faster_rcnn.py:35: (im_data, im_info, gt_boxes, num_boxes)
+        args.no_train_step = True
 
     def fwd_step():
         with torch.no_grad():
@@ -202,7 +211,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (seeded N(0,64^2) query/support pixels, 3 gt boxes/image, random-init weights)",
-        "config": {"workload": "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d %dx%d "
+        "config": {"model": args.model,
+                   "workload": "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d %dx%d "
                                "supports/episode%s, %s, %s" % (
                                    2 if args.ba else 1, args.way, args.shot, args.batch, args.height, args.width,
                                    way * args.shot, args.support_size, args.support_size,
@@ -296,7 +306,7 @@ def main():
             with open(args.dump_launches, "w") as fh:
                 for (i, tag), (f, t) in sorted(per.items()):
                     fh.write("%3d %-40s %9.2f GF %9.1f us %7.2f TF/s\n" % (i, tag, f / 1e9, t * 1e3, f / t / 1e9))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.support_size == 320:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.support_size == 320 and args.model == "DAnA":
         result["cpu_baseline"] = cpu_baseline(args, sd)  # (the oracle, like the reference, only runs 320x320 supports)
     if rank == 0:
         print(json.dumps(result), flush=True)
