@@ -101,7 +101,7 @@ def _dgrad_weights(c):
         c["wd"] = ops.conv2d_dgrad_weight(c["w"], c["cout"], c["cin"], c["k"], c["k"], c.get("scale"))
         c["ud"] = None
         if c.get("u") is not None and c["cout"] % 64 == 0:
-            c["ud"] = ops.winograd_filter_transform(c["wd"], c["cin"], c["cout"])
+            c["ud"] = ops.winograd_filter_transform(c["wd"], c["cin"], c["cout"], 2 if c["u"].size(0) == 16 else 4)
     return c["wd"], c["ud"]
 
 

@@ -155,7 +155,11 @@ class DAnARCNN(nn.Module):
         self.pool_feat_dim = 1024
         self.rcnn_dim = 64
         self.use_winograd = True   # F(2x2,3x3) for the stride-1 3x3 convs with >= winograd_min_cin channels
-        self.winograd_min_cin = int(__import__('os').environ.get('DANA_WINO_MIN_CIN', 256))  # tuning knob
+        self.winograd_tile = int(__import__('os').environ.get('DANA_WINO_TILE', 4))  # F(4x4,3x3) (or 2: F(2x2,3x3))
+        # measured break-even: F(4x4) pays from 128 input channels (layer2), F(2x2) from 256 (its transformed tensors
+        # are 4x the input instead of 2.25x)
+        self.winograd_min_cin = int(__import__('os').environ.get('DANA_WINO_MIN_CIN',
+                                                                 128 if self.winograd_tile == 4 else 256))
         self.query_streams = 1
         self.query_sequential = False  # chunks of the query batch one after the other on the main stream
         # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
@@ -245,13 +249,14 @@ class DAnARCNN(nn.Module):
         if cached is None or cached[0] != dev:  # module.to(device) swaps buffers: re-collect the tensor list
             cached = (dev, list(self.state_dict(keep_vars=True).values()))
             self._consts["sig_tensors"] = cached
-        return (dev, self.use_winograd, self.winograd_min_cin, self._epoch) + tuple(t._version for t in cached[1])
+        return (dev, self.use_winograd, self.winograd_min_cin, self.winograd_tile, self._epoch) + tuple(
+            t._version for t in cached[1])
 
     def _conv_bn(self, conv, bn, stem=False):
         """packed weight + folded frozen BN (+ Winograd filter) of one conv, re-derived only when ITS tensors changed:
         a training step touches the trainable conv weights only (BN and conv1/layer1 are frozen, dana.py:350-385)"""
         wsig = (conv.weight.data_ptr(), conv.weight._version, self._epoch if conv.weight.requires_grad else -1,
-                self.use_winograd, self.winograd_min_cin)
+                self.use_winograd, self.winograd_min_cin, self.winograd_tile)
         bsig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
         e = self._conv_cache.get(id(conv))
         if e is not None and e["wsig"] == wsig and e["bsig"] == bsig:
@@ -265,7 +270,7 @@ class DAnARCNN(nn.Module):
                  k=conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0], u=None, wsig=wsig, bsig=bsig)
         if (self.use_winograd and d["k"] == 3 and d["stride"] == 1 and d["pad"] == 1 and not stem
                 and d["cin"] >= self.winograd_min_cin):
-            d["u"] = ops.winograd_filter_transform(w, d["cout"], d["cin"])
+            d["u"] = ops.winograd_filter_transform(w, d["cout"], d["cin"], self.winograd_tile)
         self._conv_cache[id(conv)] = d
         return d
 
@@ -289,7 +294,7 @@ class DAnARCNN(nn.Module):
         p["layer4"] = [self._block_plan(b) for b in self.RCNN_top[0]]
         rpn = self.RCNN_rpn
         p["rpn_conv_w"] = ops.pack_conv_weight(rpn.RPN_Conv.weight)
-        p["rpn_conv_u"] = (ops.winograd_filter_transform(p["rpn_conv_w"], 512, rpn.din)
+        p["rpn_conv_u"] = (ops.winograd_filter_transform(p["rpn_conv_w"], 512, rpn.din, self.winograd_tile)
                            if self.use_winograd and rpn.din >= self.winograd_min_cin else None)
         p["rpn_conv_b"] = rpn.RPN_Conv.bias.detach().contiguous()
         p["rpn_head_w"] = torch.cat([rpn.RPN_cls_score.weight.detach().view(rpn.nc_score_out, -1),

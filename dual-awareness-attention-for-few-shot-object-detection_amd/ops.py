@@ -434,28 +434,33 @@ def conv2d_nhwc_dual(x, n0, h0, w0, n1, h1, w1, cin, weight, cout, kh, kw, strid
     return out0, out1, (oh0, ow0), (oh1, ow1)
 
 
-def winograd_filter_transform(w_packed, cout, cin):
+def winograd_filter_transform(w_packed, cout, cin, tile=2):
+    """U of Winograd F(tile x tile, 3x3): [16][cout][cin] (tile 2) or [36][cout][cin] (tile 4)"""
     _chk(w_packed, "w_packed")
-    u = torch.empty((16, cout, cin), dtype=torch.float32, device=w_packed.device)
-    lib().call("dana_winograd_filter_transform", _p(w_packed), _p(u), cout, cin, _stream())
+    planes = (tile + 2) * (tile + 2)
+    u = torch.empty((planes, cout, cin), dtype=torch.float32, device=w_packed.device)
+    lib().call("dana_winograd_filter_transform" if tile == 2 else "dana_winograd4_filter_transform", _p(w_packed), _p(u),
+               cout, cin, _stream())
     return u
 
 
 def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=False, in_stride=0, out=None,
                      out_stride=0, mask=None, mask_stride=0):
-    """stride-1 pad-1 3x3 conv through Winograd F(2x2,3x3) (u from winograd_filter_transform)."""
+    """stride-1 pad-1 3x3 conv through Winograd F(2x2,3x3) or F(4x4,3x3), chosen by u (winograd_filter_transform)."""
     _chk(x, "x")
     _chk(u, "u")
     if out is None:
         out = torch.empty((batch * h * w, cout), dtype=torch.float32, device=x.device)
         out_stride = cout
-    ws = _ws(lib().query("dana_conv3x3_winograd_workspace_bytes", batch, h, w, cin, cout), x.device)
+    m = 2 if u.size(0) == 16 else 4
+    sfx = "" if m == 2 else "4"
+    ws = _ws(lib().query("dana_conv3x3_winograd%s_workspace_bytes" % sfx, batch, h, w, cin, cout), x.device)
     e0 = _prof_begin()
-    lib().call("dana_conv3x3_winograd_nhwc_masked", _p(x), _p(u), _p(out), _p(scale), _p(shift), _p(mask), batch, h, w,
-               cin, cout, in_stride, out_stride, mask_stride, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
+    lib().call("dana_conv3x3_winograd%s_nhwc_masked" % sfx, _p(x), _p(u), _p(out), _p(scale), _p(shift), _p(mask), batch,
+               h, w, cin, cout, in_stride, out_stride, mask_stride, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
     _prof_end(e0, ("wino3x3 M=%d N=%d K=%d s1", (batch * h * w, cout, 9 * cin)), 2.0 * batch * h * w * cout * 9 * cin,
-              # bytes of the batched GEMM launch itself: V[16][tiles][cin], U[16][cout][cin], M[16][tiles][cout]
-              64.0 * (batch * ((h + 1) // 2) * ((w + 1) // 2) * (cin + cout) + cout * cin))
+              # bytes of the batched GEMM launch itself: V[planes][tiles][cin], U[planes][cout][cin], M[planes][tiles][cout]
+              4.0 * (m + 2) * (m + 2) * (batch * ((h + m - 1) // m) * ((w + m - 1) // m) * (cin + cout) + cout * cin))
     return out, h, w
 
 

@@ -156,6 +156,15 @@ int dana_conv3x3_winograd_nhwc_masked(const float* input, const float* u, float*
                                       int cout, long in_pix_stride, long out_pix_stride, long mask_pix_stride,
                                       int flags, void* workspace, size_t workspace_bytes, dana_stream_t stream);
 
+/* F(4x4,3x3) variant: u = dana_winograd4_filter_transform(...) -> [36][cout][cin]; 4x fewer multiplies than the
+ * direct conv and smaller transformed tensors than F(2x2,3x3), at ~1e-5 relative error (transform constants up to 8) */
+int dana_winograd4_filter_transform(const float* w_packed, float* u, int cout, int cin, dana_stream_t stream);
+size_t dana_conv3x3_winograd4_workspace_bytes(int batch, int h, int w, int cin, int cout);
+int dana_conv3x3_winograd4_nhwc_masked(const float* input, const float* u, float* output, const float* scale,
+                                       const float* shift, const float* mask_act, int batch, int h, int w, int cin,
+                                       int cout, long in_pix_stride, long out_pix_stride, long mask_pix_stride,
+                                       int flags, void* workspace, size_t workspace_bytes, dana_stream_t stream);
+
 /* nn.Linear / torch.bmm (dana.py:124,140,142,147,266-290): c[z][m][n] = epi(alpha * sum_k a[z][m][k]*b[z][n][k]).
  * Both operands K-contiguous ("NT"); nn.Linear weights [out][in] are used as stored. k % 4 == 0. */
 int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, const float* shift,

@@ -175,9 +175,12 @@ def test_attention_small_kernels_vs_torch(dev):
     _close(x * sc_.cpu() + sh_.cpu(), F.batch_norm(x, mu, var, gam, bet, False, 0., 1e-5), 1e-5)
 
 
-@pytest.mark.parametrize("case", [(2, 38, 63, 256, 256), (3, 4, 4, 512, 512), (1, 12, 16, 2048, 512), (2, 7, 9, 64, 32)])
-def test_winograd_3x3_vs_torch(dev, case):
-    """F(2x2,3x3) path (odd sizes exercise the clipped last tile row/column) vs torch fp32 conv"""
+@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("case", [(2, 38, 63, 256, 256), (3, 4, 4, 512, 512), (1, 12, 16, 2048, 512), (2, 7, 9, 64, 32),
+                                  (1, 5, 6, 64, 64), (2, 1, 3, 32, 32)])
+def test_winograd_3x3_vs_torch(dev, case, tile):
+    """F(2x2,3x3) and F(4x4,3x3) paths (sizes that are not multiples of the tile exercise the clipped last tile
+    row/column) vs torch fp32 conv"""
     ops = _ops()
     N, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(sum(case))
@@ -186,7 +189,8 @@ def test_winograd_3x3_vs_torch(dev, case):
     scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
     ref = F.relu(F.conv2d(x, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
     xd = ops.nchw_to_nhwc(x.to(dev))
-    u = ops.winograd_filter_transform(ops.pack_conv_weight(w.to(dev)), Cout, Cin)
+    u = ops.winograd_filter_transform(ops.pack_conv_weight(w.to(dev)), Cout, Cin, tile)
+    assert u.size(0) == (tile + 2) ** 2
     out = torch.full((N * H * W, Cout + 8), -7.0, device=dev)
     ops.conv3x3_winograd(xd, N, H, W, Cin, u, Cout, scale=scale.to(dev), shift=shift.to(dev), relu=True, out=out,
                          out_stride=Cout + 8)
