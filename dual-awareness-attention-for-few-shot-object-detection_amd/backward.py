@@ -16,6 +16,9 @@ from . import ops
 from .config import cfg
 
 
+USE_WINOGRAD_WGRAD = __import__("os").environ.get("DANA_WINO_WGRAD", "1") != "0"
+
+
 class WeightGrads:
     """Accumulates packed weight gradients per conv (query and support passes share the weights).
     With `stream`, the weight-gradient launches go to that side stream: they only consume (g, x) and nothing on the
@@ -57,6 +60,16 @@ class WeightGrads:
 
     def _launch(self, key, g, x, n, h, w, c, in_stride, grad_stride):
         view = self._direct_view(key)
+        u = c.get("u")
+        if u is not None and u.size(0) == 36 and c["cin"] % 64 == 0 and USE_WINOGRAD_WGRAD:
+            # the conv ran in the F(4x4,3x3) domain forward: so does its weight gradient (4x fewer multiplies)
+            out = view if view is not None else self.packed.get(key)
+            res = ops.conv3x3_wgrad_winograd(g, x, n, h, w, c["cin"], c["cout"], in_stride=in_stride,
+                                             grad_stride=grad_stride, out=out,
+                                             row_scale=c.get("scale") if view is not None else None)
+            if out is None:
+                self.packed[key] = res
+            return
         if view is not None:  # scale by the frozen BN and accumulate straight into param.grad: nothing to finish
             ops.conv2d_wgrad(g, x, n, h, w, c["cin"], c["cout"], c["k"], c["k"], c["stride"], c["pad"],
                              in_stride=in_stride, grad_stride=grad_stride, out=view, row_scale=c.get("scale"))

@@ -33,3 +33,8 @@ void dana_set_error(const char* fmt, ...);
 
 static inline int dana_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t dana_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// internal (wgrad.hip): batched "TN" GEMM out[z][N][K] = dY[z]^T . X[z] over M rows (K % 64 == 0, N % 4 == 0)
+size_t dana_wgrad_tn_batched_workspace(int planes, int M, int N, int K);
+int dana_wgrad_tn_batched(const float* dY, const float* X, float* out, int planes, int M, int N, int K, long batch_y,
+                          long batch_x, void* workspace, size_t workspace_bytes, void* stream);

@@ -33,6 +33,8 @@ struct WgradParams {
   int IH, IW, OH, OW, Cin, KH, KW, stride, pad;
   int ldy, ldx;
   int m_chunk;       // pixels per gridDim.z slice (multiple of 32)
+  int nsplit;        // gridDim.z = planes * nsplit: z = plane * nsplit + slice
+  long batch_y, batch_x;  // element strides between the planes of a batched launch (Winograd-domain weight gradient)
   unsigned y_bytes, x_bytes;
 };
 
@@ -50,10 +52,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
   const int wn = wave >> 1, wk = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int m_begin = blockIdx.z * p.m_chunk;
+  const int plane = blockIdx.z / p.nsplit, slice = blockIdx.z - plane * p.nsplit;
+  const int m_begin = slice * p.m_chunk;
   const int m_end = min(p.M, m_begin + p.m_chunk);
-  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, (int)p.y_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ysrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.dY + plane * p.batch_y), 0, (int)p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + plane * p.batch_x), 0, (int)p.x_bytes, 0x00020000);
 
   // the 64 k-columns of this tile lie inside ONE filter tap (Cin % 64 == 0): wave-uniform tap geometry
   const int tap = k0 / p.Cin, cin0 = k0 - tap * p.Cin;
@@ -130,10 +135,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_128_kernel(WgradParams p) {
   const int wn = wave >> 1, wk = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-  const int m_begin = blockIdx.z * p.m_chunk;
+  const int plane = blockIdx.z / p.nsplit, slice = blockIdx.z - plane * p.nsplit;
+  const int m_begin = slice * p.m_chunk;
   const int m_end = min(p.M, m_begin + p.m_chunk);
-  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, (int)p.y_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ysrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.dY + plane * p.batch_y), 0, (int)p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + plane * p.batch_x), 0, (int)p.x_bytes, 0x00020000);
   // staging: thread -> rows r0 + 8 j (j = 0..3), float4 column c4 = tid % 32 of a [32][128] slab
   const int c4 = tid & 31, r0 = tid >> 5;
   const bool n_ok = (n0 + c4 * 4) < p.N;
@@ -218,6 +226,8 @@ wgrad_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW,
                     long n4, int K4, int S, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
+  partial += (long)blockIdx.y * S * n4;  // plane of a batched launch
+  dW += (long)blockIdx.y * n4;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int s = 0; s < S; ++s) {
     const float4 v = partial[(long)s * n4 + i];
@@ -294,7 +304,7 @@ upsample_scatter_kernel(const float4* __restrict__ compact, float4* __restrict__
 struct WgradShape {
   int tile, tn, tk, S;
 };
-WgradShape wgrad_shape(int N, int K, int M) {
+WgradShape wgrad_shape(int N, int K, int M, int planes = 1) {
   // Pick (tile, S) by a small cost model: `rounds` of workgroups over the chip's slots (2 per CU for the 128x128
   // tile, 4 for 64x64), each doing chunk/32 slabs, plus the HBM round trip of the S partial tiles. The 128x128
   // tile sustains ~0.75 of the per-CU MFMA peak (one LDS read per MFMA), the 64x64 tile ~0.5 (two).
@@ -304,7 +314,7 @@ WgradShape wgrad_shape(int N, int K, int M) {
   for (int tile = 64; tile <= 128; tile += 64) {
     if (forced && tile != forced) continue;
     const int tn = (N + tile - 1) / tile, tk = (K + tile - 1) / tile;
-    const long tiles = (long)tn * tk;
+    const long tiles = (long)tn * tk * planes;
     const int slots = tile == 128 ? 512 : 1024;
     const double cu_flops = 157.3e12 / 256.0 * (tile == 128 ? 0.75 : 0.5);
     const double wg_flops = cu_flops / (tile == 128 ? 2 : 4);
@@ -313,7 +323,7 @@ WgradShape wgrad_shape(int N, int K, int M) {
       const int chunk = ((M + S - 1) / S + 31) / 32 * 32;
       const long rounds = (tiles * S + slots - 1) / slots;
       const double t_mma = (double)rounds * (chunk / 32) * (2.0 * tile * tile * 32) / wg_flops + rounds * 2e-6;
-      const double t_part = 2.0 * S * (double)N * K * 4.0 / 4e12;
+      const double t_part = 2.0 * S * (double)N * K * planes * 4.0 / 4e12;
       const double t = t_mma + t_part;
       if (t < best_t) {
         best_t = t;
@@ -325,6 +335,66 @@ WgradShape wgrad_shape(int N, int K, int M) {
 }
 
 }  // namespace
+
+// ---- internal (common.h): batched "TN" GEMM out[z][N][K] = dY[z]^T . X[z] over M rows, for the Winograd-domain weight
+// gradient (winograd.hip). No accumulate / scale; partial slices through the workspace as above.
+size_t dana_wgrad_tn_batched_workspace(int planes, int M, int N, int K) {
+  const WgradShape ws = wgrad_shape(N, K, M, planes);
+  return ws.S > 1 ? (size_t)planes * ws.S * N * K * sizeof(float) : 0;
+}
+
+int dana_wgrad_tn_batched(const float* dY, const float* X, float* out, int planes, int M, int N, int K, long batch_y,
+                          long batch_x, void* workspace, size_t workspace_bytes, void* stream) {
+  DANA_CHECK_ARG(planes > 0 && M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0, "dana_wgrad_tn_batched: bad shape");
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.dY = dY;
+  p.X = X;
+  p.IH = 1;
+  p.IW = M;
+  p.OH = 1;
+  p.OW = M;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.Cin = K;
+  p.KH = p.KW = 1;
+  p.stride = 1;
+  p.pad = 0;
+  p.ldx = K;
+  p.ldy = N;
+  p.batch_y = batch_y;
+  p.batch_x = batch_x;
+  const long xb = (long)M * K * 4, yb = (long)M * N * 4;
+  DANA_CHECK_ARG(xb < (long)OOB && yb < (long)OOB, "dana_wgrad_tn_batched: plane >= 2 GiB");
+  p.x_bytes = (unsigned)xb;
+  p.y_bytes = (unsigned)yb;
+  const WgradShape ws = wgrad_shape(N, K, M, planes);
+  const int S = ws.S;
+  p.m_chunk = ((M + S - 1) / S + 31) / 32 * 32;
+  p.nsplit = S;
+  const size_t need = dana_wgrad_tn_batched_workspace(planes, M, N, K);
+  if (need && (!workspace || workspace_bytes < need)) {
+    dana_set_error("dana_wgrad_tn_batched: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  p.partial = S > 1 ? (float*)workspace : out;  // one slice: the kernel writes the result itself
+  DANA_CHECK_ARG((long)planes * S <= 65535, "dana_wgrad_tn_batched: too many slices");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(ws.tn, ws.tk, planes * S);
+  if (ws.tile == 128)
+    wgrad_f32_128_kernel<<<grid, 256, 0, s>>>(p);
+  else
+    wgrad_f32_kernel<<<grid, 256, 0, s>>>(p);
+  DANA_CHECK_LAUNCH("dana_wgrad_tn_batched");
+  if (S > 1) {
+    const long n4 = (long)N * K / 4;
+    dim3 rgrid(dana_ceil_div(n4, 256), planes);
+    wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>((const float4*)workspace, (float4*)out, nullptr, n4, K / 4, S, 0);
+    DANA_CHECK_LAUNCH("dana_wgrad_tn_batched(reduce)");
+  }
+  return DANA_OK;
+}
 
 extern "C" {
 
@@ -377,6 +447,7 @@ int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* gra
   const WgradShape ws = wgrad_shape(cout, p.K, p.M);
   const int tn = ws.tn, tk = ws.tk, S = ws.S;
   p.m_chunk = ((p.M + S - 1) / S + 31) / 32 * 32;
+  p.nsplit = S;
   const size_t need = (size_t)S * cout * p.K * sizeof(float);
   if (!workspace || workspace_bytes < need) {
     dana_set_error("dana_conv2d_wgrad_nhwc: workspace %zu < %zu", workspace_bytes, need);

@@ -300,6 +300,89 @@ wino4_output_kernel(const float* __restrict__ M, float* __restrict__ out, const 
   }
 }
 
+// ---- weight gradient in the F(4x4,3x3) domain: dU[xi] = sum_tiles dM[xi]^T V[xi], dM = A dY A^T, dW = G^T dU G ----
+// rows of A (6x4) applied to a 4-vector -> 6-vector: A = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1]
+__device__ __forceinline__ void a4to6(const float4 (&y)[4], float4 (&o)[6]) {
+  const float4 p = f4add(y[0], y[2]), q = f4add(y[1], y[3]);
+  const float4 r = f4ma(y[2], 4.f, y[0]), t = f4ma(y[3], 8.f, f4s(y[1], 2.f));
+  o[0] = y[0];
+  o[1] = f4add(p, q);
+  o[2] = f4sub(p, q);
+  o[3] = f4add(r, t);
+  o[4] = f4sub(r, t);
+  o[5] = y[3];
+}
+
+// one lane = (tile, 4 output channels): dM[36][tiles][N] from dY [B*H*W][ldy]; outputs outside the image are zeros
+__global__ void __launch_bounds__(256)
+wino4_outgrad_kernel(const float* __restrict__ dy, float* __restrict__ dM, int H, int W, int N4, int th, int tw,
+                     long tiles, long ldy) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tiles * N4) return;
+  const int n4 = (int)(idx % N4);
+  const long t = idx / N4;
+  const int j = (int)(t % tw);
+  const int i = (int)((t / tw) % th);
+  const long img = t / ((long)tw * th);
+  float4 tm[6][4];  // A dy, column by column
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int x = 4 * j + c;
+    float4 col[4], o[6];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = 4 * i + r;
+      col[r] = (y < H && x < W) ? *(const float4*)(dy + ((img * H + y) * W + x) * ldy + n4 * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    a4to6(col, o);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) tm[r][c] = o[r];
+  }
+  const long plane = tiles * (long)N4;
+  float4* out = (float4*)dM + t * N4 + n4;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {  // (.) A^T
+    float4 o[6];
+    a4to6(tm[r], o);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) out[(r * 6 + c) * plane] = o[c];
+  }
+}
+
+// dW[co][3][3][ci] (+)= scale[co] * (G^T dU G): one lane = (co, ci)
+__global__ void __launch_bounds__(256)
+wino4_filtergrad_kernel(const float* __restrict__ dU, float* __restrict__ dW, const float* __restrict__ row_scale,
+                        int cout, int cin, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)cout * cin) return;
+  const int ci = (int)(i % cin);
+  const long co = i / cin;
+  const long plane = (long)cout * cin;
+  float t[3][6];  // G^T dU  (G^T = [1/4 -1/6 -1/6 1/24 1/24 0; 0 -1/6 1/6 1/12 -1/12 0; 0 -1/6 -1/6 1/6 1/6 1])
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float u[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) u[r] = dU[(r * 6 + c) * plane + i];
+    t[0][c] = 0.25f * u[0] - (u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 24.f);
+    t[1][c] = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
+    t[2][c] = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
+  }
+  const float sc = row_scale ? row_scale[co] : 1.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float* u = t[r];
+    const float g0 = 0.25f * u[0] - (u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 24.f);
+    const float g1 = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
+    const float g2 = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
+    float* o = dW + ((co * 3 + r) * 3) * cin + ci;
+    o[0] = (accumulate ? o[0] : 0.f) + sc * g0;
+    o[cin] = (accumulate ? o[cin] : 0.f) + sc * g1;
+    o[2 * cin] = (accumulate ? o[2 * cin] : 0.f) + sc * g2;
+  }
+}
+
 struct WinoPlan {
   int th, tw;
   long tiles;
@@ -378,6 +461,53 @@ int dana_conv3x3_winograd_nhwc_masked(const float* input, const float* u, float*
                                                                      p.th, p.tw, p.tiles, ldc,
                                                                      (flags & DANA_EPI_RELU) ? 1 : 0);
   DANA_CHECK_LAUNCH("dana_conv3x3_winograd_nhwc(output transform)");
+  return DANA_OK;
+}
+
+size_t dana_conv3x3_wgrad_winograd4_workspace_bytes(int batch, int h, int w, int cin, int cout) {
+  if (batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+  const WinoPlan p = wino_plan(batch, h, w, cin, cout, 4);
+  const size_t du = dana_align_up((size_t)36 * cout * cin * 4, 256);
+  return p.total + du + dana_align_up(dana_wgrad_tn_batched_workspace(36, (int)p.tiles, cout, cin), 256);
+}
+
+int dana_conv3x3_wgrad_winograd4(const float* grad_out, const float* input, float* grad_weight, int batch, int h, int w,
+                                 int cin, int cout, long in_pix_stride, long grad_pix_stride, const float* row_scale,
+                                 int accumulate, void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 64 == 0 && cout % 4 == 0,
+                 "dana_conv3x3_wgrad_winograd4: bad shape (cin %% 64, cout %% 4)");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad_out && input && grad_weight, "dana_conv3x3_wgrad_winograd4: null pointer");
+  const long lda = in_pix_stride > 0 ? in_pix_stride : cin;
+  const long ldy = grad_pix_stride > 0 ? grad_pix_stride : cout;
+  DANA_CHECK_ARG(lda % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)input & 15) == 0 && ((uintptr_t)grad_out & 15) == 0,
+                 "dana_conv3x3_wgrad_winograd4: strides / pointers must be 16-byte aligned");
+  const long in_bytes = (long)batch * h * w * lda * 4;
+  DANA_CHECK_ARG(in_bytes < (long)OOB, "dana_conv3x3_wgrad_winograd4: input span >= 2 GiB; split the batch");
+  const size_t need = dana_conv3x3_wgrad_winograd4_workspace_bytes(batch, h, w, cin, cout);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("dana_conv3x3_wgrad_winograd4: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  const WinoPlan p = wino_plan(batch, h, w, cin, cout, 4);
+  hipStream_t s = (hipStream_t)stream;
+  float* V = (float*)workspace;                            // [36][tiles][cin]
+  float* dM = (float*)((char*)workspace + p.v_bytes);      // [36][tiles][cout]
+  float* dU = (float*)((char*)workspace + p.total);        // [36][cout][cin]
+  const size_t du = dana_align_up((size_t)36 * cout * cin * 4, 256);
+  void* gws = (char*)workspace + p.total + du;
+  const int C4 = cin / 4, N4 = cout / 4;
+  wino4_input_kernel<<<dana_ceil_div(p.tiles * C4, 256), 256, 0, s>>>(input, V, h, w, C4, p.th, p.tw, p.tiles, (int)lda,
+                                                                     (unsigned)in_bytes);
+  DANA_CHECK_LAUNCH("dana_conv3x3_wgrad_winograd4(input transform)");
+  wino4_outgrad_kernel<<<dana_ceil_div(p.tiles * N4, 256), 256, 0, s>>>(grad_out, dM, h, w, N4, p.th, p.tw, p.tiles, ldy);
+  DANA_CHECK_LAUNCH("dana_conv3x3_wgrad_winograd4(output-gradient transform)");
+  int rc = dana_wgrad_tn_batched(dM, V, dU, 36, (int)p.tiles, cout, cin, p.tiles * cout, p.tiles * cin, gws,
+                                 workspace_bytes - (p.total + du), (void*)s);
+  if (rc) return rc;
+  const long total = (long)cout * cin;
+  wino4_filtergrad_kernel<<<dana_ceil_div(total, 256), 256, 0, s>>>(dU, grad_weight, row_scale, cout, cin, accumulate);
+  DANA_CHECK_LAUNCH("dana_conv3x3_wgrad_winograd4(filter-gradient transform)");
   return DANA_OK;
 }
 

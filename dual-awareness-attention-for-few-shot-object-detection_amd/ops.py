@@ -657,6 +657,21 @@ def conv2d_wgrad(grad_out, x, batch, in_h, in_w, cin, cout, kh, kw, stride, pad,
     return out
 
 
+def conv3x3_wgrad_winograd(grad_out, x, batch, h, w, cin, cout, in_stride=0, grad_stride=0, out=None, row_scale=None):
+    """conv2d_wgrad of a stride-1 pad-1 3x3 conv through the F(4x4,3x3) domain (4x fewer multiplies)"""
+    _chk(grad_out, "grad_out")
+    _chk(x, "x")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((cout, 9 * cin), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().query("dana_conv3x3_wgrad_winograd4_workspace_bytes", batch, h, w, cin, cout), x.device)
+    e0 = _prof_begin()
+    lib().call("dana_conv3x3_wgrad_winograd4", _p(grad_out), _p(x), _p(out), batch, h, w, cin, cout, in_stride,
+               grad_stride, _p(row_scale), int(accumulate), _p(ws), ws.numel(), _stream())
+    _prof_end(e0, ("wgradwino M=%d N=%d K=%d", (batch * h * w, cout, 9 * cin)), 2.0 * batch * h * w * cout * 9 * cin)
+    return out
+
+
 def conv2d_dgrad_weight(w_packed, cout, cin, kh, kw, scale=None):
     """flipped / transposed (and frozen-BN scaled) weights [cin][kh*kw*cout]: the data gradient is a forward conv on them"""
     wd = torch.empty((cin, kh * kw * cout), dtype=torch.float32, device=w_packed.device)

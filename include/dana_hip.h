@@ -165,6 +165,14 @@ int dana_conv3x3_winograd4_nhwc_masked(const float* input, const float* u, float
                                        int cout, long in_pix_stride, long out_pix_stride, long mask_pix_stride,
                                        int flags, void* workspace, size_t workspace_bytes, dana_stream_t stream);
 
+/* weight gradient of a stride-1 pad-1 3x3 conv in the F(4x4,3x3) domain: dU[36] = sum over tiles of
+ * (A dY A^T)^T (B^T x B), dW = G^T dU G -- 4x fewer multiplies than dana_conv2d_wgrad_nhwc; same packed
+ * [cout][3][3][cin] result, same row_scale / accumulate semantics. cin % 64 == 0, cout % 4 == 0. */
+size_t dana_conv3x3_wgrad_winograd4_workspace_bytes(int batch, int h, int w, int cin, int cout);
+int dana_conv3x3_wgrad_winograd4(const float* grad_out, const float* input, float* grad_weight, int batch, int h, int w,
+                                 int cin, int cout, long in_pix_stride, long grad_pix_stride, const float* row_scale,
+                                 int accumulate, void* workspace, size_t workspace_bytes, dana_stream_t stream);
+
 /* nn.Linear / torch.bmm (dana.py:124,140,142,147,266-290): c[z][m][n] = epi(alpha * sum_k a[z][m][k]*b[z][n][k]).
  * Both operands K-contiguous ("NT"); nn.Linear weights [out][in] are used as stored. k % 4 == 0. */
 int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, const float* shift,

@@ -225,3 +225,25 @@ def test_conv_backward_blocks_vs_torch_autograd(dev, case):
     acc = dw.clone()
     ops.conv2d_wgrad(gyd, xd, N, H, W, Cin, Cout, k, k, stride, pad, out=acc)
     _close(acc.cpu(), 2 * ref_dw, 2e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 38, 63, 256, 256), (16, 4, 4, 512, 128), (1, 12, 17, 128, 64), (2, 5, 3, 64, 72)])
+def test_winograd_weight_gradient_vs_direct_and_autograd(dev, case):
+    """F(4x4,3x3)-domain weight gradient (with row scale + accumulate) vs the direct split-M kernel and float64 autograd"""
+    ops = _ops()
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    init = torch.randn(Cout, 9 * Cin, generator=g)
+    wd = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wd, padding=1).backward(gy.double())
+    ref = wd.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin) * scale.double().view(-1, 1) + init.double()
+    xd, gd = ops.nchw_to_nhwc(x.to(dev)), ops.nchw_to_nhwc(gy.to(dev))
+    out = init.clone().to(dev)
+    ops.conv3x3_wgrad_winograd(gd, xd, N, H, W, Cin, Cout, out=out, row_scale=scale.to(dev))
+    _close(out.cpu(), ref, 2e-4)
+    direct = ops.conv2d_wgrad(gd, xd, N, H, W, Cin, Cout, 3, 3, 1, 1)
+    fresh = ops.conv3x3_wgrad_winograd(gd, xd, N, H, W, Cin, Cout)
+    _close(fresh.cpu(), direct.cpu(), 2e-4)
