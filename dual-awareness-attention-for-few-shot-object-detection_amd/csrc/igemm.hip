@@ -383,6 +383,8 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   static const int force = getenv("DANA_IGEMM_TILE") ? atoi(getenv("DANA_IGEMM_TILE")) : 0;
   if (force == 1 && p.N > 64) return launch<128, 128, 0>(p, batch, s);
   if (force == 2) return launch<128, 64, 0>(p, batch, s);
+  if (force == 4 && p.N > 64) return launch<64, 128, 0>(p, batch, s);
+  if (force == 5 && p.N > 128) return launch<64, 256, 0>(p, batch, s);
   return launch<64, 64, 0>(p, batch, s);
 }
 

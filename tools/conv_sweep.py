@@ -9,7 +9,9 @@ SHAPES = [  # (name, N_img, H, W, Cin, Cout, k, stride)
     ("l1c3  M150000 64->256 1x1", 4, 150, 250, 64, 256, 1, 1),
     ("l2c2  M37500 128->128 3x3", 4, 75, 125, 128, 128, 3, 1),
     ("l2c3  M37500 128->512 1x1", 4, 75, 125, 128, 512, 1, 1),
+    ("l2c1  M37500 512->128 1x1", 4, 75, 125, 512, 128, 1, 1),
     ("l3c1  M9576 1024->256 1x1", 4, 38, 63, 1024, 256, 1, 1),
+    ("l4c3  M8192 512->2048 1x1", 512, 4, 4, 512, 2048, 1, 1),
     ("l3c2  M9576 256->256 3x3", 4, 38, 63, 256, 256, 3, 1),
     ("l3c3  M9576 256->1024 1x1", 4, 38, 63, 256, 1024, 1, 1),
     ("l3c2x2 M19152 256->256 3x3", 8, 38, 63, 256, 256, 3, 1),
