@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--shot", type=int, default=3)
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
-    ap.add_argument("--model", default="DAnA", choices=["DAnA", "frcnn"],
+    ap.add_argument("--model", default="DAnA", choices=["DAnA", "frcnn", "meta"],
                     help="DAnA: the hot path (default); frcnn: the sibling plain Faster R-CNN (utils.py:109-110, row N4) "
                          "on the same operators -- forward modes only")
     ap.add_argument("--support-size", type=int, default=320,
@@ -146,6 +146,9 @@ def main():
 
     if args.model == "frcnn":
         inputs = inputs[:4]  # faster_rcnn.py:35: (im_data, im_info, gt_boxes, num_boxes)
+    elif args.model == "meta":
+        inputs = inputs + [inputs[2].clone()]  # meta.py:39,48: all_cls_gt_boxes (one class in the synthetic episodes)
+    if args.model != "DAnA":
         args.no_train_step = True
 
     def fwd_step():

@@ -71,6 +71,40 @@ maxpool3x3s2_kernel(const float4* __restrict__ in, float4* __restrict__ out, int
   }
 }
 
+// nn.MaxPool2d(2): 2x2 stride-2 max pool, floor mode (meta.py:203,246: the PRN's pooling of the support map)
+__global__ void __launch_bounds__(256)
+maxpool2x2s2_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, int W, int OH, int OW, int C4,
+                    long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const int ow = (int)((i / C4) % OW);
+    const int oh = (int)((i / C4 / OW) % OH);
+    const long b = i / C4 / OW / OH;
+    const float4* p = in + ((b * H + oh * 2) * W + ow * 2) * C4 + c;
+    const float4 a = p[0], bb = p[C4], cc = p[(long)W * C4], d = p[(long)W * C4 + C4];
+    out[i] = make_float4(fmaxf(fmaxf(a.x, bb.x), fmaxf(cc.x, d.x)), fmaxf(fmaxf(a.y, bb.y), fmaxf(cc.y, d.y)),
+                         fmaxf(fmaxf(a.z, bb.z), fmaxf(cc.z, d.z)), fmaxf(fmaxf(a.w, bb.w), fmaxf(cc.w, d.w)));
+  }
+}
+
+// y = 1 / (1 + exp(-x)), in place (meta.py:202,250)
+__global__ void __launch_bounds__(256) sigmoid_kernel(float* __restrict__ x, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)blockDim.x * gridDim.x)
+    x[i] = 1.f / (1.f + expf(-x[i]));
+}
+
+// out[r][c] = x[r][c] * vec[r / rows_per_group][c]  (meta.py:136-140: RoI features x the class-attentive vector)
+__global__ void __launch_bounds__(256)
+scale_rows_by_group_kernel(const float4* __restrict__ x, const float4* __restrict__ vec, float4* __restrict__ out,
+                           long rows_per_group, int C4, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const long g = (i / C4) / rows_per_group;
+    const float4 a = x[i], v = vec[g * C4 + c];
+    out[i] = make_float4(a.x * v.x, a.y * v.y, a.z * v.z, a.w * v.w);
+  }
+}
+
 // k x k average pool, given stride, no padding (dana.py:42: AvgPool2d(14, stride=1))
 __global__ void __launch_bounds__(256)
 avgpool_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, int W, int OH, int OW, int C4, int k,
@@ -291,6 +325,42 @@ int dana_maxpool3x3s2_ceil_nhwc(const float* in, float* out, int batch, int heig
   maxpool3x3s2_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)in, (float4*)out, height,
                                                                              width, oh, ow, channels / 4, total);
   DANA_CHECK_LAUNCH("dana_maxpool3x3s2_ceil_nhwc");
+  return DANA_OK;
+}
+
+int dana_maxpool2x2s2_nhwc(const float* in, float* out, int batch, int height, int width, int channels,
+                           dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && height >= 2 && width >= 2 && channels > 0 && channels % 4 == 0,
+                 "dana_maxpool2x2s2_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && out, "dana_maxpool2x2s2_nhwc: null pointer");
+  const int oh = height / 2, ow = width / 2;
+  const long total = (long)batch * oh * ow * (channels / 4);
+  maxpool2x2s2_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)in, (float4*)out, height,
+                                                                             width, oh, ow, channels / 4, total);
+  DANA_CHECK_LAUNCH("dana_maxpool2x2s2_nhwc");
+  return DANA_OK;
+}
+
+int dana_sigmoid(float* x, long n, dana_stream_t stream) {
+  DANA_CHECK_ARG(n >= 0, "dana_sigmoid: bad size");
+  if (n == 0) return DANA_OK;
+  DANA_CHECK_ARG(x, "dana_sigmoid: null pointer");
+  sigmoid_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(x, n);
+  DANA_CHECK_LAUNCH("dana_sigmoid");
+  return DANA_OK;
+}
+
+int dana_scale_rows_by_group(const float* x, const float* group_vec, float* out, long rows, long rows_per_group,
+                             int channels, dana_stream_t stream) {
+  DANA_CHECK_ARG(rows >= 0 && rows_per_group > 0 && channels > 0 && channels % 4 == 0,
+                 "dana_scale_rows_by_group: bad shape");
+  if (rows == 0) return DANA_OK;
+  DANA_CHECK_ARG(x && group_vec && out, "dana_scale_rows_by_group: null pointer");
+  const long total = rows * (channels / 4);
+  scale_rows_by_group_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      (const float4*)x, (const float4*)group_vec, (float4*)out, rows_per_group, channels / 4, total);
+  DANA_CHECK_LAUNCH("dana_scale_rows_by_group");
   return DANA_OK;
 }
 

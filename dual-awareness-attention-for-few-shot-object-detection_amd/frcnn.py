@@ -46,13 +46,17 @@ class FasterRCNN(DAnARCNN):
         self.RCNN_cls_score.weight.data.normal_(0, 0.01)
         self.RCNN_cls_score.bias.data.zero_()
 
-    def forward(self, im_data, im_info, gt_boxes, num_boxes):
+    # ---- shared stages of the sibling detectors (frcnn, meta): trunk -> RPN -> targets -> RoI features -> layer4 ----
+    def _stages(self, im_data, im_info, gt_boxes, anchor_gt_boxes=None):
+        """-> dict(B, R, n_roi, rois, rpn losses, rois_label / targets (train), fc7 [n_roi][2048]).
+        anchor_gt_boxes: boxes the anchor-target layer sees (meta.py:65 passes ALL classes' boxes); default gt_boxes"""
         plan = self._get_plan()
         dev = im_data.device
         training = self.training
         B = im_data.size(0)
         im_info = im_info.data.float().contiguous()
         gt_boxes = gt_boxes.data
+        anchor_gt = gt_boxes if anchor_gt_boxes is None else anchor_gt_boxes.data
         inputs_ready = torch.cuda.Event()
         inputs_ready.record()
         main = torch.cuda.current_stream()
@@ -73,30 +77,30 @@ class FasterRCNN(DAnARCNN):
         rois = ops.proposal_layer(heads, (hw * nh, 1, nh), False, heads.view(-1)[rpn.nc_score_out:], (hw * nh, 1, nh),
                                   im_info, plan["anchors"], B, A, fh, fw, rpn.feat_stride, cfg[key].RPN_PRE_NMS_TOP_N,
                                   cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH, self.nms_inclusive)
-        rpn_loss_cls = rpn_loss_bbox = 0
-        rois_label = None
+        st = dict(B=B, rpn_loss_cls=0, rpn_loss_bbox=0, rois_label=None, labels_f=None)
         if training:
             tr_ = cfg.TRAIN
             side = self._stream("targets", dev)
             side.wait_event(inputs_ready)
             with torch.cuda.stream(side):
-                at = ops.anchor_target_assign(gt_boxes.float(), im_info, plan["anchors"], fh, fw, rpn.feat_stride,
+                at = ops.anchor_target_assign(anchor_gt.float(), im_info, plan["anchors"], fh, fw, rpn.feat_stride,
                                               tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP, tr_.RPN_BATCHSIZE,
                                               tr_.RPN_FG_FRACTION)
             at["ibuf"].record_stream(main)
             at["labels"].record_stream(main)
             main.wait_stream(side)
             rpn_l = ops.rpn_losses(heads, nh, at, sigma=3.0, inside_weight=tr_.RPN_BBOX_INSIDE_WEIGHTS[0])
-            rpn_loss_cls, rpn_loss_bbox = rpn_l[0], rpn_l[1]
+            st["rpn_loss_cls"], st["rpn_loss_bbox"] = rpn_l[0], rpn_l[1]
             fg_per = int(np.round(tr_.FG_FRACTION * tr_.BATCH_SIZE)) or 1
             rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_layer(
                 rois, gt_boxes.float(), int(tr_.BATCH_SIZE), fg_per, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
                 tr_.BBOX_NORMALIZE_MEANS, tr_.BBOX_NORMALIZE_STDS, tr_.BBOX_INSIDE_WEIGHTS,
                 tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)
-            rois_label = rois_label.view(-1).long()
-            rois_target = rois_target.view(-1, 4)
-            rois_inside_ws = rois_inside_ws.view(-1, 4)
-            rois_outside_ws = rois_outside_ws.view(-1, 4)
+            st["labels_f"] = rois_label.reshape(-1).contiguous()
+            st["rois_label"] = st["labels_f"].long()
+            st["rois_target"] = rois_target.view(-1, 4)
+            st["rois_inside_ws"] = rois_inside_ws.view(-1, 4)
+            st["rois_outside_ws"] = rois_outside_ws.view(-1, 4)
         R = rois.size(1)
         n_roi = B * R
         P = cfg.POOLING_SIZE
@@ -109,19 +113,86 @@ class FasterRCNN(DAnARCNN):
             pooled = ops.nchw_to_nhwc(pooled_nchw)
         else:
             raise NotImplementedError("POOLING_MODE '%s'" % cfg.POOLING_MODE)
-        # -- head: layer4 -> mean -> two Linear layers (faster_rcnn.py:76-88,183-185) --
-        y, h4, w4 = pooled, P, P
+        st.update(rois=rois, R=R, n_roi=n_roi, fc7=self._head_to_tail(pooled, n_roi, P, P, plan), plan=plan)
+        return st
+
+    def _head_to_tail(self, x, n, h, w, plan):
+        """layer4 + spatial mean (faster_rcnn.py:183-185) on an NHWC batch of n maps -> [n][2048]"""
         for bp in plan["layer4"]:
-            y, h4, w4 = self._bottleneck(y, n_roi, h4, w4, bp)
-        fc7 = ops.spatial_mean(y, n_roi, h4 * w4, 2048)
+            x, h, w = self._bottleneck(x, n, h, w, bp)
+        return ops.spatial_mean(x, n, h * w, 2048)
+
+    def forward(self, im_data, im_info, gt_boxes, num_boxes):
+        st = self._stages(im_data, im_info, gt_boxes)
+        B, R, n_roi, fc7 = st["B"], st["R"], st["n_roi"], st["fc7"]
         wb, bb = self._w(self.RCNN_bbox_pred)
         wc, bc = self._w(self.RCNN_cls_score)
         bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
         cls_score = ops.gemm_nt(fc7, wc, n_roi, self.n_classes, 2048, shift=bc)
         cls_prob = ops.softmax_rows_(cls_score.clone(), n_roi, self.n_classes)
         RCNN_loss_cls = RCNN_loss_bbox = 0
-        if training:  # faster_rcnn.py:93-98
-            RCNN_loss_cls = F.cross_entropy(cls_score, rois_label)
-            RCNN_loss_bbox = T._smooth_l1_loss(bbox_pred, rois_target, rois_inside_ws, rois_outside_ws)
-        return (rois, cls_prob.view(B, R, -1), bbox_pred.view(B, R, -1), rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls,
-                RCNN_loss_bbox, rois_label)
+        if self.training:  # faster_rcnn.py:93-98
+            RCNN_loss_cls = F.cross_entropy(cls_score, st["rois_label"])
+            RCNN_loss_bbox = T._smooth_l1_loss(bbox_pred, st["rois_target"], st["rois_inside_ws"], st["rois_outside_ws"])
+        return (st["rois"], cls_prob.view(B, R, -1), bbox_pred.view(B, R, -1), st["rpn_loss_cls"], st["rpn_loss_bbox"],
+                RCNN_loss_cls, RCNN_loss_bbox, st["rois_label"])
+
+
+class MetaRCNN(FasterRCNN):
+    """Sibling model `meta` (utils.py:113-114): Meta R-CNN, lib/model/framework/meta.py:18-251. The Predictor-head
+    Remodeling Network turns every support image into a class-attentive vector, sigmoid(mean(layer4(maxpool2(trunk)))),
+    the shots' mean multiplies the RoI features channel-wise in front of a 2-way Linear; positive + negative supports
+    and the 1:2:1 hard-negative-mined loss as in DAnA. Forward only."""
+
+    def __init__(self, classes, num_layers=50, pretrained=False, num_way=2, num_shot=5):
+        self.n_way, self.n_shot = num_way, num_shot
+        FasterRCNN.__init__(self, classes, num_layers, pretrained)
+
+    def _init_modules(self):
+        FasterRCNN._init_modules(self)
+        self.RCNN_cls_score = nn.Sequential(nn.Linear(2048, 2))  # meta.py:199-201 (state_dict key RCNN_cls_score.0.*)
+
+    def _init_weights(self):  # meta.py:144-159: RCNN_cls_score keeps its default init
+        from .dana import DAnARCNN
+        DAnARCNN._init_weights(self)
+
+    def forward(self, im_data, im_info, gt_boxes, num_boxes, support_ims, all_cls_gt_boxes=None):
+        if all_cls_gt_boxes is None:
+            raise RuntimeError("meta: all_cls_gt_boxes is required (meta.py:48,65)")
+        training = self.training
+        shot = self.n_shot
+        way = self.n_way if training else 1
+        st = self._stages(im_data, im_info, gt_boxes, anchor_gt_boxes=all_cls_gt_boxes)
+        B, R, n_roi, fc7, plan = st["B"], st["R"], st["n_roi"], st["fc7"], st["plan"]
+        # PRN (meta.py:241-251) on every support image
+        sup_ims = support_ims.reshape(-1, support_ims.size(2), support_ims.size(3), support_ims.size(4))
+        Ns = sup_ims.size(0)
+        if Ns != B * way * shot:
+            raise RuntimeError("support_ims must hold batch*way*shot = %d images, got %d" % (B * way * shot, Ns))
+        sup, sh_, sw_ = self._rcnn_base(sup_ims, plan)
+        mp, mh, mw = ops.maxpool2x2s2(sup, Ns, sh_, sw_, 1024)
+        att = ops.sigmoid_(self._head_to_tail(mp, Ns, mh, mw, plan))  # [Ns][2048]
+        wb, bb = self._w(self.RCNN_bbox_pred)
+        wc, bc = self._w(self.RCNN_cls_score[0])
+        bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
+
+        def head(offset):  # supports [offset, offset + shot) of every episode: their mean vector x the RoI features
+            vec = torch.empty((B, 2048), dtype=torch.float32, device=fc7.device)
+            for b in range(B):
+                vec[b:b + 1] = ops.spatial_mean(att.view(-1)[(b * way * shot + offset) * 2048:], 1, shot, 2048)
+            comb = ops.scale_rows_by_group(fc7, vec, n_roi, R, 2048)
+            score = ops.gemm_nt(comb, wc, n_roi, 2, 2048, shift=bc)
+            return ops.softmax_rows_(score.clone(), n_roi, 2), score
+
+        cls_prob, cls_score = head(0)
+        RCNN_loss_cls = RCNN_loss_bbox = 0
+        rois_label = st["rois_label"]
+        if training:
+            neg_prob, neg_score = head(shot)
+            cls_prob = torch.cat([cls_prob, neg_prob], 0)
+            rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
+            rl, _ = ops.rcnn_losses(cls_score, neg_score, st["labels_f"], bbox_pred, st["rois_target"].contiguous(),
+                                    st["rois_inside_ws"].contiguous(), st["rois_outside_ws"].contiguous())
+            RCNN_loss_cls, RCNN_loss_bbox = rl[0], rl[1]
+        return (st["rois"], cls_prob, bbox_pred, st["rpn_loss_cls"], st["rpn_loss_bbox"], RCNN_loss_cls, RCNN_loss_bbox,
+                rois_label)

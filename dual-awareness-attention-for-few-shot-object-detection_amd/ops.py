@@ -522,6 +522,26 @@ def maxpool3x3s2_ceil(x, B, H, W, C, out=None):
     return out, oh, ow
 
 
+def maxpool2x2s2(x, B, H, W, C):
+    _chk(x, "x")
+    out = torch.empty((B * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)
+    lib().call("dana_maxpool2x2s2_nhwc", _p(x), _p(out), B, H, W, C, _stream())
+    return out, H // 2, W // 2
+
+
+def sigmoid_(x):
+    lib().call("dana_sigmoid", _p(_chk(x, "x")), x.numel(), _stream())
+    return x
+
+
+def scale_rows_by_group(x, vec, rows, rows_per_group, channels):
+    """out[r] = x[r] * vec[r // rows_per_group] (channel-wise)"""
+    out = torch.empty((rows, channels), dtype=torch.float32, device=x.device)
+    lib().call("dana_scale_rows_by_group", _p(_chk(x, "x")), _p(_chk(vec, "vec")), _p(out), rows, rows_per_group,
+               channels, _stream())
+    return out
+
+
 def avgpool(x, B, H, W, C, k, stride):
     _chk(x, "x")
     oh, ow = (H - k) // stride + 1, (W - k) // stride + 1

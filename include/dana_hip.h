@@ -195,6 +195,13 @@ int dana_avgpool_nhwc(const float* in, float* out, int batch, int height, int wi
 /* RCNN_top(pool5).mean(3).mean(2): dana.py:387-389; in[groups][positions][stride] -> out[groups][channels] */
 int dana_spatial_mean_nhwc(const float* in, float* out, int groups, int positions, int channels, long in_pix_stride,
                            dana_stream_t stream);
+/* sibling model `meta` (framework/meta.py): nn.MaxPool2d(2) of the PRN (:203,246), nn.Sigmoid (:202,250), and the
+ * channel-wise product of the RoI features with their image's class-attentive vector (:136-140) */
+int dana_maxpool2x2s2_nhwc(const float* in, float* out, int batch, int height, int width, int channels,
+                           dana_stream_t stream);
+int dana_sigmoid(float* x, long n, dana_stream_t stream);
+int dana_scale_rows_by_group(const float* x, const float* group_vec, float* out, long rows, long rows_per_group,
+                             int channels, dana_stream_t stream);
 /* PositionalEncoding.forward: dana.py:322-324; out[r] = in[r] + pe[r % length] */
 int dana_add_pe(const float* in, const float* pe, float* out, long rows, int length, int channels,
                 long in_stride, long out_stride, dana_stream_t stream);

@@ -535,6 +535,71 @@ def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_
 
 
 # ------------------------------------------------------------------------------------------------
+# sibling model `meta` (Meta R-CNN): lib/model/framework/meta.py:39-142,241-251
+# ------------------------------------------------------------------------------------------------
+def mined_cross_entropy(cls_score, rois_label):
+    """the 2-way loss with 1:2:1 hard-negative mining shared by dana.py:203-215, meta.py:111-123, fsod.py:163-175"""
+    fg = (rois_label == 1).nonzero().squeeze(-1)
+    bg = (rois_label == 0).nonzero().squeeze(-1)
+    sm = F.softmax(cls_score, 1)[bg, :]
+    n_all = rois_label.shape[0]
+    bg0 = max(1, min(fg.shape[0] * 2, int(n_all * 0.25)))
+    bg1 = max(1, min(fg.shape[0], bg0))
+    _, sidx = torch.sort(sm[:, 1], descending=True)
+    real_bg = bg[sidx]
+    idx = torch.cat([fg, real_bg[real_bg < int(n_all * 0.5)][:bg0], real_bg[real_bg >= int(n_all * 0.5)][:bg1]], 0)
+    return F.cross_entropy(cls_score[idx], rois_label[idx])
+
+
+def meta_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, all_cls_gt_boxes, training, n_way=2, n_shot=3,
+                 nms_inclusive=True):
+    B = im_data.shape[0]
+    base_feat = rcnn_base(im_data, sd)
+    # PRN (meta.py:241-251): class-attentive vectors = sigmoid(layer4(maxpool2(base(support))).mean)
+    sf = torch.sigmoid(rcnn_top(F.max_pool2d(rcnn_base(support_ims.reshape(-1, *support_ims.shape[2:]), sd), 2), sd))
+    if training:
+        sf = sf.view(-1, n_way * n_shot, sf.shape[1])
+        pos, neg = sf[:, :n_shot].mean(1), sf[:, n_shot:n_way * n_shot].mean(1)
+    else:
+        pos = sf.view(-1, n_shot, sf.shape[1]).mean(1)
+    cls, prob, bbox = rpn_head(base_feat, sd)
+    rois = proposal_layer(prob.detach(), bbox.detach(), im_info, "TRAIN" if training else "TEST", nms_inclusive)
+    rpn_loss_cls = rpn_loss_bbox = 0
+    rois_label = None
+    if training:
+        H, W = cls.shape[2:]
+        lab, tg, w_in, w_out = anchor_target_layer((H, W), all_cls_gt_boxes, im_info)  # meta.py:65: ALL classes' boxes
+        sc = cls.view(B, 2, -1, W).permute(0, 2, 3, 1).reshape(-1, 2)
+        keep = lab.view(-1).ne(-1).nonzero().view(-1)
+        rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
+        rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
+        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        rois_label = rois_label.view(-1).long()
+        rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
+    pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
+                                                       1.0 / 16.0, 7, 7, 0))
+    fc7 = rcnn_top(pooled, sd)
+    R = rois.size(1)
+
+    def head(vec):  # meta.py:129-142
+        comb = (fc7.view(B, R, -1) * vec.view(B, 1, -1)).view(B * R, -1)
+        score = _lin(comb, sd, "RCNN_cls_score.0")
+        return F.softmax(score, 1), score
+
+    bbox_pred = _lin(fc7, sd, "RCNN_bbox_pred")
+    cls_prob, cls_score = head(pos)
+    loss_cls = loss_bbox = 0
+    if training:
+        neg_prob, neg_score = head(neg)
+        cls_prob = torch.cat([cls_prob, neg_prob], 0)
+        cls_score = torch.cat([cls_score, neg_score], 0)
+        rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
+        loss_bbox = smooth_l1(bbox_pred, rois_target, rw_in, rw_out)
+        loss_cls = mined_cross_entropy(cls_score, rois_label)
+    return rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, loss_cls, loss_bbox, rois_label
+
+
+# ------------------------------------------------------------------------------------------------
 # sibling model on the same ops: plain Faster R-CNN, lib/model/framework/faster_rcnn.py:35-103
 # ------------------------------------------------------------------------------------------------
 def frcnn_forward(sd, im_data, im_info, gt_boxes, num_boxes, training, nms_inclusive=True, pooling="align"):

@@ -109,3 +109,12 @@ def build_frcnn():
     m = faster_rcnn.FasterRCNN(["fg", "bg"], pretrained=False)
     m.create_architecture()
     return m
+
+
+def build_meta(way, shot):
+    """the reference's Meta R-CNN sibling (lib/model/framework/meta.py:173-251)"""
+    load()
+    from model.framework import meta
+    m = meta.METARCNN(["fg", "bg"], pretrained=False, num_way=way, num_shot=shot)
+    m.create_architecture()
+    return m
