@@ -374,10 +374,9 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     _acc(rpn.RPN_bbox_pred.weight, dwh[ns:])
     _acc(rpn.RPN_bbox_pred.bias, dbh[ns:])
     ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
-    c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None)
+    c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None, u=plan["rpn_conv_u"])
     grads.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn)
     _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
-    c_rpn["u"] = plan["rpn_conv_u"]
     d_corr = conv_dgrad(d_x, B, fh, fw, c_rpn)  # [B*hw][2048]
 
     # -- RPN-level attention (dana.py:118-154): corr = [base_feat | dense] --
