@@ -199,6 +199,60 @@ roi_align_bwd(const float* __restrict__ gout, const float* __restrict__ rois, fl
   }
 }
 
+// NHWC backward, one workgroup per (roi, bin) like the forward: the bilinear weight of a sample is separable, so the
+// weights of all grid_h x grid_w samples of the bin collapse to a row vector times a column vector over the few
+// feature pixels the bin touches -- one atomic per touched pixel and channel instead of four per sample, and the
+// geometry is computed once per workgroup instead of once per element. Used for maps of at most RB_MAX x RB_MAX pixels.
+constexpr int RB_MAX = 128;  // lo / hi are clamped to the map, so a bin never spans more than the map side
+__global__ void __launch_bounds__(256)
+roi_align_bwd_nhwc_bins(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin, int C,
+                        int H, int W, int PH, int PW, float scale, int sr) {
+  __shared__ float wy[RB_MAX], wx[RB_MAX];
+  __shared__ int base[2], span[2];
+  const int n = blockIdx.x, bin = blockIdx.y;
+  const int ph = bin / PW, pw = bin % PW;
+  const RoiGeom g = roi_geom(rois + (long)n * 5, scale, PH, PW, sr);
+  for (int i = threadIdx.x; i < 2 * RB_MAX; i += blockDim.x) (i < RB_MAX ? wy : wx)[i % RB_MAX] = 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0 || threadIdx.x == 64) {  // one lane per axis (different waves)
+    const bool ax = threadIdx.x == 64;  // false: rows, true: columns
+    const int grid = ax ? g.grid_w : g.grid_h, size = ax ? W : H;
+    const float start = ax ? g.start_w + pw * g.bin_w : g.start_h + ph * g.bin_h, bsz = ax ? g.bin_w : g.bin_h;
+    float* wv = ax ? wx : wy;
+    int b0 = -1, last = -1;
+    for (int i = 0; i < grid; ++i) {
+      const AxisSample sa = axis_sample(start + ((float)i + .5f) * bsz / (float)grid, size);
+      if (sa.empty) continue;
+      if (b0 < 0) b0 = sa.lo;  // sample positions increase with i, so do lo / hi
+      if (sa.hi - b0 < RB_MAX) {
+        wv[sa.lo - b0] += sa.h;
+        wv[sa.hi - b0] += sa.l;
+      }
+      last = sa.hi;
+    }
+    base[ax] = b0;
+    span[ax] = b0 < 0 ? 0 : last - b0 + 1;
+  }
+  __syncthreads();
+  const int ry = span[0], rx = span[1];
+  if (ry == 0 || rx == 0) return;  // every sample of the bin falls outside the map
+  const int y0 = base[0], x0 = base[1];
+  const float inv = 1.f / g.count;
+  const float* go = gout + ((long)n * PH * PW + bin) * C;
+  float* img = gin + (long)g.batch * H * W * C;
+  // lanes own consecutive channels: one atomic instruction covers 256 contiguous bytes of the feature gradient
+  for (int r = 0; r < ry; ++r) {
+    const float wr = wy[r] * inv;
+    if (wr == 0.f) continue;
+    for (int q = 0; q < rx; ++q) {
+      const float wgt = wr * wx[q];
+      if (wgt == 0.f) continue;
+      float* p = img + ((long)(y0 + r) * W + x0 + q) * C;
+      for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(p + c, go[c] * wgt);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // RoIPool (NCHW): ROIPool_cuda.cu:16-77 forward (max + int32 argmax), :79-108 backward.
 __global__ void __launch_bounds__(256)
@@ -318,7 +372,12 @@ int dana_roi_align_backward(const float* grad_out, const float* rois, float* gra
     roi_align_bwd<false><<<stream_grid(total, 256), 256, 0, s>>>(grad_out, rois, grad_in, total, channels, height,
                                                                  width, pooled_h, pooled_w, spatial_scale,
                                                                  sampling_ratio);
-  else
+  else if (channels % 4 == 0 && height <= RB_MAX && width <= RB_MAX && pooled_h * pooled_w <= 65535 &&
+           ((uintptr_t)grad_out & 15) == 0) {
+    dim3 grid(num_rois, pooled_h * pooled_w);
+    roi_align_bwd_nhwc_bins<<<grid, 256, 0, s>>>(grad_out, rois, grad_in, channels, height, width, pooled_h, pooled_w,
+                                                 spatial_scale, sampling_ratio);
+  } else
     roi_align_bwd<true><<<stream_grid(total, 256), 256, 0, s>>>(grad_out, rois, grad_in, total, channels, height,
                                                                 width, pooled_h, pooled_w, spatial_scale,
                                                                 sampling_ratio);

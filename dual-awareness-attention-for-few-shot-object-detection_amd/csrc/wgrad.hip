@@ -221,21 +221,35 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_128_kernel(WgradParams p) {
 
 // dW[i] = (accumulate ? dW[i] : 0) + row_scale[row(i)] * sum_s partial[s][i], fixed order. row_scale (optional) is the
 // frozen-BN scale of the output channel: with it the launch writes straight into the parameter's gradient.
+// A block = 64 float4 outputs x 4 slice-lanes (lane q sums slices q, q+4, ...; the four are combined in a fixed order
+// through LDS): 4x the blocks and S/4 dependent loads per thread -- the 1-lane version was latency-bound (~19 us).
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW, const float* __restrict__ row_scale,
                     long n4, int K4, int S, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
+  __shared__ float4 part[4][64];
+  const int ol = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + ol;
   partial += (long)blockIdx.y * S * n4;  // plane of a batched launch
   dW += (long)blockIdx.y * n4;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < S; ++s) {
-    const float4 v = partial[(long)s * n4 + i];
-    a.x += v.x;
-    a.y += v.y;
-    a.z += v.z;
-    a.w += v.w;
+  if (i < n4) {
+#pragma unroll 4
+    for (int s = q; s < S; s += 4) {
+      const float4 v = partial[(long)s * n4 + i];
+      a.x += v.x;
+      a.y += v.y;
+      a.z += v.z;
+      a.w += v.w;
+    }
   }
+  part[q][ol] = a;
+  __syncthreads();
+  if (q != 0 || i >= n4) return;
+  const float4 b = part[1][ol], c = part[2][ol], d = part[3][ol];
+  a.x = (a.x + b.x) + (c.x + d.x);
+  a.y = (a.y + b.y) + (c.y + d.y);
+  a.z = (a.z + b.z) + (c.z + d.z);
+  a.w = (a.w + b.w) + (c.w + d.w);
   if (row_scale) {
     const float sc = row_scale[i / K4];
     a.x *= sc;
@@ -389,7 +403,7 @@ int dana_wgrad_tn_batched(const float* dY, const float* X, float* out, int plane
   DANA_CHECK_LAUNCH("dana_wgrad_tn_batched");
   if (S > 1) {
     const long n4 = (long)N * K / 4;
-    dim3 rgrid(dana_ceil_div(n4, 256), planes);
+    dim3 rgrid(dana_ceil_div(n4, 64), planes);
     wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>((const float4*)workspace, (float4*)out, nullptr, n4, K / 4, S, 0);
     DANA_CHECK_LAUNCH("dana_wgrad_tn_batched(reduce)");
   }
@@ -462,7 +476,7 @@ int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* gra
     wgrad_f32_kernel<<<grid, 256, 0, s>>>(p);
   DANA_CHECK_LAUNCH("dana_conv2d_wgrad_nhwc");
   const long n4 = (long)cout * p.K / 4;
-  wgrad_reduce_kernel<<<dana_ceil_div(n4, 256), 256, 0, s>>>((const float4*)workspace, (float4*)grad_weight, row_scale,
+  wgrad_reduce_kernel<<<dana_ceil_div(n4, 64), 256, 0, s>>>((const float4*)workspace, (float4*)grad_weight, row_scale,
                                                              n4, p.K / 4, S, accumulate);
   DANA_CHECK_LAUNCH("dana_conv2d_wgrad_nhwc(reduce)");
   return DANA_OK;
