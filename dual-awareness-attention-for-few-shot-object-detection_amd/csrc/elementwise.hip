@@ -105,6 +105,31 @@ scale_rows_by_group_kernel(const float4* __restrict__ x, const float4* __restric
   }
 }
 
+// depth-wise "valid" cross-correlation (fsod.py:109-116,207-214: F.conv2d(feat, kernel.view(C,1,kh,kw), groups=C)):
+// out[n][oh][ow][c] = sum_{i,j} feat[n][oh+i][ow+j][c] * kern[n / per_kernel][i][j][c]
+__global__ void __launch_bounds__(256)
+depthwise_corr_kernel(const float4* __restrict__ feat, const float4* __restrict__ kern, float4* __restrict__ out, int H,
+                      int W, int KH, int KW, int OH, int OW, int C4, long lda4, long per_kernel, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const int ow = (int)((i / C4) % OW);
+    const int oh = (int)((i / C4 / OW) % OH);
+    const long n = i / C4 / OW / OH;
+    const float4* kp = kern + (n / per_kernel) * KH * KW * C4 + c;
+    const float4* fp = feat + ((n * H + oh) * W + ow) * lda4 + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < KH; ++a)
+      for (int b = 0; b < KW; ++b) {
+        const float4 f = fp[((long)a * W + b) * lda4], k = kp[(a * KW + b) * C4];
+        acc.x += f.x * k.x;
+        acc.y += f.y * k.y;
+        acc.z += f.z * k.z;
+        acc.w += f.w * k.w;
+      }
+    out[i] = acc;
+  }
+}
+
 // k x k average pool, given stride, no padding (dana.py:42: AvgPool2d(14, stride=1))
 __global__ void __launch_bounds__(256)
 avgpool_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, int W, int OH, int OW, int C4, int k,
@@ -325,6 +350,25 @@ int dana_maxpool3x3s2_ceil_nhwc(const float* in, float* out, int batch, int heig
   maxpool3x3s2_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)in, (float4*)out, height,
                                                                              width, oh, ow, channels / 4, total);
   DANA_CHECK_LAUNCH("dana_maxpool3x3s2_ceil_nhwc");
+  return DANA_OK;
+}
+
+int dana_depthwise_corr_nhwc(const float* feat, const float* kernels, float* out, long n_maps, int height, int width,
+                             int channels, int kh, int kw, long maps_per_kernel, long feat_pix_stride,
+                             dana_stream_t stream) {
+  DANA_CHECK_ARG(n_maps >= 0 && height >= kh && width >= kw && kh > 0 && kw > 0 && channels > 0 && channels % 4 == 0 &&
+                     maps_per_kernel > 0,
+                 "dana_depthwise_corr_nhwc: bad shape");
+  if (n_maps == 0) return DANA_OK;
+  DANA_CHECK_ARG(feat && kernels && out, "dana_depthwise_corr_nhwc: null pointer");
+  if (feat_pix_stride <= 0) feat_pix_stride = channels;
+  DANA_CHECK_ARG(feat_pix_stride % 4 == 0, "dana_depthwise_corr_nhwc: stride %% 4 != 0");
+  const int oh = height - kh + 1, ow = width - kw + 1;
+  const long total = n_maps * oh * ow * (channels / 4);
+  depthwise_corr_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      (const float4*)feat, (const float4*)kernels, (float4*)out, height, width, kh, kw, oh, ow, channels / 4,
+      feat_pix_stride / 4, maps_per_kernel, total);
+  DANA_CHECK_LAUNCH("dana_depthwise_corr_nhwc");
   return DANA_OK;
 }
 

@@ -47,9 +47,11 @@ class FasterRCNN(DAnARCNN):
         self.RCNN_cls_score.bias.data.zero_()
 
     # ---- shared stages of the sibling detectors (frcnn, meta): trunk -> RPN -> targets -> RoI features -> layer4 ----
-    def _stages(self, im_data, im_info, gt_boxes, anchor_gt_boxes=None):
-        """-> dict(B, R, n_roi, rois, rpn losses, rois_label / targets (train), fc7 [n_roi][2048]).
-        anchor_gt_boxes: boxes the anchor-target layer sees (meta.py:65 passes ALL classes' boxes); default gt_boxes"""
+    def _stages(self, im_data, im_info, gt_boxes, anchor_gt_boxes=None, rpn_input=None):
+        """-> dict(B, R, n_roi, rois, rpn losses, rois_label / targets (train), pooled, fc7 [n_roi][2048]).
+        anchor_gt_boxes: boxes the anchor-target layer sees (meta.py:65 passes ALL classes' boxes); default gt_boxes.
+        rpn_input(base, B, fh, fw, plan) -> (feature [B*h*w][1024], h, w): what the RPN runs on instead of base_feat
+        (fsod.py:109-119: the attention RPN's correlation map, which is smaller than base_feat)"""
         plan = self._get_plan()
         dev = im_data.device
         training = self.training
@@ -61,14 +63,17 @@ class FasterRCNN(DAnARCNN):
         inputs_ready.record()
         main = torch.cuda.current_stream()
         base, fh, fw = self._rcnn_base(im_data, plan)  # [B*fh*fw][1024] NHWC (faster_rcnn.py:43)
+        # -- RPN (rpn.py:58-115) on base_feat (or on the model's own RPN input) --
+        rfeat, rh, rw = (base, fh, fw) if rpn_input is None else rpn_input(base, B, fh, fw, plan)
+        base_hw = (fh, fw)
+        fh, fw = rh, rw  # the RPN / anchor / proposal geometry below is the RPN input's
         hw = fh * fw
-        # -- RPN (rpn.py:58-115) on base_feat --
         rpn = self.RCNN_rpn
         if plan["rpn_conv_u"] is not None:
-            x, _, _ = ops.conv3x3_winograd(base, B, fh, fw, rpn.din, plan["rpn_conv_u"], 512, shift=plan["rpn_conv_b"],
+            x, _, _ = ops.conv3x3_winograd(rfeat, B, fh, fw, rpn.din, plan["rpn_conv_u"], 512, shift=plan["rpn_conv_b"],
                                            relu=True)
         else:
-            x, _, _ = ops.conv2d_nhwc(base, B, fh, fw, rpn.din, plan["rpn_conv_w"], 512, 3, 3, 1, 1,
+            x, _, _ = ops.conv2d_nhwc(rfeat, B, fh, fw, rpn.din, plan["rpn_conv_w"], 512, 3, 3, 1, 1,
                                       shift=plan["rpn_conv_b"], relu=True)
         nh = rpn.nc_score_out + rpn.nc_bbox_out
         heads = ops.gemm_nt(x, plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])
@@ -104,7 +109,8 @@ class FasterRCNN(DAnARCNN):
         R = rois.size(1)
         n_roi = B * R
         P = cfg.POOLING_SIZE
-        # -- RoI pooling (faster_rcnn.py:70-73): both modes of the reference --
+        fh, fw = base_hw
+        # -- RoI pooling (faster_rcnn.py:70-73) on base_feat: both modes of the reference --
         if cfg.POOLING_MODE == "align":
             pooled, _ = ops.roi_align_forward_nhwc(base, B, fh, fw, 1024, 1024, rois.view(-1, 5), 1.0 / 16.0, P, 0)
         elif cfg.POOLING_MODE == "pool":
@@ -113,7 +119,8 @@ class FasterRCNN(DAnARCNN):
             pooled = ops.nchw_to_nhwc(pooled_nchw)
         else:
             raise NotImplementedError("POOLING_MODE '%s'" % cfg.POOLING_MODE)
-        st.update(rois=rois, R=R, n_roi=n_roi, fc7=self._head_to_tail(pooled, n_roi, P, P, plan), plan=plan)
+        st.update(rois=rois, R=R, n_roi=n_roi, pooled=pooled, fc7=self._head_to_tail(pooled, n_roi, P, P, plan),
+                  plan=plan)
         return st
 
     def _head_to_tail(self, x, n, h, w, plan):

@@ -522,6 +522,15 @@ def maxpool3x3s2_ceil(x, B, H, W, C, out=None):
     return out, oh, ow
 
 
+def depthwise_corr(feat, kernels, n_maps, H, W, C, kh, kw, maps_per_kernel=1, feat_stride=0):
+    """F.conv2d(feat, kernel.view(C,1,kh,kw), groups=C) in NHWC: -> ([n_maps*(H-kh+1)*(W-kw+1)][C], oh, ow)"""
+    oh, ow = H - kh + 1, W - kw + 1
+    out = torch.empty((n_maps * oh * ow, C), dtype=torch.float32, device=feat.device)
+    lib().call("dana_depthwise_corr_nhwc", _p(_chk(feat, "feat")), _p(_chk(kernels, "kernels")), _p(out), n_maps, H, W, C,
+               kh, kw, maps_per_kernel, feat_stride, _stream())
+    return out, oh, ow
+
+
 def maxpool2x2s2(x, B, H, W, C):
     _chk(x, "x")
     out = torch.empty((B * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)

@@ -195,6 +195,12 @@ int dana_avgpool_nhwc(const float* in, float* out, int batch, int height, int wi
 /* RCNN_top(pool5).mean(3).mean(2): dana.py:387-389; in[groups][positions][stride] -> out[groups][channels] */
 int dana_spatial_mean_nhwc(const float* in, float* out, int groups, int positions, int channels, long in_pix_stride,
                            dana_stream_t stream);
+/* sibling model `fsod` (framework/fsod.py:109-116, 207-214): depth-wise "valid" cross-correlation
+ * F.conv2d(feat, kernel.view(C, 1, kh, kw), groups=C): out[n][oh][ow][c] = sum feat[n][oh+i][ow+j][c] *
+ * kernels[n / maps_per_kernel][i][j][c]; feat [n_maps][height][width][feat_pix_stride], out [n_maps][oh][ow][channels] */
+int dana_depthwise_corr_nhwc(const float* feat, const float* kernels, float* out, long n_maps, int height, int width,
+                             int channels, int kh, int kw, long maps_per_kernel, long feat_pix_stride,
+                             dana_stream_t stream);
 /* sibling model `meta` (framework/meta.py): nn.MaxPool2d(2) of the PRN (:203,246), nn.Sigmoid (:202,250), and the
  * channel-wise product of the RoI features with their image's class-attentive vector (:136-140) */
 int dana_maxpool2x2s2_nhwc(const float* in, float* out, int batch, int height, int width, int channels,

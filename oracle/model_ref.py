@@ -600,6 +600,73 @@ def meta_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, all_cls
 
 
 # ------------------------------------------------------------------------------------------------
+# sibling model `fsod` (attention-RPN + multi-relation head): lib/model/framework/fsod.py:79-249
+# ------------------------------------------------------------------------------------------------
+def fsod_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_way=2, n_shot=3, nms_inclusive=True):
+    B = im_data.shape[0]
+    base_feat = rcnn_base(im_data, sd)
+    sup = rcnn_base(support_ims.reshape(-1, *support_ims.shape[2:]), sd)
+    if training:
+        sup = sup.view(-1, n_way * n_shot, *sup.shape[1:])
+        pos = F.avg_pool2d(sup[:, :n_shot].mean(1), 14, 1)  # [B,1024,7,7] (fsod.py:98-101)
+        neg = F.avg_pool2d(sup[:, n_shot:n_way * n_shot].mean(1), 14, 1)
+    else:
+        pos = F.avg_pool2d(sup.view(-1, n_shot, *sup.shape[1:]).mean(1), 14, 1)
+    # attention RPN (fsod.py:109-116): depth-wise cross-correlation of the query map with the pooled support
+    corr = torch.stack([F.conv2d(base_feat[b:b + 1], pos[b].view(1024, 1, 7, 7), groups=1024)[0] for b in range(B)], 0)
+    cls, prob, bbox = rpn_head(corr, sd)
+    rois = proposal_layer(prob.detach(), bbox.detach(), im_info, "TRAIN" if training else "TEST", nms_inclusive)
+    rpn_loss_cls = rpn_loss_bbox = 0
+    rois_label = None
+    if training:
+        H, W = cls.shape[2:]
+        lab, tg, w_in, w_out = anchor_target_layer((H, W), gt_boxes, im_info)
+        sc = cls.view(B, 2, -1, W).permute(0, 2, 3, 1).reshape(-1, 2)
+        keep = lab.view(-1).ne(-1).nonzero().view(-1)
+        rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
+        rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
+        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        rois_label = rois_label.view(-1).long()
+        rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
+    pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
+                                                       1.0 / 16.0, 7, 7, 0))
+    R = rois.size(1)
+    n = B * R
+    bbox_pred = _lin(rcnn_top(pooled, sd), sd, "RCNN_bbox_pred")
+
+    def head(support):  # fsod.py:181-249, support [B,1024,7,7]
+        srep = support.view(B, 1, 1024, 7, 7).expand(B, R, 1024, 7, 7).reshape(n, 1024, 7, 7)
+        # global relation
+        gf = torch.cat([pooled, srep], 1).mean(3).mean(2)
+        g = _lin(F.relu(_lin(F.relu(_lin(gf, sd, "global_fc_1")), sd, "global_fc_2")), sd, "global_cls_score")
+        # local correlation
+        cr = F.conv2d(pooled, sd["corr_conv.weight"])
+        cs = F.conv2d(support, sd["corr_conv.weight"])
+        oc = (cr.view(B, R, 1024, 49) * cs.view(B, 1, 1024, 49)).sum(3).view(n, 1024)
+        c = _lin(oc, sd, "corr_cls_score")
+        # patch relation
+        x = F.relu(F.conv2d(torch.cat([pooled, srep], 1), sd["patch_conv_1.weight"]))
+        x = F.avg_pool2d(x, 3, 1)
+        x = F.relu(F.conv2d(x, sd["patch_conv_2.weight"]))
+        x = F.relu(F.conv2d(x, sd["patch_conv_3.weight"]))
+        x = F.avg_pool2d(x, 3, 1).view(n, 1024)
+        pt = _lin(x, sd, "patch_cls_score")
+        score = (g + c + pt) / 10.0
+        return F.softmax(score, 1), score
+
+    cls_prob, cls_score = head(pos)
+    loss_cls = loss_bbox = 0
+    if training:
+        neg_prob, neg_score = head(neg)
+        cls_prob = torch.cat([cls_prob, neg_prob], 0)
+        cls_score = torch.cat([cls_score, neg_score], 0)
+        rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
+        loss_bbox = smooth_l1(bbox_pred, rois_target, rw_in, rw_out)
+        loss_cls = mined_cross_entropy(cls_score, rois_label)
+    return rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, loss_cls, loss_bbox, rois_label
+
+
+# ------------------------------------------------------------------------------------------------
 # sibling model on the same ops: plain Faster R-CNN, lib/model/framework/faster_rcnn.py:35-103
 # ------------------------------------------------------------------------------------------------
 def frcnn_forward(sd, im_data, im_info, gt_boxes, num_boxes, training, nms_inclusive=True, pooling="align"):

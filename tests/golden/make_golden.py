@@ -242,6 +242,35 @@ def e2e_meta(tag, training, B, way, shot, H, W, nms_seed=7):
     save("e2e_meta_" + tag, **store)
 
 
+def e2e_fsod(tag, training, B, way, shot, H, W, nms_seed=7):
+    """the sibling `fsod` model (utils.py:111-112)"""
+    m = R.build_fsod(way, shot)
+    sd = S.tame_fsod_weights(S.fill_state_dict(m.state_dict(), seed=19, profile="test"))
+    m.load_state_dict(sd)
+    im_data, im_info, gt, nb, sup = S.episode_inputs(B, way if training else 1, shot, H, W, seed=1996)
+    m.train() if training else m.eval()
+    np.random.seed(nms_seed)
+    with torch.no_grad():
+        out_ref = m(im_data, im_info, gt, nb, sup)
+    np.random.seed(nms_seed)
+    with torch.no_grad():
+        out_or = O.fsod_forward(sd, im_data, im_info, gt, nb, sup, training, way, shot, nms_inclusive=True)
+    names = ["rois", "cls_prob", "bbox_pred", "rpn_loss_cls", "rpn_loss_bbox", "RCNN_loss_cls", "RCNN_loss_bbox",
+             "rois_label"]
+    store = {}
+    for n, a, b in zip(names, out_ref, out_or):
+        if a is None or (not torch.is_tensor(a) and a == 0):
+            assert b is None or (not torch.is_tensor(b) and b == 0), n
+            continue
+        a, b = a.detach(), b.detach()
+        diff = (a.float() - b.float()).abs().max().item() if a.numel() else 0.0
+        print("  %-16s ref-vs-oracle max|d| = %.3e" % (n, diff))
+        assert diff <= {"rois": 1e-3, "rois_label": 0.0}.get(n, 2e-5), (n, diff)
+        store[n] = a.numpy()
+    store["meta"] = np.array([int(training), B, way, shot, H, W, 19, 1996, nms_seed])
+    save("e2e_fsod_" + tag, **store)
+
+
 if __name__ == "__main__":
     assert R.available(), "reference not present: golden vectors can only be (re)generated in the build container"
     ref = R.load()
@@ -250,6 +279,8 @@ if __name__ == "__main__":
         print("eval 192x256 BA off"); e2e("eval_small_cisa", False, False, 1, 1, 3, 192, 256)
         print("eval 192x256 BA on"); e2e("eval_small_ba", True, False, 1, 1, 3, 192, 256)
         print("train 192x256 B=2 BA on"); e2e("train_small_ba", True, True, 2, 2, 3, 192, 256)
+        print("fsod eval 192x256"); e2e_fsod("eval_small", False, 1, 1, 3, 192, 256)
+        print("fsod train 192x256 B=2"); e2e_fsod("train_small", True, 2, 2, 3, 192, 256)
         print("meta eval 192x256"); e2e_meta("eval_small", False, 1, 1, 3, 192, 256)
         print("meta train 192x256 B=2"); e2e_meta("train_small", True, 2, 2, 3, 192, 256)
         print("frcnn eval 192x256"); e2e_frcnn("eval_small", False, 1, 192, 256)

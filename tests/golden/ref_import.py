@@ -118,3 +118,12 @@ def build_meta(way, shot):
     m = meta.METARCNN(["fg", "bg"], pretrained=False, num_way=way, num_shot=shot)
     m.create_architecture()
     return m
+
+
+def build_fsod(way, shot):
+    """the reference's FSOD sibling (lib/model/framework/fsod.py:252-327): attention RPN + multi-relation head"""
+    load()
+    from model.framework import fsod
+    m = fsod.FSOD(["fg", "bg"], pretrained=False, num_way=way, num_shot=shot)
+    m.create_architecture()
+    return m

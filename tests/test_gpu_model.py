@@ -353,3 +353,33 @@ def test_meta_sibling_matches_reference_golden(golden_dir, dev, tag):
             assert np.array_equal(out[7].cpu().numpy(), g["rois_label"])
             for i, name in ((3, "rpn_loss_cls"), (4, "rpn_loss_bbox"), (5, "RCNN_loss_cls"), (6, "RCNN_loss_bbox")):
                 assert abs(float(out[i]) - float(g[name])) <= 1e-4 * max(1.0, abs(float(g[name]))), name
+
+
+@pytest.mark.parametrize("tag", ["eval_small", "train_small"])
+def test_fsod_sibling_matches_reference_golden(golden_dir, dev, tag):
+    """get_model('fsod') (utils.py:111-112) on the same HIP operators vs the reference's own outputs"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    g = _load(golden_dir, "fsod_" + tag)
+    training, B, way, shot, H, W, wseed, iseed, nseed = [int(v) for v in g["meta"]]
+    m = dana_amd.get_model("fsod", pretrained=False, way=way, shot=shot, classes=["fg", "bg"])
+    m.load_state_dict(S.tame_fsod_weights(S.fill_state_dict(m.state_dict(), seed=wseed, profile="test")))
+    m.to(dev)
+    m.nms_inclusive = True
+    m.train() if training else m.eval()
+    inputs = S.episode_inputs(B, way if training else 1, shot, H, W, seed=iseed)
+    np.random.seed(nseed)
+    with torch.no_grad():
+        out = m(*[t.to(dev) for t in inputs])
+    r, rg = out[0].cpu().numpy().reshape(-1, 5), g["rois"].reshape(-1, 5)
+    matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
+    assert matched.mean() >= 0.97
+    if not training:
+        assert matched.all()
+    if matched.all():
+        assert np.abs(out[1].cpu().numpy() - g["cls_prob"]).max() <= 1e-4
+        assert np.abs(out[2].cpu().numpy() - g["bbox_pred"]).max() <= 1e-4
+        if training:
+            assert np.array_equal(out[7].cpu().numpy(), g["rois_label"])
+            for i, name in ((3, "rpn_loss_cls"), (4, "rpn_loss_bbox"), (5, "RCNN_loss_cls"), (6, "RCNN_loss_bbox")):
+                assert abs(float(out[i]) - float(g[name])) <= 1e-4 * max(1.0, abs(float(g[name]))), name

@@ -179,3 +179,27 @@ def test_oracle_meta_reproduces_reference_outputs(golden_dir, tag):
         assert np.array_equal(out[7].numpy(), g["rois_label"])
         for i, name in ((3, "rpn_loss_cls"), (4, "rpn_loss_bbox"), (5, "RCNN_loss_cls"), (6, "RCNN_loss_bbox")):
             assert abs(float(out[i]) - float(g[name])) <= 2e-5, name
+
+
+@pytest.mark.parametrize("tag", ["eval_small", "train_small"])
+def test_oracle_fsod_reproduces_reference_outputs(golden_dir, tag):
+    """sibling `fsod` (attention RPN + multi-relation head, fsod.py:79-249): oracle restatement vs the reference"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    g = np.load(os.path.join(golden_dir, "e2e_fsod_%s.npz" % tag))
+    training, B, way, shot, H, W, wseed, iseed, nseed = [int(v) for v in g["meta"]]
+    m = dana_amd.get_model("fsod", pretrained=False, way=way, shot=shot, classes=["fg", "bg"])
+    assert len(m.state_dict()) == 340 and "patch_conv_2.weight" in m.state_dict()
+    sd = S.tame_fsod_weights(S.fill_state_dict(m.state_dict(), seed=wseed, profile="test"))
+    im_data, im_info, gt, nb, sup = S.episode_inputs(B, way if training else 1, shot, H, W, seed=iseed)
+    np.random.seed(nseed)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        out = O.fsod_forward(sd, im_data, im_info, gt, nb, sup, bool(training), way, shot, nms_inclusive=True)
+    assert np.abs(out[0].numpy() - g["rois"]).max() <= 1e-3
+    assert np.abs(out[1].numpy() - g["cls_prob"]).max() <= 2e-5
+    assert np.abs(out[2].numpy() - g["bbox_pred"]).max() <= 2e-5
+    if training:
+        assert np.array_equal(out[7].numpy(), g["rois_label"])
+        for i, name in ((3, "rpn_loss_cls"), (4, "rpn_loss_bbox"), (5, "RCNN_loss_cls"), (6, "RCNN_loss_bbox")):
+            assert abs(float(out[i]) - float(g[name])) <= 2e-5, name
