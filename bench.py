@@ -40,8 +40,8 @@ def parse():
     ap.add_argument("--shot", type=int, default=3)
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
-    ap.add_argument("--model", default="DAnA", choices=["DAnA", "frcnn", "fsod", "meta"],
-                    help="DAnA: the hot path (default); frcnn / fsod / meta: the sibling detectors of utils.py:109-114 (row N4) "
+    ap.add_argument("--model", default="DAnA", choices=["DAnA", "frcnn", "fsod", "meta", "fgn"],
+                    help="DAnA: the hot path (default); frcnn / fsod / meta / fgn: the sibling detectors of utils.py:109-116 (row N4) "
                          "on the same operators -- forward modes only")
     ap.add_argument("--support-size", type=int, default=320,
                     help="support image side. 320 = the only size the reference can run (it hard-codes the 20x20 map); "

@@ -82,6 +82,41 @@ colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, 
   if (rl == 0 && col < C)
     partial[(long)blockIdx.y * C + col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
+// partial[chunk][c] = sum over the chunk's rows of (x[r][c] - mean[c])^2  (BatchNorm batch variance, second pass)
+__global__ void __launch_bounds__(256)
+colsqdev_partial_kernel(const float* __restrict__ x, const float* __restrict__ mean, float* __restrict__ partial,
+                        long rows, int C, long ld) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  float s = 0.f;
+  if (col < C) {
+    const float m = mean[col];
+    for (long r = r0 + rl; r < r1; r += 4) {
+      const float d = x[r * ld + col] - m;
+      s += d * d;
+    }
+  }
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < C)
+    partial[(long)blockIdx.y * C + col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// x[r][c] = relu?(x[r][c] * scale[c] + shift[c]), in place (a BatchNorm applied after the conv's residual sum)
+__global__ void __launch_bounds__(256)
+scale_shift_relu_kernel(float4* __restrict__ x, const float4* __restrict__ scale, const float4* __restrict__ shift,
+                        long total, int C4, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const float4 v = x[i], sc = scale[c], sh = shift[c];
+    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    x[i] = o;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int chunks, int C, float alpha,
                     int accumulate) {
@@ -249,6 +284,42 @@ int dana_colsum(const float* x, float* out, long rows, int channels, long ld, fl
   colsum_final_kernel<<<dana_ceil_div(channels, 256), 256, 0, (hipStream_t)stream>>>((const float*)workspace, out, chunks,
                                                                                       channels, alpha, accumulate);
   DANA_CHECK_LAUNCH("dana_colsum(final)");
+  return DANA_OK;
+}
+
+int dana_batch_stats(const float* x, float* mean, float* var_biased, long rows, int channels, long ld, void* workspace,
+                     size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(rows > 0 && channels > 0 && x && mean && var_biased, "dana_batch_stats: bad args");
+  if (ld <= 0) ld = channels;
+  const size_t need = dana_colsum_workspace_bytes(rows, channels);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("dana_batch_stats: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  const int chunks = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+  DANA_CHECK_ARG(chunks <= 65535, "dana_batch_stats: too many rows");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(dana_ceil_div(channels, 64), chunks);
+  const float inv = 1.f / (float)rows;
+  colsum_partial_kernel<<<grid, 256, 0, s>>>(x, (float*)workspace, rows, channels, ld);
+  colsum_final_kernel<<<dana_ceil_div(channels, 256), 256, 0, s>>>((const float*)workspace, mean, chunks, channels, inv, 0);
+  colsqdev_partial_kernel<<<grid, 256, 0, s>>>(x, mean, (float*)workspace, rows, channels, ld);
+  colsum_final_kernel<<<dana_ceil_div(channels, 256), 256, 0, s>>>((const float*)workspace, var_biased, chunks, channels,
+                                                                  inv, 0);
+  DANA_CHECK_LAUNCH("dana_batch_stats");
+  return DANA_OK;
+}
+
+int dana_scale_shift_relu(float* x, const float* scale, const float* shift, long rows, int channels, int relu,
+                          dana_stream_t stream) {
+  DANA_CHECK_ARG(rows >= 0 && channels > 0 && channels % 4 == 0, "dana_scale_shift_relu: bad shape");
+  if (rows == 0) return DANA_OK;
+  DANA_CHECK_ARG(x && scale && shift, "dana_scale_shift_relu: null pointer");
+  const long total = rows * (channels / 4);
+  scale_shift_relu_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((float4*)x, (const float4*)scale,
+                                                                                 (const float4*)shift, total,
+                                                                                 channels / 4, relu);
+  DANA_CHECK_LAUNCH("dana_scale_shift_relu");
   return DANA_OK;
 }
 

@@ -531,6 +531,22 @@ def depthwise_corr(feat, kernels, n_maps, H, W, C, kh, kw, maps_per_kernel=1, fe
     return out, oh, ow
 
 
+def batch_stats(x, rows, channels, ld=0):
+    """per-channel (mean, biased variance) over the rows: what nn.BatchNorm2d normalises with in train mode"""
+    _chk(x, "x")
+    mean = torch.empty((channels,), dtype=torch.float32, device=x.device)
+    var = torch.empty_like(mean)
+    ws = _ws(lib().query("dana_colsum_workspace_bytes", rows, channels), x.device)
+    lib().call("dana_batch_stats", _p(x), _p(mean), _p(var), rows, channels, ld, _p(ws), ws.numel(), _stream())
+    return mean, var
+
+
+def scale_shift_relu_(x, scale, shift, rows, channels, relu=True):
+    lib().call("dana_scale_shift_relu", _p(_chk(x, "x")), _p(_chk(scale, "scale")), _p(_chk(shift, "shift")), rows,
+               channels, int(bool(relu)), _stream())
+    return x
+
+
 def maxpool2x2s2(x, B, H, W, C):
     _chk(x, "x")
     out = torch.empty((B * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)

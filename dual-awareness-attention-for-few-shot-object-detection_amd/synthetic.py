@@ -117,3 +117,12 @@ def tame_fsod_weights(sd):
     sd["RCNN_rpn.RPN_Conv.weight"] = sd["RCNN_rpn.RPN_Conv.weight"] * 0.01
     sd["corr_cls_score.weight"] = sd["corr_cls_score.weight"] * 0.02
     return sd
+
+
+def tame_fgn_weights(sd):
+    """test-profile weights for the `fgn` sibling: its RPN runs on base_feat * mean(support) (magnitude ~7x base_feat),
+    so RPN_Conv is scaled down to keep the objectness logits away from saturation (exactly tied scores make the proposal
+    order arbitrary). Applied identically by the golden generator and the tests."""
+    sd = dict(sd)
+    sd["RCNN_rpn.RPN_Conv.weight"] = sd["RCNN_rpn.RPN_Conv.weight"] * 0.1
+    return sd

@@ -195,6 +195,14 @@ int dana_avgpool_nhwc(const float* in, float* out, int batch, int height, int wi
 /* RCNN_top(pool5).mean(3).mean(2): dana.py:387-389; in[groups][positions][stride] -> out[groups][channels] */
 int dana_spatial_mean_nhwc(const float* in, float* out, int groups, int positions, int channels, long in_pix_stride,
                            dana_stream_t stream);
+/* sibling model `fgn` (framework/fgn.py:36-39,156-161): its head's nn.BatchNorm2d layers are NOT frozen. Batch
+ * statistics over rows (= N*H*W) per channel, two passes (mean, then biased variance about it); workspace:
+ * dana_colsum_workspace_bytes(rows, channels). dana_bn_fold turns (gamma, beta, mean, var) into scale / shift for
+ * dana_scale_shift_relu: x = relu?(x * scale + shift), in place. */
+int dana_batch_stats(const float* x, float* mean, float* var_biased, long rows, int channels, long ld, void* workspace,
+                     size_t workspace_bytes, dana_stream_t stream);
+int dana_scale_shift_relu(float* x, const float* scale, const float* shift, long rows, int channels, int relu,
+                          dana_stream_t stream);
 /* sibling model `fsod` (framework/fsod.py:109-116, 207-214): depth-wise "valid" cross-correlation
  * F.conv2d(feat, kernel.view(C, 1, kh, kw), groups=C): out[n][oh][ow][c] = sum feat[n][oh+i][ow+j][c] *
  * kernels[n / maps_per_kernel][i][j][c]; feat [n_maps][height][width][feat_pix_stride], out [n_maps][oh][ow][channels] */

@@ -667,6 +667,70 @@ def fsod_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, trainin
 
 
 # ------------------------------------------------------------------------------------------------
+# sibling model `fgn`: lib/model/framework/fgn.py:45-165. Its head's bn1 / bn2 are ordinary BatchNorm layers: batch
+# statistics (and running-stat updates) in train mode, running statistics in eval mode.
+# ------------------------------------------------------------------------------------------------
+def fgn_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_way=2, n_shot=3, nms_inclusive=True,
+                bn_state=None):
+    """bn_state: dict that receives the updated running statistics of bn1 / bn2 (train mode)"""
+    B = im_data.shape[0]
+    base_feat = rcnn_base(im_data, sd)
+    sup = rcnn_base(support_ims.reshape(-1, *support_ims.shape[2:]), sd)
+    if training:
+        sup = sup.view(-1, n_way * n_shot, *sup.shape[1:])
+        pos_map, neg_map = sup[:, :n_shot].mean(1), sup[:, n_shot:n_way * n_shot].mean(1)
+        neg_rcnn = F.avg_pool2d(neg_map, 14, 1)
+    else:
+        pos_map = sup.view(-1, n_shot, *sup.shape[1:]).mean(1)
+    pos_rpn = F.avg_pool2d(pos_map, 20)       # [B,1024,1,1]
+    pos_rcnn = F.avg_pool2d(pos_map, 14, 1)   # [B,1024,7,7]
+    cls, prob, bbox = rpn_head(base_feat * pos_rpn, sd)  # attention RPN (fgn.py:75-82)
+    rois = proposal_layer(prob.detach(), bbox.detach(), im_info, "TRAIN" if training else "TEST", nms_inclusive)
+    rpn_loss_cls = rpn_loss_bbox = 0
+    rois_label = None
+    if training:
+        H, W = cls.shape[2:]
+        lab, tg, w_in, w_out = anchor_target_layer((H, W), gt_boxes, im_info)
+        sc = cls.view(B, 2, -1, W).permute(0, 2, 3, 1).reshape(-1, 2)
+        keep = lab.view(-1).ne(-1).nonzero().view(-1)
+        rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
+        rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
+        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        rois_label = rois_label.view(-1).long()
+        rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
+    pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
+                                                       1.0 / 16.0, 7, 7, 0))
+    R = rois.size(1)
+    n = B * R
+    bbox_pred = _lin(rcnn_top(pooled, sd), sd, "RCNN_bbox_pred")
+    run = {k: sd[k].clone() for k in ("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var")}
+
+    def bn(x, p):
+        return F.batch_norm(x, run[p + ".running_mean"], run[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                            training, 0.1, 1e-5)
+
+    def head(support):  # fgn.py:145-165
+        comb = torch.cat([support.view(B, 1, 1024, 7, 7).expand(B, R, 1024, 7, 7).reshape(n, 1024, 7, 7), pooled], 1)
+        x = F.relu(bn(F.conv2d(comb, sd["cls_conv1.weight"]), "bn1"))
+        x = F.relu(bn(F.conv2d(x, sd["cls_conv2.weight"]), "bn2"))
+        score = _lin(x.reshape(n, -1), sd, "RCNN_cls_score")
+        return F.softmax(score, 1), score
+
+    cls_prob, cls_score = head(pos_rcnn)
+    loss_cls = loss_bbox = 0
+    if training:
+        neg_prob, neg_score = head(neg_rcnn)
+        cls_prob = torch.cat([cls_prob, neg_prob], 0)
+        cls_score = torch.cat([cls_score, neg_score], 0)
+        rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
+        loss_bbox = smooth_l1(bbox_pred, rois_target, rw_in, rw_out)
+        loss_cls = mined_cross_entropy(cls_score, rois_label)
+    if bn_state is not None:
+        bn_state.update(run)
+    return rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, loss_cls, loss_bbox, rois_label
+
+
+# ------------------------------------------------------------------------------------------------
 # sibling model on the same ops: plain Faster R-CNN, lib/model/framework/faster_rcnn.py:35-103
 # ------------------------------------------------------------------------------------------------
 def frcnn_forward(sd, im_data, im_info, gt_boxes, num_boxes, training, nms_inclusive=True, pooling="align"):

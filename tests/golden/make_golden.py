@@ -271,6 +271,43 @@ def e2e_fsod(tag, training, B, way, shot, H, W, nms_seed=7):
     save("e2e_fsod_" + tag, **store)
 
 
+def e2e_fgn(tag, training, B, way, shot, H, W, nms_seed=7):
+    """the sibling `fgn` model (utils.py:115-116); its head's BatchNorm layers run on batch statistics in train mode"""
+    m = R.build_fgn(way, shot)
+    sd = S.tame_fgn_weights(S.fill_state_dict(m.state_dict(), seed=23, profile="test"))
+    m.load_state_dict(sd)
+    im_data, im_info, gt, nb, sup = S.episode_inputs(B, way if training else 1, shot, H, W, seed=1996)
+    m.train() if training else m.eval()
+    np.random.seed(nms_seed)
+    with torch.no_grad():
+        out_ref = m(im_data, im_info, gt, nb, sup)
+    np.random.seed(nms_seed)
+    bn_state = {}
+    with torch.no_grad():
+        out_or = O.fgn_forward(sd, im_data, im_info, gt, nb, sup, training, way, shot, nms_inclusive=True,
+                               bn_state=bn_state)
+    names = ["rois", "cls_prob", "bbox_pred", "rpn_loss_cls", "rpn_loss_bbox", "RCNN_loss_cls", "RCNN_loss_bbox",
+             "rois_label"]
+    store = {}
+    for n, a, b in zip(names, out_ref, out_or):
+        if a is None or (not torch.is_tensor(a) and a == 0):
+            assert b is None or (not torch.is_tensor(b) and b == 0), n
+            continue
+        a, b = a.detach(), b.detach()
+        diff = (a.float() - b.float()).abs().max().item() if a.numel() else 0.0
+        print("  %-16s ref-vs-oracle max|d| = %.3e" % (n, diff))
+        assert diff <= {"rois": 1e-3, "rois_label": 0.0}.get(n, 2e-5), (n, diff)
+        store[n] = a.numpy()
+    after = m.state_dict()
+    for k in ("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var"):
+        d = (after[k] - bn_state[k]).abs().max().item()
+        print("  %-16s ref-vs-oracle max|d| = %.3e" % (k, d))
+        assert d <= 1e-5 * max(1.0, after[k].abs().max().item()), (k, d)
+        store[k] = after[k].numpy()
+    store["meta"] = np.array([int(training), B, way, shot, H, W, 23, 1996, nms_seed])
+    save("e2e_fgn_" + tag, **store)
+
+
 if __name__ == "__main__":
     assert R.available(), "reference not present: golden vectors can only be (re)generated in the build container"
     ref = R.load()
@@ -279,6 +316,8 @@ if __name__ == "__main__":
         print("eval 192x256 BA off"); e2e("eval_small_cisa", False, False, 1, 1, 3, 192, 256)
         print("eval 192x256 BA on"); e2e("eval_small_ba", True, False, 1, 1, 3, 192, 256)
         print("train 192x256 B=2 BA on"); e2e("train_small_ba", True, True, 2, 2, 3, 192, 256)
+        print("fgn eval 192x256"); e2e_fgn("eval_small", False, 1, 1, 3, 192, 256)
+        print("fgn train 192x256 B=2"); e2e_fgn("train_small", True, 2, 2, 3, 192, 256)
         print("fsod eval 192x256"); e2e_fsod("eval_small", False, 1, 1, 3, 192, 256)
         print("fsod train 192x256 B=2"); e2e_fsod("train_small", True, 2, 2, 3, 192, 256)
         print("meta eval 192x256"); e2e_meta("eval_small", False, 1, 1, 3, 192, 256)

@@ -127,3 +127,12 @@ def build_fsod(way, shot):
     m = fsod.FSOD(["fg", "bg"], pretrained=False, num_way=way, num_shot=shot)
     m.create_architecture()
     return m
+
+
+def build_fgn(way, shot):
+    """the reference's FGN sibling (lib/model/framework/fgn.py:190-259)"""
+    load()
+    from model.framework import fgn
+    m = fgn.FGN(["fg", "bg"], pretrained=False, num_way=way, num_shot=shot)
+    m.create_architecture()
+    return m

@@ -203,3 +203,32 @@ def test_oracle_fsod_reproduces_reference_outputs(golden_dir, tag):
         assert np.array_equal(out[7].numpy(), g["rois_label"])
         for i, name in ((3, "rpn_loss_cls"), (4, "rpn_loss_bbox"), (5, "RCNN_loss_cls"), (6, "RCNN_loss_bbox")):
             assert abs(float(out[i]) - float(g[name])) <= 2e-5, name
+
+
+@pytest.mark.parametrize("tag", ["eval_small", "train_small"])
+def test_oracle_fgn_reproduces_reference_outputs(golden_dir, tag):
+    """sibling `fgn` (fgn.py:45-165; train-mode BatchNorm in its head): oracle restatement vs the reference, including
+    the running statistics the forward leaves behind"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    g = np.load(os.path.join(golden_dir, "e2e_fgn_%s.npz" % tag))
+    training, B, way, shot, H, W, wseed, iseed, nseed = [int(v) for v in g["meta"]]
+    m = dana_amd.get_model("fgn", pretrained=False, way=way, shot=shot, classes=["fg", "bg"])
+    assert len(m.state_dict()) == 340 and "bn2.running_var" in m.state_dict()
+    sd = S.tame_fgn_weights(S.fill_state_dict(m.state_dict(), seed=wseed, profile="test"))
+    im_data, im_info, gt, nb, sup = S.episode_inputs(B, way if training else 1, shot, H, W, seed=iseed)
+    np.random.seed(nseed)
+    torch.set_num_threads(8)
+    bn_state = {}
+    with torch.no_grad():
+        out = O.fgn_forward(sd, im_data, im_info, gt, nb, sup, bool(training), way, shot, nms_inclusive=True,
+                            bn_state=bn_state)
+    assert np.abs(out[0].numpy() - g["rois"]).max() <= 1e-3
+    assert np.abs(out[1].numpy() - g["cls_prob"]).max() <= 2e-5
+    assert np.abs(out[2].numpy() - g["bbox_pred"]).max() <= 2e-5
+    for k in ("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var"):
+        assert np.abs(bn_state[k].numpy() - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k
+    if training:
+        assert np.array_equal(out[7].numpy(), g["rois_label"])
+        for i, name in ((3, "rpn_loss_cls"), (4, "rpn_loss_bbox"), (5, "RCNN_loss_cls"), (6, "RCNN_loss_bbox")):
+            assert abs(float(out[i]) - float(g[name])) <= 2e-5, name
