@@ -375,6 +375,31 @@ int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const floa
 // ---- attention adjoints ---------------------------------------------------------------------------------
 namespace {
 
+// torch.optim.Adam (train.py:84-85), one flat segment: g' = grad_scale * g + wd * p; m = b1 m + (1-b1) g';
+// v = b2 v + (1-b2) g'^2; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps,
+                                      float wd, float gs, float bc1, float bc2) {
+  g = g * gs + wd * p;
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  p -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + eps);
+}
+__global__ void __launch_bounds__(256)
+adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v, long n4,
+            float lr, float b1, float b2, float eps, float wd, float gs, float bc1, float bc2) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)blockDim.x * gridDim.x) {
+    float4 pv = p[i], mv = m[i], vv = v[i];
+    const float4 gv = g[i];
+    adam1(pv.x, gv.x, mv.x, vv.x, lr, b1, b2, eps, wd, gs, bc1, bc2);
+    adam1(pv.y, gv.y, mv.y, vv.y, lr, b1, b2, eps, wd, gs, bc1, bc2);
+    adam1(pv.z, gv.z, mv.z, vv.z, lr, b1, b2, eps, wd, gs, bc1, bc2);
+    adam1(pv.w, gv.w, mv.w, vv.w, lr, b1, b2, eps, wd, gs, bc1, bc2);
+    p[i] = pv;
+    m[i] = mv;
+    v[i] = vv;
+  }
+}
+
 // x[i] *= s[0] with the scalar in device memory (upstream loss gradients never visit the host)
 __global__ void __launch_bounds__(256) scale_by_dev_kernel(float* __restrict__ x, long n, const float* __restrict__ s) {
   const float v = s[0];
@@ -568,6 +593,19 @@ int dana_scale_by_device_scalar(float* x, long n, const float* scalar_dev, dana_
   DANA_CHECK_ARG(x && scalar_dev, "dana_scale_by_device_scalar: null pointer");
   scale_by_dev_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(x, n, scalar_dev);
   DANA_CHECK_LAUNCH("dana_scale_by_device_scalar");
+  return DANA_OK;
+}
+
+int dana_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+              float beta2, float eps, float weight_decay, float grad_scale, int step, dana_stream_t stream) {
+  DANA_CHECK_ARG(n >= 0 && n % 4 == 0 && step >= 1, "dana_adam: n must be a multiple of 4 and step >= 1");
+  if (n == 0) return DANA_OK;
+  DANA_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "dana_adam: null pointer");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  adam_kernel<<<grid_for(n / 4, 256), 256, 0, (hipStream_t)stream>>>((float4*)params, (const float4*)grads,
+                                                                    (float4*)exp_avg, (float4*)exp_avg_sq, n / 4, lr, beta1,
+                                                                    beta2, eps, weight_decay, grad_scale, bc1, bc2);
+  DANA_CHECK_LAUNCH("dana_adam");
   return DANA_OK;
 }
 

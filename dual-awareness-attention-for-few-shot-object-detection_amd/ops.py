@@ -900,3 +900,11 @@ def sgd_momentum_(params, grads, buf, lr, momentum, weight_decay, grad_scale=1.0
     lib().call("dana_sgd_momentum", _p(_chk(params, "params")), _p(_chk(grads, "grads")), _p(_chk(buf, "buf")), n,
                float(lr), float(momentum), float(weight_decay), float(grad_scale), int(bool(first_step)), _stream())
     return params
+
+
+def adam_(params, grads, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """fused torch.optim.Adam update of one flat fp32 segment (numel % 4 == 0), in place; step counts from 1"""
+    lib().call("dana_adam", _p(_chk(params, "params")), _p(_chk(grads, "grads")), _p(_chk(exp_avg, "exp_avg")),
+               _p(_chk(exp_avg_sq, "exp_avg_sq")), params.numel(), float(lr), float(beta1), float(beta2), float(eps),
+               float(weight_decay), float(grad_scale), int(step), _stream())
+    return params

@@ -107,7 +107,10 @@ class FlatBuckets:
 
 class Trainer:
     def __init__(self, model, lr, momentum=None, weight_decay=None, double_bias=None, bias_decay=None,
-                 process_group=None, bucket_bytes=32 << 20):
+                 process_group=None, bucket_bytes=32 << 20, optimizer="sgd"):
+        if optimizer not in ("sgd", "adam"):  # train.py:84-87
+            raise ValueError("optimizer must be 'sgd' or 'adam'")
+        self.optimizer = optimizer
         self.model = model
         self.lr = float(lr)
         self.momentum = float(cfg.TRAIN.MOMENTUM if momentum is None else momentum)
@@ -125,7 +128,8 @@ class Trainer:
         self.weights = FlatBuckets([(n, params[n]) for n in w_names], bucket_bytes, process_group)
         self.biases = FlatBuckets([(n, params[n]) for n in b_names], bucket_bytes, process_group)
         self.groups = [(self.weights, 1.0, wd), (self.biases, float(double_bias) + 1.0, wd if bias_decay else 0.0)]
-        self.bufs = [torch.zeros_like(fb.params) for fb, _, _ in self.groups]
+        self.bufs = [torch.zeros_like(fb.params) for fb, _, _ in self.groups]  # SGD momentum / Adam exp_avg
+        self.bufs2 = [torch.zeros_like(fb.params) for fb, _, _ in self.groups] if optimizer == "adam" else None
         self.steps = 0
         model._plan = None  # parameter storage moved: re-pack on the next forward
         model._grad_ready_cb = self._on_ready
@@ -156,8 +160,12 @@ class Trainer:
         from . import ops
         for (fb, lr_mult, wd), buf in zip(self.groups, self.bufs):
             fb.wait_all()
-            ops.sgd_momentum_(fb.params, fb.grads, buf, self.lr * lr_mult, self.momentum, wd,
-                              grad_scale=1.0 / fb.world, first_step=self.steps == 0)
+            if self.optimizer == "adam":
+                ops.adam_(fb.params, fb.grads, buf, self.bufs2[self.groups.index((fb, lr_mult, wd))], self.lr * lr_mult,
+                          self.steps + 1, weight_decay=wd, grad_scale=1.0 / fb.world)
+            else:
+                ops.sgd_momentum_(fb.params, fb.grads, buf, self.lr * lr_mult, self.momentum, wd,
+                                  grad_scale=1.0 / fb.world, first_step=self.steps == 0)
         self.steps += 1
         self.model._epoch += 1  # weights changed under the packed / Winograd-transformed copies: re-derive those
 
@@ -190,14 +198,22 @@ class Trainer:
     def state_dict(self):
         """optimizer state in the parameters' logical (OIHW) shapes, like torch.optim.SGD's momentum_buffer entries"""
         mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
-        return {"lr": self.lr, "momentum": self.momentum, "steps": self.steps,
-                "momentum_buffer": {n: v.detach().clone().contiguous() for n, v in mom.items()}}
+        out = {"lr": self.lr, "momentum": self.momentum, "steps": self.steps, "optimizer": self.optimizer,
+               "momentum_buffer": {n: v.detach().clone().contiguous() for n, v in mom.items()}}
+        if self.optimizer == "adam":
+            sq = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs2)])
+            out["exp_avg_sq"] = {n: v.detach().clone().contiguous() for n, v in sq.items()}
+        return out
 
     def load_state_dict(self, state):
         self.lr, self.momentum, self.steps = float(state["lr"]), float(state["momentum"]), int(state["steps"])
         mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
         for n, v in mom.items():
             v.copy_(state["momentum_buffer"][n])
+        if self.optimizer == "adam":
+            sq = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs2)])
+            for n, v in sq.items():
+                v.copy_(state["exp_avg_sq"][n])
 
     def adjust_learning_rate(self, decay=0.1):
         """net_utils.adjust_learning_rate (train.py:118-120)"""

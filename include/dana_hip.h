@@ -350,6 +350,9 @@ int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const floa
  * g' = grad_scale * g + weight_decay * p; buf = first_step ? g' : momentum * buf + g'; p -= lr * buf */
 int dana_sgd_momentum(float* params, const float* grads, float* momentum_buf, long n, float lr, float momentum,
                       float weight_decay, float grad_scale, int first_step, dana_stream_t stream);
+/* torch.optim.Adam over a flat fp32 segment (train.py:84-85; defaults betas (0.9, 0.999), eps 1e-8): step = 1, 2, ... */
+int dana_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+              float beta2, float eps, float weight_decay, float grad_scale, int step, dana_stream_t stream);
 /* adjoint of dana_rowdot: grad_w[dim] (+)= sum_r grad_out[r] x[r]; grad_x[r] += grad_out[r] w (grad_x may be NULL);
  * workspace: dana_colsum_workspace_bytes(rows, dim) */
 int dana_rowdot_backward(const float* x, const float* grad_out, const float* w, float* grad_x, float* grad_w, long rows,

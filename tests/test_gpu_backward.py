@@ -248,3 +248,53 @@ def test_checkpoint_resume_reproduces_the_next_iteration(dev):
     for k in pa:  # (RoIAlign backward accumulates with float atomics, like the reference's: equal up to summation order)
         d = (pa[k].detach() - pb[k].detach()).abs().max().item()
         assert d <= 1e-6 + 1e-5 * pa[k].detach().abs().max().item(), (k, d)
+
+
+def test_trainer_adam_matches_torch_adam(dev):
+    """train.py:84-85 (--o adam): two iterations through the autograd bridge + torch.optim.Adam vs Trainer(optimizer='adam')"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    from dana_amd.config import cfg
+    from dana_amd.trainer import Trainer
+    lr = 1e-3
+
+    def build():
+        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=2, shot=2, classes=["fg", "bg"])
+        m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=5, profile="test"))
+        return m.to(dev).train()
+
+    inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=6)]
+    ma, mb = build(), build()
+    groups = []
+    for key, value in dict(ma.named_parameters()).items():
+        if value.requires_grad:
+            if "bias" in key:
+                groups.append({"params": [value], "lr": lr * (cfg.TRAIN.DOUBLE_BIAS + 1),
+                               "weight_decay": cfg.TRAIN.BIAS_DECAY and cfg.TRAIN.WEIGHT_DECAY or 0})
+            else:
+                groups.append({"params": [value], "lr": lr, "weight_decay": cfg.TRAIN.WEIGHT_DECAY})
+    opt = torch.optim.Adam(groups)
+    tr = Trainer(mb, lr, optimizer="adam")
+    for it in range(2):
+        np.random.seed(40 + it)
+        ma.zero_grad()
+        out = ma(*inputs)
+        loss = out[3].mean() + out[4].mean() + out[5].mean() + out[6].mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        np.random.seed(40 + it)
+        tr.step(*inputs)
+    torch.cuda.synchronize()
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    # the biases in front of a mean subtraction / softmax have an exactly-zero gradient: both sides hold round-off
+    # there, which Adam normalises into +-lr steps of arbitrary sign
+    zero_grad = ("unary_layer.bias", "adapt_q_layer.bias", "adapt_k_layer.bias", "channel_k_layer.bias")
+    for k in pa:  # Adam's first steps move every weight by ~lr regardless of the gradient's size: compare to lr
+        if k.endswith(zero_grad):
+            continue
+        diff = (pa[k].detach() - pb[k].detach()).abs()
+        # elements whose gradient is at round-off level get sign-of-noise steps from Adam on both sides: bound the
+        # share of such elements and the bulk tightly
+        frac = (diff > 0.05 * lr).float().mean().item()
+        assert frac <= 2e-3 and diff.mean().item() <= 2e-3 * lr, (k, frac, diff.max().item(), diff.mean().item())
