@@ -214,8 +214,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (seeded N(0,64^2) query/support pixels, 3 gt boxes/image, random-init weights)",
-        "config": {"model": args.model,
-                   "workload": "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d %dx%d "
+        "config": {"workload": ("" if args.model == "DAnA" else "[sibling detector '%s'] " % args.model) +
+                               "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d %dx%d "
                                "supports/episode%s, %s, %s" % (
                                    2 if args.ba else 1, args.way, args.shot, args.batch, args.height, args.width,
                                    way * args.shot, args.support_size, args.support_size,
