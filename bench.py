@@ -28,6 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_bf16 dense: 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz
+# fp32 contractions on the bf16 matrix cores cost six bf16 products per fp32 multiply (exact 3-way operand split)
+PEAK_SPLIT_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
 
 
 def parse():
@@ -222,7 +225,11 @@ def main():
                                    "" if args.support_size == 320 else " (generalised support pooling: NOT a reference "
                                    "configuration, no oracle)", "BA+CISA" if args.ba else "CISA only", what),
                    "global_batch": world * args.batch, "parallelism": "episodes sharded, %d rank(s)" % world,
-                   "target_sampling": "device Philox RNG" if args.device_rng else "host np.random (reference stream)"},
+                   "target_sampling": "device Philox RNG" if args.device_rng else "host np.random (reference stream)",
+                   "contractions": ("fp32 operands and accumulation; multiplies as an exact 3-way bf16 split, six products on "
+                                    "v_mfma_f32_32x32x16_bf16 (error vs fp64 at the f32-MFMA kernel's level; "
+                                    "f32_mfma_only = the same step with v_mfma_f32_32x32x2_f32)")
+                                   if ops.get_mfma_mode() else "v_mfma_f32_32x32x2_f32"},
     }
 
     if args.mode == "train" and not args.no_train_step:
@@ -257,18 +264,23 @@ def main():
         }
 
     if rank == 0 and not args.no_roofline and args.mode != "step":
-        # dominant kernel family: igemm_f32_kernel (every conv / Linear / bmm). Same K steps, each launch
+        # dominant kernel family: the implicit-GEMM contraction (every conv / Linear / bmm). Same K steps, each launch
         # bracketed by HIP events recorded on the stream the kernel is launched on (torch's current stream).
         # The product overlaps independent branches on several streams; for a per-kernel duration the
         # timing pass runs them on ONE stream so that every launch is measured alone on the chip.
-        ops.PROFILE = []
-        model._single_stream = True
-        torch.cuda.synchronize()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        model._single_stream = bool(args.single_stream)
-        prof, ops.PROFILE = ops.PROFILE, None
+        def contraction_pass():
+            ops.PROFILE = []
+            model._single_stream = True
+            torch.cuda.synchronize()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            model._single_stream = bool(args.single_stream)
+            prof, ops.PROFILE = ops.PROFILE, None
+            return prof
+
+        split = ops.get_mfma_mode() != 0
+        prof = contraction_pass()
         flops = sum(p[1] for p in prof)
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         launches = len(prof) // args.steps
@@ -282,18 +294,22 @@ def main():
         # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this very
         # command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py -> profiles/): bytes per launch,
         # next to the algorithmic bytes per launch (each operand / result of a launch touched once)
-        traffic = None
+        traffic, traffic_kernel = None, "igemm_split_kernel<128, 128>" if split else "igemm_f32_kernel<64, 64, 0>"
         try:
             with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
-                traffic = round(json.load(fh)["igemm_f32_kernel<64, 64, 0>"]["hbm_bytes_per_launch_corrected"])
+                traffic = round(json.load(fh)[traffic_kernel]["hbm_bytes_per_launch_corrected"])
         except (OSError, KeyError, ValueError):
             pass
         mfma = [p for p in prof if not p[0].startswith("conv7x7") and " N=2 " not in p[0] and " N=4 " not in p[0]]
+        peak = PEAK_SPLIT_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
         result["roofline"] = {
-            "bound": "mfma", "kernel": "igemm_f32_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)",
-            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM bytes per igemm_f32_kernel<64,64,0> launch (PMC, profiles/r1_pmc_traffic.json)",
+            "bound": "mfma",
+            "kernel": ("igemm_split_kernel (fp32 operands split exactly into 3 bf16 each, 6 x v_mfma_f32_32x32x16_bf16 per "
+                       "K=16, fp32 accumulation)" if split else
+                       "igemm_f32_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)"),
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per %s launch (PMC, profiles/r1_pmc_traffic.json)" % traffic_kernel,
             "algorithmic_bytes_per_launch": round(sum(p[4] for p in mfma) / max(len(mfma), 1)),
             "launches_per_step": launches,
             "algorithmic_gflop_per_step": round(flops / args.steps / 1e9, 1),
@@ -301,6 +317,34 @@ def main():
             "by_kind_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in by.items()},
             "whole_step_tflops": round(flops / args.steps / (dt / args.steps) / 1e12, 2),
         }
+        if split:
+            # `achieved` counts ALGORITHMIC fp32 FLOPs (2 per multiply-add of the convolution); the matrix cores issue
+            # six bf16 products for each, so the peak is the bf16 dense peak / 6. For reference: the same step and the
+            # same contraction pass with every contraction on the f32 MFMA (dana_set_mfma_mode(0)).
+            result["roofline"]["peak_is"] = "%.1f TFLOP/s bf16 dense MFMA / 6 products per fp32 multiply" % PEAK_BF16_MFMA_TFLOPS
+            result["roofline"]["mfma_issued_tflops"] = round(6.0 * achieved, 1)
+            result["roofline"]["vs_f32_mfma_peak"] = round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)
+            ops.set_mfma_mode(0)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt0 = time.perf_counter() - t0
+            prof0 = contraction_pass()
+            ms0 = sum(p[2].elapsed_time(p[3]) for p in prof0)
+            ach0 = sum(p[1] for p in prof0) / (ms0 * 1e-3) / 1e12
+            ops.set_mfma_mode(1)
+            result["f32_mfma_only"] = {
+                "value": round(args.batch * args.steps / dt0, 3), "unit": result["unit"],
+                "ms_per_step": round(dt0 / args.steps * 1e3, 3),
+                "roofline": {"bound": "mfma", "kernel": "igemm_f32_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                             "achieved": round(ach0, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ach0 / PEAK_FP32_MFMA_TFLOPS, 4),
+                             "kernel_ms_per_step": round(ms0 / args.steps, 3)},
+            }
         if args.dump_launches:
             per = {}
             for i, (tag, f, e0, e1, _nb) in enumerate(prof):

@@ -318,6 +318,385 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   }
 }
 
+// ---- fp32 contraction on the bf16 matrix cores: exact three-way split, six products ------------------------------
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of v_mfma_f32_32x32x2_f32. An fp32 value x is EXACTLY
+// x = h + m + l with h, m, l three bf16 numbers (8 significant bits each, taken by truncation: h = top 16 bits of x,
+// m = top 16 bits of x - h, l = x - h - m), so a*b = sum of nine bf16 x bf16 products, each of which the matrix core
+// forms exactly and accumulates in fp32. The six products of weight >= 2^-16 are issued (hh, hm, mh, mm, hl, lh); the
+// three dropped ones are <= 2^-23 |a||b| together, i.e. below the rounding of the fp32 accumulation itself -- operands,
+// accumulation and results are fp32, only the multiplier array is the bf16 one (tests/test_gpu_contractions.py checks
+// both kernels against an fp64 contraction: same error level). 6 x 32 cycles per K = 16 instead of 8 x 64: 2.67x
+// the f32-MFMA ceiling.
+//
+// Structure: block BM x BN x 16, 4 waves as 2x2, wave tile (BM/2) x (BN/2). The staging path is the f32 kernel's
+// (branch-free buffer loads of fp32 rows, two register sets in flight); the split happens once per element on the
+// way into LDS (4 VALU + 1.5 v_perm per element), which holds three bf16 planes per operand: rows of 16 bf16 padded
+// to 48 bytes (ds_write_b64 staging writes and ds_read_b128 fragment reads are bank-conflict-free). A lane's b128
+// fragment is k = 8*(lane>>5) .. +7 of row lane&31 -- the operand layout of the 32x32x16 MFMA.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SBK = 16;  // K per step
+constexpr int SLD = 12;  // LDS row of one plane, dwords (32 B of bf16 + 16 B pad)
+
+template <int V>
+struct IC {
+  static constexpr int value = V;
+};
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IC<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ void split3(const float4& v, uint2& h, uint2& m, uint2& l) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    hb[q] = __float_as_uint(x[q]) & 0xffff0000u;
+    const float r1 = x[q] - __uint_as_float(hb[q]);  // exact
+    mb[q] = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb[q]);    // exact; <= 8 significant bits left
+    lb[q] = __float_as_uint(r2);
+  }
+  // pack the upper halves of two dwords: bytes {S1.2, S1.3, S0.2, S0.3}
+  h.x = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
+  h.y = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+  m.x = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+  m.y = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+  l.x = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+  l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+}
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_split_kernel(IgemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
+  constexpr int RA = BM / 64, RB = BN / 64;  // float4 loads per thread per K-step (64 rows per pass)
+  constexpr int CLD = BN + 4;                // epilogue C-tile row, dwords
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned* As = (unsigned*)smem;      // [2][3][BM][SLD]
+  unsigned* Bs = As + 2 * 3 * BM * SLD;  // [2][3][BN][SLD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm_idx = tile / p.tiles_n, tn_idx = tile % p.tiles_n;
+  const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+  const float* Ab = p.A + (long)blockIdx.z * p.batch_a;
+  const float* Bb = p.Bw + (long)blockIdx.z * p.batch_b;
+  float* Cb = p.C + (long)blockIdx.z * p.batch_c;
+  const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)p.b_bytes, 0x00020000);
+
+  const int c4 = tid & 3;   // which float4 of the 16-wide k chunk
+  const int r0 = tid >> 2;  // row within a 64-row slab
+  unsigned a_off[RA];
+  unsigned a_mask[RA];  // bit t: tap t reads inside the image (<= 32 taps on this kernel)
+  bool a_seg1[RA];
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int m = m0 + r0 + 64 * j;
+    const bool ok = m < p.M;
+    const bool s1 = ok && m >= p.M0;
+    a_seg1[j] = s1;
+    const int mm = ok ? (s1 ? m - p.M0 : m) : 0;
+    const int IH = s1 ? p.IH1 : p.IH, IW = s1 ? p.IW1 : p.IW, OW = s1 ? p.OW1 : p.OW;
+    const int ohw = (s1 ? p.OH1 : p.OH) * OW;
+    const int img = mm / ohw, rem = mm - img * ohw;
+    const int oh = rem / OW, ow = rem - oh * OW;
+    const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+    const int pix = (s1 ? p.pix1 : 0) + (img * IH + ih0) * IW;
+    unsigned mask = 0;
+    if (ok)
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw)
+          if (ih0 + kh >= 0 && ih0 + kh < IH && iw0 + kw >= 0 && iw0 + kw < IW) mask |= 1u << (kh * p.KW + kw);
+    a_off[j] = (unsigned)(((pix + iw0) * p.lda + c4 * 4) * 4);
+    a_mask[j] = mask;
+  }
+  unsigned b_off[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int n = n0 + r0 + 64 * j;
+    b_off[j] = n < p.N ? (unsigned)((n * p.ldb + c4 * 4) * 4) : OOB;
+  }
+
+  float4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+  // K-steps are loaded in order, so the (tap, channel) walk is a few scalar adds per step (no divisions); a step
+  // past the end of K reads nothing (every offset out of range -> zeros), which keeps the loop body branch-free
+  int lt_k0 = 0, lt_cin = 0, lt_kh = 0, lt_kw = 0, lt_tap = 0;
+  auto load_tile = [&](float4(&ra)[RA], float4(&rb)[RB]) {
+    const bool kok = (lt_k0 + c4 * 4) < p.K;
+    const unsigned delta = (unsigned)__builtin_amdgcn_readfirstlane(((lt_kh * p.IW + lt_kw) * p.lda + lt_cin) * 4);
+    const unsigned delta1 = (unsigned)__builtin_amdgcn_readfirstlane(((lt_kh * p.IW1 + lt_kw) * p.lda + lt_cin) * 4);
+    const unsigned tbit = 1u << (lt_tap & 31);
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const unsigned off = a_off[j] + (a_seg1[j] ? delta1 : delta);
+      ra[j] = ldg_b128(ra_src, (kok && (a_mask[j] & tbit)) ? off : OOB);
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const unsigned off = b_off[j] + (unsigned)lt_k0 * 4u;
+      rb[j] = ldg_b128(rb_src, (kok && b_off[j] != OOB) ? off : OOB);
+    }
+    lt_k0 += SBK;
+    lt_cin += SBK;
+    const int wrap = lt_cin >= p.Cin ? 1 : 0;  // branch-free (tap, channel) walk
+    lt_cin = wrap ? 0 : lt_cin;
+    lt_tap += wrap;
+    lt_kw += wrap;
+    const int wrap2 = lt_kw == p.KW ? 1 : 0;
+    lt_kw = wrap2 ? 0 : lt_kw;
+    lt_kh += wrap2;
+  };
+  auto store_tile = [&](int buf, const float4(&ra)[RA], const float4(&rb)[RB]) {
+    unsigned* as = As + buf * 3 * BM * SLD + r0 * SLD + c4 * 2;
+    unsigned* bs = Bs + buf * 3 * BN * SLD + r0 * SLD + c4 * 2;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      uint2 h, m, l;
+      split3(ra[j], h, m, l);
+      *(uint2*)(as + (0 * BM + 64 * j) * SLD) = h;
+      *(uint2*)(as + (1 * BM + 64 * j) * SLD) = m;
+      *(uint2*)(as + (2 * BM + 64 * j) * SLD) = l;
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      uint2 h, m, l;
+      split3(rb[j], h, m, l);
+      *(uint2*)(bs + (0 * BN + 64 * j) * SLD) = h;
+      *(uint2*)(bs + (1 * BN + 64 * j) * SLD) = m;
+      *(uint2*)(bs + (2 * BN + 64 * j) * SLD) = l;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- main loop: three stages in flight -------------------------------------------------------------------------
+  //   registers R[.]  : fp32 rows of tile t+2 / t+3 (global loads, issued one iteration before they are split)
+  //   LDS[.]          : bf16 planes of tile t+1 (written during iteration t-1) and, being written, tile t+2
+  //   fragments F[.]  : tile t (read from LDS during iteration t-1) feeding this iteration's MFMAs, tile t+1 being read
+  // One barrier per K-step and nothing of the step's own data movement in front of its MFMAs: with one wave per SIMD
+  // (few tiles) the matrix pipe would otherwise idle through every address computation and LDS round trip.
+  // The issue order is fixed by hand (sched_barrier fences + empty asm pins): the 8-pass MFMA occupies the matrix pipe
+  // for 32 cycles and about five independent issues fit in its shadow, so all other work of the step is cut into items
+  // -- address set-up, one global load, four fragment reads, one element's h/m/l (4 VALU), one pair's three packs (3
+  // v_perm), one float4's three staging writes -- and dealt out evenly between the MFMAs.
+  constexpr int NM = 6 * TM * TN;  // MFMAs per K-step
+  constexpr int NF = RA + RB;      // float4s loaded / split per thread per K-step
+  constexpr int NR = 3 * (TM + TN);  // fragment reads per K-step
+  constexpr int I_LD = 1;                  // items [0, I_LD): step scalars; then NF loads
+  constexpr int I_RD = I_LD + NF;          // then NR fragment reads (one item each)
+  constexpr int I_CV = I_RD + NR;          // then 7 per float4: e0 e1 P01 e2 e3 P23 W
+  constexpr int NI = I_CV + 7 * NF;
+  const int klim = p.K - c4 * 4;  // this lane's float4 of a K-step starting at k0 is inside K iff k0 < klim
+  const int nk = (p.K + SBK - 1) / SBK;
+
+  u32x4 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];  // fragments as raw dwords (8 bf16 each)
+  auto read_frags = [&](int buf, u32x4(&fa)[3][TM], u32x4(&fb)[3][TN]) {
+    const unsigned* as = As + buf * 3 * BM * SLD + (wm * (BM / 2) + li) * SLD + lh * 4;
+    const unsigned* bs = Bs + buf * 3 * BN * SLD + (wn * (BN / 2) + li) * SLD + lh * 4;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[pc][i] = *(const u32x4*)(as + (pc * BM + i * 32) * SLD);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[pc][j] = *(const u32x4*)(bs + (pc * BN + j * 32) * SLD);
+    }
+  };
+
+  load_tile(ra0, rb0);       // tile 0
+  load_tile(ra1, rb1);       // tile 1
+  store_tile(0, ra0, rb0);
+  __syncthreads();
+  load_tile(ra0, rb0);       // tile 2
+  read_frags(0, fa0, fb0);   // tile 0
+  store_tile(1, ra1, rb1);
+  __syncthreads();
+
+  // iteration t: MFMAs on F_cur (tile t); reads tile t+1 from LDS[(t+1)&1] into F_nxt; splits R_cv (tile t+2) into
+  // LDS[t&1]; loads tile t+3 into R_ld
+  auto k_step = [&](int t, const u32x4(&fa)[3][TM], const u32x4(&fb)[3][TN], u32x4(&na)[3][TM], u32x4(&nb)[3][TN],
+                    const float4(&cv_a)[RA], const float4(&cv_b)[RB], float4(&ld_a)[RA], float4(&ld_b)[RB]) {
+    const int bw_ = t & 1, br_ = bw_ ^ 1;
+    const unsigned* as = As + br_ * 3 * BM * SLD + (wm * (BM / 2) + li) * SLD + lh * 4;
+    const unsigned* bs = Bs + br_ * 3 * BN * SLD + (wn * (BN / 2) + li) * SLD + lh * 4;
+    unsigned* aw = As + bw_ * 3 * BM * SLD + r0 * SLD + c4 * 2;
+    unsigned* bw = Bs + bw_ * 3 * BN * SLD + r0 * SLD + c4 * 2;
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
+    constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
+    unsigned hb[NF][4], mb[NF][4], lb[NF][4];
+    uint2 hp[NF], mp[NF], lp[NF];
+    bool kok = false;
+    unsigned delta = 0, delta1 = 0, tbit = 0, kb = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NM>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int pq = q / (TM * TN), ti = (q / TN) % TM, tj = q % TN;
+      acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[pq]][ti]),
+                                                            __builtin_bit_cast(bf16x8, fb[PB[pq]][tj]), acc[ti][tj], 0, 0, 0);
+      static_for<0, NI>([&](auto ic) {
+        constexpr int it = decltype(ic)::value;
+        if constexpr (it * NM / NI != q) {
+        } else if constexpr (it < I_LD) {  // wave-uniform scalars of the K-step being loaded, then advance the (tap, channel) walk
+          kok = lt_k0 < klim;
+          delta = (unsigned)__builtin_amdgcn_readfirstlane(((lt_kh * p.IW + lt_kw) * p.lda + lt_cin) * 4);
+          delta1 = (unsigned)__builtin_amdgcn_readfirstlane(((lt_kh * p.IW1 + lt_kw) * p.lda + lt_cin) * 4);
+          tbit = 1u << (lt_tap & 31);
+          kb = (unsigned)lt_k0 * 4u;
+          lt_k0 += SBK;
+          lt_cin += SBK;
+          const int wrap = lt_cin >= p.Cin ? 1 : 0;
+          lt_cin = wrap ? 0 : lt_cin;
+          lt_tap += wrap;
+          lt_kw += wrap;
+          const int wrap2 = lt_kw == p.KW ? 1 : 0;
+          lt_kw = wrap2 ? 0 : lt_kw;
+          lt_kh += wrap2;
+        } else if constexpr (it < I_RD) {
+          constexpr int f = it - I_LD;
+          if constexpr (f < RA) {
+            constexpr int j = f < RA ? f : 0;
+            unsigned off = a_off[j] + (a_seg1[j] ? delta1 : delta);
+            off = (kok && (a_mask[j] & tbit)) ? off : OOB;
+            asm volatile("" : "+v"(off));
+            ld_a[j] = ldg_b128(ra_src, off);
+          } else {
+            constexpr int j = f < RA ? 0 : f - RA;
+            unsigned off = (kok && b_off[j] != OOB) ? b_off[j] + kb : OOB;
+            asm volatile("" : "+v"(off));
+            ld_b[j] = ldg_b128(rb_src, off);
+          }
+        } else if constexpr (it < I_CV) {
+          constexpr int r = it - I_RD;  // planes in order h, m, l; within a plane A fragments then B fragments
+          constexpr int pc = r / (TM + TN), x = r % (TM + TN);
+          if constexpr (x < TM) na[pc][x < TM ? x : 0] = *(const u32x4*)(as + (pc * BM + x * 32) * SLD);
+          else nb[pc][x < TM ? 0 : x - TM] = *(const u32x4*)(bs + (pc * BN + (x - TM) * 32) * SLD);
+        } else {
+          constexpr int f = (it - I_CV) / 7, r = (it - I_CV) % 7;
+          const float4 v = f < RA ? cv_a[f < RA ? f : 0] : cv_b[f < RA ? 0 : f - RA];
+          if constexpr (r == 0 || r == 1 || r == 3 || r == 4) {
+            constexpr int e = r < 2 ? r : r - 1;
+            float x = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+            asm volatile("" : "+v"(x));
+            hb[f][e] = __float_as_uint(x) & 0xffff0000u;
+            const float r1 = x - __uint_as_float(hb[f][e]);  // exact
+            mb[f][e] = __float_as_uint(r1) & 0xffff0000u;
+            lb[f][e] = __float_as_uint(r1 - __uint_as_float(mb[f][e]));  // exact; <= 8 significant bits
+            asm volatile("" : "+v"(hb[f][e]), "+v"(mb[f][e]), "+v"(lb[f][e]));
+          } else if constexpr (r == 2) {  // pack the upper halves of two dwords: bytes {S1.2, S1.3, S0.2, S0.3}
+            asm volatile("" : "+v"(hb[f][0]), "+v"(hb[f][1]));
+            hp[f].x = __builtin_amdgcn_perm(hb[f][1], hb[f][0], 0x07060302u);
+            mp[f].x = __builtin_amdgcn_perm(mb[f][1], mb[f][0], 0x07060302u);
+            lp[f].x = __builtin_amdgcn_perm(lb[f][1], lb[f][0], 0x07060302u);
+            asm volatile("" : "+v"(hp[f].x), "+v"(mp[f].x), "+v"(lp[f].x));
+          } else if constexpr (r == 5) {
+            asm volatile("" : "+v"(hb[f][2]), "+v"(hb[f][3]));
+            hp[f].y = __builtin_amdgcn_perm(hb[f][3], hb[f][2], 0x07060302u);
+            mp[f].y = __builtin_amdgcn_perm(mb[f][3], mb[f][2], 0x07060302u);
+            lp[f].y = __builtin_amdgcn_perm(lb[f][3], lb[f][2], 0x07060302u);
+            asm volatile("" : "+v"(hp[f].y), "+v"(mp[f].y), "+v"(lp[f].y));
+          } else {
+            unsigned* w = f < RA ? aw + 64 * f * SLD : bw + 64 * (f - RA) * SLD;
+            constexpr int rows = f < RA ? BM : BN;
+            *(uint2*)(w + 0 * rows * SLD) = hp[f];
+            *(uint2*)(w + 1 * rows * SLD) = mp[f];
+            *(uint2*)(w + 2 * rows * SLD) = lp[f];
+          }
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+  };
+  // always whole pairs of K-steps (an odd count runs one extra all-zero step): no conditional between the two halves,
+  // so the register sets swap roles without copies
+  for (int t = 0; t < nk; t += 2) {
+    k_step(t, fa0, fb0, fa1, fb1, ra0, rb0, ra1, rb1);
+    k_step(t + 1, fa1, fb1, fa0, fb0, ra1, rb1, ra0, rb0);
+  }
+
+  // ---- epilogue through LDS (same C/D map as the f32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
+  constexpr int TPR = BN / 4;
+  constexpr int RPP = 256 / TPR;
+  const int ec = (tid % TPR) * 4;
+  const int er = tid / TPR;
+  float* Cs = smem;  // [BM][CLD]
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float* cw = Cs + (wm * (BM / 2) + i * 32 + 4 * lh) * CLD + wn * (BN / 2) + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * CLD] = acc[i][j][r];
+    }
+  __syncthreads();
+  const int n = n0 + ec;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool nok = (n + q) < p.N;
+    sc[q] = (nok && p.scale) ? p.scale[n + q] : 1.f;
+    sh[q] = (nok && p.shift) ? p.shift[n + q] : 0.f;
+  }
+  const bool full4 = p.vec_io && (n + 3) < p.N;
+#pragma unroll 4
+  for (int q = 0; q < BM / RPP; ++q) {
+    const int rr = er + q * RPP;
+    const int m = m0 + rr;
+    if (m >= p.M) break;
+    const float4 a4 = *(const float4*)(Cs + rr * CLD + ec);
+    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = v[t] * p.alpha * sc[t] + sh[t];
+    const bool s1 = m >= p.M0;
+    float* cp = s1 ? p.C1 + (long)(m - p.M0) * p.ldc1 + n : Cb + (long)m * p.ldc + n;
+    const float* rp = s1 ? p.residual1 + (long)(m - p.M0) * p.ldr1 + n : p.residual + (long)m * p.ldr + n;
+    if (full4) {
+      if (p.residual) {
+        const float4 r4 = *(const float4*)rp;
+        v[0] += r4.x;
+        v[1] += r4.y;
+        v[2] += r4.z;
+        v[3] += r4.w;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+      }
+      if (p.mask) {
+        const float4 k4 = *(const float4*)(p.mask + (long)m * p.ldm + n);
+        v[0] = k4.x > 0.f ? v[0] : 0.f;
+        v[1] = k4.y > 0.f ? v[1] : 0.f;
+        v[2] = k4.z > 0.f ? v[2] : 0.f;
+        v[3] = k4.w > 0.f ? v[3] : 0.f;
+      }
+      *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if ((n + t) < p.N) {
+          float x = v[t];
+          if (p.residual) x += rp[t];
+          if (p.relu) x = fmaxf(x, 0.f);
+          if (p.mask && !(p.mask[(long)m * p.ldm + n + t] > 0.f)) x = 0.f;
+          cp[t] = x;
+        }
+    }
+  }
+}
+
 // ---- skinny GEMM (N <= 8): one wave per output row, lanes split K (RCNN_bbox_pred 2048->4,
 // output_score_layer.linear2 1024->2: dana.py:246,304). HBM-bound on reading A once. ------------
 template <int NMAX>
@@ -373,13 +752,47 @@ int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   return 0;
 }
 
+template <int BM, int BN>
+int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
+  IgemmParams p = p0;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  size_t lds = (size_t)2 * 3 * (BM + BN) * SLD * sizeof(unsigned);
+  const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+  if (lds_c > lds) lds = lds_c;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
+  igemm_split_kernel<BM, BN><<<grid, 256, lds, s>>>(p);
+  return 0;
+}
+
 // Tile choice (measured on MI355X, tools/conv_sweep.py): the 64x64 block wins or ties on every layer of
 // the path -- 36.9 KB of LDS and 68 VGPRs let 4 blocks (16 waves) share a CU, which hides the
 // barrier/staging bubbles of the 64-cycle f32 MFMA better than 2 blocks of 128x128, and its finer
 // granularity shortens the tail (a CU finishes ceil(tiles/256) tiles while the average is tiles/256).
 // DANA_IGEMM_TILE=1|2|3 forces 128x128 | 128x64 | 64x64 for tuning.
+int g_mfma_mode = -1;  // -1: read DANA_MFMA_SPLIT on first use
+
 int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   if (stem) return launch<128, 64, 1>(p, batch, s);
+  // fp32 contractions run on the bf16 matrix cores by default (exact 3-way split, 6 products: igemm_split_kernel);
+  // dana_set_mfma_mode(0) / DANA_MFMA_SPLIT=0 selects the f32-MFMA kernel. 128x128 blocks amortise the split best; a
+  // launch that cannot give most CUs one of those falls back to 64x64 blocks (measured: tools/conv_sweep.py).
+  const int mode = g_mfma_mode < 0 ? (g_mfma_mode = getenv("DANA_MFMA_SPLIT") ? atoi(getenv("DANA_MFMA_SPLIT")) : 1)
+                                   : g_mfma_mode;
+  if (mode && p.KH * p.KW <= 32) {
+    if (mode == 2) return launch_split<128, 64>(p, batch, s);
+    if (mode == 3) return launch_split<64, 64>(p, batch, s);
+    if (p.N <= 64) return launch_split<128, 64>(p, batch, s);
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+    if (mode == 1 && t128 < 160) return launch_split<64, 64>(p, batch, s);
+    return launch_split<128, 128>(p, batch, s);
+  }
   static const int force = getenv("DANA_IGEMM_TILE") ? atoi(getenv("DANA_IGEMM_TILE")) : 0;
   if (force == 1 && p.N > 64) return launch<128, 128, 0>(p, batch, s);
   if (force == 2) return launch<128, 64, 0>(p, batch, s);
@@ -404,6 +817,17 @@ int run(IgemmParams& p, int batch, int stem, hipStream_t s) {
 }  // namespace
 
 extern "C" {
+
+int dana_set_mfma_mode(int mode) {
+  DANA_CHECK_ARG(mode >= 0 && mode <= 4, "dana_set_mfma_mode: mode must be 0 (f32 MFMA) or 1 (bf16x6 split; 2-4: forced tiles)");
+  g_mfma_mode = mode;
+  return DANA_OK;
+}
+
+int dana_get_mfma_mode(void) {
+  if (g_mfma_mode < 0) g_mfma_mode = getenv("DANA_MFMA_SPLIT") ? atoi(getenv("DANA_MFMA_SPLIT")) : 1;
+  return g_mfma_mode;
+}
 
 static int conv2d_impl(const char* who, const float* input, const float* weight, float* out0, float* out1,
                        const float* scale, const float* shift, const float* res0, const float* res1, int batch0,

@@ -464,6 +464,18 @@ def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=
     return out, h, w
 
 
+def set_mfma_mode(mode):
+    """0: fp32 contractions on v_mfma_f32_32x32x2_f32; 1 (default): exact bf16x3 split, six products on the bf16 matrix
+    cores with fp32 accumulation (include/dana_hip.h: dana_set_mfma_mode). Returns the previous mode."""
+    prev = lib().query("dana_get_mfma_mode")
+    lib().call("dana_set_mfma_mode", int(mode))
+    return prev
+
+
+def get_mfma_mode():
+    return lib().query("dana_get_mfma_mode")
+
+
 def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None, residual=None, ldr=0, batch=1,
             batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False, k_true=0):
     """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous."""

@@ -31,6 +31,14 @@ typedef void* dana_stream_t; /* hipStream_t */
 const char* dana_last_error(void);
 int dana_abi_version(void);
 
+/* How the fp32 contractions (every conv / GEMM below) use the matrix cores. 1 (default; DANA_MFMA_SPLIT overrides the
+ * initial value): each fp32 operand is split EXACTLY into three bf16 numbers and the six products of weight >= 2^-16
+ * run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error vs an fp64 contraction equal to the f32 kernel's,
+ * tests/test_gpu_contractions.py); 0: v_mfma_f32_32x32x2_f32. (2, 3, 4 force a tile shape of mode 1, for tuning.)
+ * Replaces nothing in the reference: cuDNN picks its own algorithm / math mode there (lib/model/framework/resnet.py). */
+int dana_set_mfma_mode(int mode);
+int dana_get_mfma_mode(void);
+
 /* ---- native operators: lib/model/csrc/vision.cpp:7-13 (module `model._C`) ------------------- */
 
 /* ROIAlign_forward: lib/model/csrc/ROIAlign.h:11-25 -> cuda/ROIAlign_cuda.cu:257-305.

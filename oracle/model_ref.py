@@ -311,10 +311,10 @@ def anchor_target_layer(cls_shape, gt_boxes, im_info):
 
     def unmap(d, fill):
         if d.dim() == 2:
-            r = torch.full((B, total), float(fill))
+            r = torch.full((B, total), float(fill), dtype=d.dtype)
             r[:, inds] = d
         else:
-            r = torch.full((B, total, d.shape[2]), float(fill))
+            r = torch.full((B, total, d.shape[2]), float(fill), dtype=d.dtype)
             r[:, inds, :] = d
         return r
 

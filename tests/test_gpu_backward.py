@@ -102,10 +102,19 @@ def test_rpn_loss_backward_vs_autograd(dev):
     _close(g.cpu(), hd.grad, 1e-5)
 
 
+@pytest.fixture(params=[1, 0], ids=["bf16x6", "f32mfma"])
+def mfma_mode(request):
+    from dana_amd import ops
+    prev = ops.set_mfma_mode(request.param)
+    yield request.param
+    ops.set_mfma_mode(prev)
+
+
 @pytest.mark.parametrize("use_ba", [False, True])
-def test_model_backward_vs_oracle_autograd(dev, use_ba):
+def test_model_backward_vs_oracle_autograd(dev, use_ba, mfma_mode):
     """every trainable parameter's gradient of (rpn_cls + rpn_box + rcnn_cls + rcnn_box), HIP backward vs autograd
-    through the oracle (same weights, inputs and np.random stream -> same sampled anchors / rois)"""
+    through the oracle (same weights, inputs and np.random stream -> same sampled anchors / rois), with the
+    contractions on the bf16 matrix cores (exact split, the default) and on the f32 MFMA"""
     import dana_amd
     from dana_amd import synthetic as S, backward as BW
     from oracle import model_ref as O
@@ -115,7 +124,10 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba):
     m.load_state_dict(sd)
     m.to(dev).train()
     m.nms_inclusive = True
-    inputs = S.episode_inputs(B, way, shot, H, W, seed=22)
+    # seed: one without a near tie in the proposal ranking / NMS of this tiny random-weight model (tools/rois_cmp.py:
+    # with seed 22 the split kernel and with seed 25 the f32 kernel pick one different roi than the oracle -- either
+    # is fp32 round-off deciding a tie, and gradients of different rois cannot be compared)
+    inputs = S.episode_inputs(B, way, shot, H, W, seed=23)
     weights = (1.0, 0.5, 2.0, 1.5)
 
     def trainable(k):
@@ -136,6 +148,8 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba):
     with torch.no_grad():
         res = m(*[t.to(dev) for t in inputs])
     assert np.array_equal(res[7].cpu().numpy(), out[7].numpy()), "different sampled rois: cannot compare gradients"
+    assert (res[0].cpu() - out[0].detach()).abs().max().item() < 0.05, \
+        "a different proposal was sampled (near tie in the ranking): cannot compare gradients, pick another seed"
     for a, b in zip(res[3:7], out[3:7]):
         assert abs(float(a) - float(b.detach())) <= 1e-4 * max(1.0, abs(float(b.detach())))
     BW.model_backward(m, weights)

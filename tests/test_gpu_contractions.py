@@ -1,6 +1,8 @@
-"""fp32 MFMA implicit-GEMM conv / GEMM and the small attention kernels vs a plain PyTorch fp32
+"""fp32 implicit-GEMM conv / GEMM and the small attention kernels vs a plain PyTorch fp32
 CPU reference of the same op. Tolerance: fp32 roundoff with a different summation order,
-|d| <= 2e-5 * sum|a*b| bound -> checked as rtol 1e-4 on the output scale."""
+|d| <= 2e-5 * sum|a*b| bound -> checked as rtol 1e-4 on the output scale.
+Every test of this file runs twice: with the contractions on the bf16 matrix cores (exact 3-way split of the fp32
+operands, six products, fp32 accumulation -- the default) and on the f32 MFMA (dana_set_mfma_mode)."""
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,14 @@ pytestmark = pytest.mark.gpu
 def _ops():
     import dana_amd
     return dana_amd.ops
+
+
+@pytest.fixture(autouse=True, params=[1, 0], ids=["bf16x6", "f32mfma"])
+def mfma_mode(request):
+    ops = _ops()
+    prev = ops.set_mfma_mode(request.param)
+    yield request.param
+    ops.set_mfma_mode(prev)
 
 
 def _close(a, b, tol=1e-4):
@@ -247,3 +257,27 @@ def test_winograd_weight_gradient_vs_direct_and_autograd(dev, case):
     direct = ops.conv2d_wgrad(gd, xd, N, H, W, Cin, Cout, 3, 3, 1, 1)
     fresh = ops.conv3x3_wgrad_winograd(gd, xd, N, H, W, Cin, Cout)
     _close(fresh.cpu(), direct.cpu(), 2e-4)
+
+
+@pytest.mark.parametrize("m,n,k,relu", [(1000, 256, 1024, False), (4096, 512, 4608, False), (777, 130, 36, False),
+                                        (2048, 256, 2304, True), (98, 1024, 3136, True)])
+def test_contraction_error_vs_fp64_is_at_the_fp32_level(dev, mfma_mode, m, n, k, relu):
+    """both kernels against an fp64 contraction of the same fp32 operands: max |err| / (|a| . |b|) must stay at the level
+    of a plain fp32 GEMM (rocBLAS on the same data) -- in particular for the bf16x6 split, whose dropped cross terms are
+    below the rounding of the fp32 accumulation"""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    b = torch.randn(n, k, generator=g)
+    if relu:
+        a, b = torch.relu(a) * 3.0, b * 0.02
+    else:  # wide dynamic range
+        a, b = a * torch.exp(torch.randn(m, k, generator=g)), b * torch.exp(torch.randn(n, k, generator=g))
+    a, b = a.to(dev), b.to(dev)
+    c = ops.gemm_nt(a, b, m, n, k)
+    ref = a.double() @ b.double().t()
+    mag = a.double().abs() @ b.double().abs().t()
+    err = ((c.double() - ref).abs() / mag).max().item()
+    err_blas = (((a @ b.t()).double() - ref).abs() / mag).max().item()
+    assert err <= 2.0 * err_blas + 2e-7, (err, err_blas)
+    assert ops.get_mfma_mode() == mfma_mode
