@@ -369,7 +369,7 @@ __device__ __forceinline__ void split3(const float4& v, uint2& h, uint2& m, uint
   l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int STEM>
 __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_split_kernel(IgemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
   constexpr int RA = BM / 64, RB = BN / 64;  // float4 loads per thread per K-step (64 rows per pass)
@@ -392,17 +392,26 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)p.b_bytes, 0x00020000);
 
+  // The K walk is over "taps" of `cin_t` channels. Conv / GEMM: tap = filter tap (kh, kw), cin_t = Cin, and this
+  // thread's float4 is channels c4*4.. of the pixel. 7x7 stem over NHWC4 (weights [cout][7][8][4], K = 224): a tap is
+  // half a filter row -- four pixels x four channels = 16 k -- i.e. (kh, half), and the float4 is pixel kw = 4*half+c4.
+  const int cin_t = STEM ? SBK : p.Cin;
+  const int kw_t = STEM ? 2 : p.KW;                // taps per filter row
+  const int kh_t = STEM ? 7 : p.KH;
+  const int lda4 = (STEM ? 4 : p.lda) * 4;          // bytes between pixels
+  const int kwstep = STEM ? 4 * lda4 : lda4;        // bytes between taps of a row
   const int c4 = tid & 3;   // which float4 of the 16-wide k chunk
   const int r0 = tid >> 2;  // row within a 64-row slab
-  unsigned a_off[RA];
-  unsigned a_mask[RA];  // bit t: tap t reads inside the image (<= 32 taps on this kernel)
-  bool a_seg1[RA];
+  const int klim = p.K - c4 * 4;  // this lane's float4 of a K-step starting at k0 is inside K iff k0 < klim
+  constexpr int DEAD = (int)0x80000000;  // k0 < DEAD never holds
+  unsigned a_off[RA];   // byte offset of this lane's float4 at tap (0, 0), channel chunk 0
+  unsigned a_mask[RA];  // bit t: tap t reads inside the image (and the row exists); <= 32 taps on this kernel
+  int a_dseg[RA];       // bytes added per filter row on top of segment 0's row pitch (second geometry segment)
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int m = m0 + r0 + 64 * j;
     const bool ok = m < p.M;
     const bool s1 = ok && m >= p.M0;
-    a_seg1[j] = s1;
     const int mm = ok ? (s1 ? m - p.M0 : m) : 0;
     const int IH = s1 ? p.IH1 : p.IH, IW = s1 ? p.IW1 : p.IW, OW = s1 ? p.OW1 : p.OW;
     const int ohw = (s1 ? p.OH1 : p.OH) * OW;
@@ -412,47 +421,75 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     const int pix = (s1 ? p.pix1 : 0) + (img * IH + ih0) * IW;
     unsigned mask = 0;
     if (ok)
-      for (int kh = 0; kh < p.KH; ++kh)
-        for (int kw = 0; kw < p.KW; ++kw)
-          if (ih0 + kh >= 0 && ih0 + kh < IH && iw0 + kw >= 0 && iw0 + kw < IW) mask |= 1u << (kh * p.KW + kw);
-    a_off[j] = (unsigned)(((pix + iw0) * p.lda + c4 * 4) * 4);
+      for (int kh = 0; kh < kh_t; ++kh)
+        for (int kw = 0; kw < kw_t; ++kw) {
+          const int iw = iw0 + (STEM ? 4 * kw + c4 : kw);
+          if (ih0 + kh >= 0 && ih0 + kh < IH && iw >= 0 && iw < IW && (!STEM || 4 * kw + c4 < 7))
+            mask |= 1u << (kh * kw_t + kw);
+        }
+    a_off[j] = STEM ? (unsigned)((pix + iw0 + c4) * lda4) : (unsigned)((pix + iw0) * lda4 + c4 * 16);
     a_mask[j] = mask;
+    a_dseg[j] = s1 ? (p.IW1 - p.IW) * lda4 : 0;
   }
-  unsigned b_off[RB];
+  unsigned b_cur[RB];  // byte offset of this lane's float4 of the current K-step in its filter row
+  int b_lim[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     const int n = n0 + r0 + 64 * j;
-    b_off[j] = n < p.N ? (unsigned)((n * p.ldb + c4 * 4) * 4) : OOB;
+    b_cur[j] = (unsigned)((n * p.ldb + c4 * 4) * 4);
+    b_lim[j] = n < p.N ? klim : DEAD;
   }
 
   float4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
-  // K-steps are loaded in order, so the (tap, channel) walk is a few scalar adds per step (no divisions); a step
-  // past the end of K reads nothing (every offset out of range -> zeros), which keeps the loop body branch-free
-  int lt_k0 = 0, lt_cin = 0, lt_kh = 0, lt_kw = 0, lt_tap = 0;
+  // K-steps are loaded in order: per step and load one compare (k0 against a per-lane limit that is DEAD for padding
+  // taps, missing rows / filters and the K tail), one select (offset or out-of-range -> the load returns zeros) and
+  // one add; the per-tap state is rebuilt under a scalar branch when a tap's channels run out (every Cin/16 steps).
+  // A step past the end of K reads nothing, which keeps the main loop free of tail conditions.
+  int lt_k0 = 0, lt_cin = 0, lt_kh = 0, lt_kw = 0;
+  unsigned lt_bit = 1u;
+  unsigned a_cur[RA];
+  int a_lim[RA];
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    a_cur[j] = a_off[j];
+    a_lim[j] = (a_mask[j] & 1u) ? klim : DEAD;
+  }
+  auto next_tap = [&]() {  // rare: the tap's channels are used up
+    if (lt_cin >= cin_t) {
+      lt_cin = 0;
+      lt_bit <<= 1;
+      if (++lt_kw == kw_t) {
+        lt_kw = 0;
+        ++lt_kh;
+      }
+      const int d0 = lt_kh * p.IW * lda4 + lt_kw * kwstep;
+#pragma unroll
+      for (int j = 0; j < RA; ++j) {
+        a_cur[j] = a_off[j] + (unsigned)(d0 + lt_kh * a_dseg[j]);
+        a_lim[j] = (a_mask[j] & lt_bit) ? klim : DEAD;
+      }
+    }
+  };
+  auto load_a = [&](int j, float4& dst) {
+    unsigned off = lt_k0 < a_lim[j] ? a_cur[j] : OOB;
+    asm volatile("" : "+v"(off));
+    dst = ldg_b128(ra_src, off);
+    a_cur[j] += SBK * 4;
+  };
+  auto load_b = [&](int j, float4& dst) {
+    unsigned off = lt_k0 < b_lim[j] ? b_cur[j] : OOB;
+    asm volatile("" : "+v"(off));
+    dst = ldg_b128(rb_src, off);
+    b_cur[j] += SBK * 4;
+  };
   auto load_tile = [&](float4(&ra)[RA], float4(&rb)[RB]) {
-    const bool kok = (lt_k0 + c4 * 4) < p.K;
-    const unsigned delta = (unsigned)__builtin_amdgcn_readfirstlane(((lt_kh * p.IW + lt_kw) * p.lda + lt_cin) * 4);
-    const unsigned delta1 = (unsigned)__builtin_amdgcn_readfirstlane(((lt_kh * p.IW1 + lt_kw) * p.lda + lt_cin) * 4);
-    const unsigned tbit = 1u << (lt_tap & 31);
+    next_tap();
 #pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const unsigned off = a_off[j] + (a_seg1[j] ? delta1 : delta);
-      ra[j] = ldg_b128(ra_src, (kok && (a_mask[j] & tbit)) ? off : OOB);
-    }
+    for (int j = 0; j < RA; ++j) load_a(j, ra[j]);
 #pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const unsigned off = b_off[j] + (unsigned)lt_k0 * 4u;
-      rb[j] = ldg_b128(rb_src, (kok && b_off[j] != OOB) ? off : OOB);
-    }
+    for (int j = 0; j < RB; ++j) load_b(j, rb[j]);
     lt_k0 += SBK;
     lt_cin += SBK;
-    const int wrap = lt_cin >= p.Cin ? 1 : 0;  // branch-free (tap, channel) walk
-    lt_cin = wrap ? 0 : lt_cin;
-    lt_tap += wrap;
-    lt_kw += wrap;
-    const int wrap2 = lt_kw == p.KW ? 1 : 0;
-    lt_kw = wrap2 ? 0 : lt_kw;
-    lt_kh += wrap2;
   };
   auto store_tile = [&](int buf, const float4(&ra)[RA], const float4(&rb)[RB]) {
     unsigned* as = As + buf * 3 * BM * SLD + r0 * SLD + c4 * 2;
@@ -500,7 +537,6 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   constexpr int I_RD = I_LD + NF;          // then NR fragment reads (one item each)
   constexpr int I_CV = I_RD + NR;          // then 7 per float4: e0 e1 P01 e2 e3 P23 W
   constexpr int NI = I_CV + 7 * NF;
-  const int klim = p.K - c4 * 4;  // this lane's float4 of a K-step starting at k0 is inside K iff k0 < klim
   const int nk = (p.K + SBK - 1) / SBK;
 
   u32x4 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];  // fragments as raw dwords (8 bf16 each)
@@ -538,8 +574,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
     unsigned hb[NF][4], mb[NF][4], lb[NF][4];
     uint2 hp[NF], mp[NF], lp[NF];
-    bool kok = false;
-    unsigned delta = 0, delta1 = 0, tbit = 0, kb = 0;
+    next_tap();  // (scalar branch, before the fenced stream)
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, NM>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
@@ -549,34 +584,14 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
       static_for<0, NI>([&](auto ic) {
         constexpr int it = decltype(ic)::value;
         if constexpr (it * NM / NI != q) {
-        } else if constexpr (it < I_LD) {  // wave-uniform scalars of the K-step being loaded, then advance the (tap, channel) walk
-          kok = lt_k0 < klim;
-          delta = (unsigned)__builtin_amdgcn_readfirstlane(((lt_kh * p.IW + lt_kw) * p.lda + lt_cin) * 4);
-          delta1 = (unsigned)__builtin_amdgcn_readfirstlane(((lt_kh * p.IW1 + lt_kw) * p.lda + lt_cin) * 4);
-          tbit = 1u << (lt_tap & 31);
-          kb = (unsigned)lt_k0 * 4u;
-          lt_k0 += SBK;
-          lt_cin += SBK;
-          const int wrap = lt_cin >= p.Cin ? 1 : 0;
-          lt_cin = wrap ? 0 : lt_cin;
-          lt_tap += wrap;
-          lt_kw += wrap;
-          const int wrap2 = lt_kw == p.KW ? 1 : 0;
-          lt_kw = wrap2 ? 0 : lt_kw;
-          lt_kh += wrap2;
+        } else if constexpr (it < I_LD) {
         } else if constexpr (it < I_RD) {
           constexpr int f = it - I_LD;
-          if constexpr (f < RA) {
-            constexpr int j = f < RA ? f : 0;
-            unsigned off = a_off[j] + (a_seg1[j] ? delta1 : delta);
-            off = (kok && (a_mask[j] & tbit)) ? off : OOB;
-            asm volatile("" : "+v"(off));
-            ld_a[j] = ldg_b128(ra_src, off);
-          } else {
-            constexpr int j = f < RA ? 0 : f - RA;
-            unsigned off = (kok && b_off[j] != OOB) ? b_off[j] + kb : OOB;
-            asm volatile("" : "+v"(off));
-            ld_b[j] = ldg_b128(rb_src, off);
+          if constexpr (f < RA) load_a(f < RA ? f : 0, ld_a[f < RA ? f : 0]);
+          else load_b(f < RA ? 0 : f - RA, ld_b[f < RA ? 0 : f - RA]);
+          if constexpr (f == NF - 1) {
+            lt_k0 += SBK;
+            lt_cin += SBK;
           }
         } else if constexpr (it < I_CV) {
           constexpr int r = it - I_RD;  // planes in order h, m, l; within a plane A fragments then B fragments
@@ -628,10 +643,28 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   }
 
   // ---- epilogue through LDS (same C/D map as the f32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
+  // The residual (and ReLU-adjoint mask) rows of the whole tile are requested BEFORE the accumulators go through LDS:
+  // the 1x1 expand convs (K = 64..512) are HBM-bound on exactly these reads and the output writes, and a load issued
+  // per pass would put one HBM round trip in front of every store.
   constexpr int TPR = BN / 4;
   constexpr int RPP = 256 / TPR;
+  constexpr int NP = BM / RPP;  // passes
   const int ec = (tid % TPR) * 4;
   const int er = tid / TPR;
+  const int n = n0 + ec;
+  const bool full4 = p.vec_io && (n + 3) < p.N;
+  float4 rres[NP];
+  if (p.residual && full4) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int m = m0 + er + q * RPP;
+      rres[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p.M) {
+        const bool s1 = m >= p.M0;
+        rres[q] = *(const float4*)(s1 ? p.residual1 + (long)(m - p.M0) * p.ldr1 + n : p.residual + (long)m * p.ldr + n);
+      }
+    }
+  }
   float* Cs = smem;  // [BM][CLD]
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -642,52 +675,54 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
       for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * CLD] = acc[i][j][r];
     }
   __syncthreads();
-  const int n = n0 + ec;
   float sc[4], sh[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const bool nok = (n + q) < p.N;
-    sc[q] = (nok && p.scale) ? p.scale[n + q] : 1.f;
+    sc[q] = (nok && p.scale) ? p.alpha * p.scale[n + q] : p.alpha;
     sh[q] = (nok && p.shift) ? p.shift[n + q] : 0.f;
   }
-  const bool full4 = p.vec_io && (n + 3) < p.N;
-#pragma unroll 4
-  for (int q = 0; q < BM / RPP; ++q) {
-    const int rr = er + q * RPP;
-    const int m = m0 + rr;
-    if (m >= p.M) break;
-    const float4 a4 = *(const float4*)(Cs + rr * CLD + ec);
-    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+  if (full4) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = v[t] * p.alpha * sc[t] + sh[t];
-    const bool s1 = m >= p.M0;
-    float* cp = s1 ? p.C1 + (long)(m - p.M0) * p.ldc1 + n : Cb + (long)m * p.ldc + n;
-    const float* rp = s1 ? p.residual1 + (long)(m - p.M0) * p.ldr1 + n : p.residual + (long)m * p.ldr + n;
-    if (full4) {
-      if (p.residual) {
-        const float4 r4 = *(const float4*)rp;
-        v[0] += r4.x;
-        v[1] += r4.y;
-        v[2] += r4.z;
-        v[3] += r4.w;
-      }
-      if (p.relu) {
+    for (int q = 0; q < NP; ++q) {
+      const int rr = er + q * RPP;
+      const int m = m0 + rr;
+      if (m < p.M) {
+        const float4 a4 = *(const float4*)(Cs + rr * CLD + ec);
+        float v[4] = {a4.x * sc[0] + sh[0], a4.y * sc[1] + sh[1], a4.z * sc[2] + sh[2], a4.w * sc[3] + sh[3]};
+        const bool s1 = m >= p.M0;
+        float* cp = s1 ? p.C1 + (long)(m - p.M0) * p.ldc1 + n : Cb + (long)m * p.ldc + n;
+        if (p.residual) {
+          v[0] += rres[q].x;
+          v[1] += rres[q].y;
+          v[2] += rres[q].z;
+          v[3] += rres[q].w;
+        }
+        if (p.relu) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        if (p.mask) {
+          const float4 k4 = *(const float4*)(p.mask + (long)m * p.ldm + n);
+          v[0] = k4.x > 0.f ? v[0] : 0.f;
+          v[1] = k4.y > 0.f ? v[1] : 0.f;
+          v[2] = k4.z > 0.f ? v[2] : 0.f;
+          v[3] = k4.w > 0.f ? v[3] : 0.f;
+        }
+        *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
       }
-      if (p.mask) {
-        const float4 k4 = *(const float4*)(p.mask + (long)m * p.ldm + n);
-        v[0] = k4.x > 0.f ? v[0] : 0.f;
-        v[1] = k4.y > 0.f ? v[1] : 0.f;
-        v[2] = k4.z > 0.f ? v[2] : 0.f;
-        v[3] = k4.w > 0.f ? v[3] : 0.f;
-      }
-      *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-#pragma unroll
+    }
+  } else {
+    for (int q = 0; q < NP; ++q) {
+      const int rr = er + q * RPP;
+      const int m = m0 + rr;
+      if (m >= p.M) break;
+      const bool s1 = m >= p.M0;
+      float* cp = s1 ? p.C1 + (long)(m - p.M0) * p.ldc1 + n : Cb + (long)m * p.ldc + n;
+      const float* rp = s1 ? p.residual1 + (long)(m - p.M0) * p.ldr1 + n : p.residual + (long)m * p.ldr + n;
       for (int t = 0; t < 4; ++t)
         if ((n + t) < p.N) {
-          float x = v[t];
+          float x = Cs[rr * CLD + ec + t] * sc[t] + sh[t];
           if (p.residual) x += rp[t];
           if (p.relu) x = fmaxf(x, 0.f);
           if (p.mask && !(p.mask[(long)m * p.ldm + n + t] > 0.f)) x = 0.f;
@@ -752,7 +787,7 @@ int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   return 0;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int STEM = 0>
 int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -762,12 +797,12 @@ int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
   if (lds_c > lds) lds = lds_c;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-  igemm_split_kernel<BM, BN><<<grid, 256, lds, s>>>(p);
+  igemm_split_kernel<BM, BN, STEM><<<grid, 256, lds, s>>>(p);
   return 0;
 }
 
@@ -779,7 +814,11 @@ int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
 int g_mfma_mode = -1;  // -1: read DANA_MFMA_SPLIT on first use
 
 int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
-  if (stem) return launch<128, 64, 1>(p, batch, s);
+  if (stem) {
+    const int smode = g_mfma_mode < 0 ? (g_mfma_mode = getenv("DANA_MFMA_SPLIT") ? atoi(getenv("DANA_MFMA_SPLIT")) : 1)
+                                      : g_mfma_mode;
+    return smode ? launch_split<128, 64, 1>(p, batch, s) : launch<128, 64, 1>(p, batch, s);
+  }
   // fp32 contractions run on the bf16 matrix cores by default (exact 3-way split, 6 products: igemm_split_kernel);
   // dana_set_mfma_mode(0) / DANA_MFMA_SPLIT=0 selects the f32-MFMA kernel. 128x128 blocks amortise the split best; a
   // launch that cannot give most CUs one of those falls back to 64x64 blocks (measured: tools/conv_sweep.py).

@@ -124,16 +124,31 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba, mfma_mode):
     m.load_state_dict(sd)
     m.to(dev).train()
     m.nms_inclusive = True
-    # seed: one without a near tie in the proposal ranking / NMS of this tiny random-weight model (tools/rois_cmp.py:
-    # with seed 22 the split kernel and with seed 25 the f32 kernel pick one different roi than the oracle -- either
-    # is fp32 round-off deciding a tie, and gradients of different rois cannot be compared)
-    inputs = S.episode_inputs(B, way, shot, H, W, seed=23)
     weights = (1.0, 0.5, 2.0, 1.5)
 
     def trainable(k):
         if "bn" in k or "downsample.1" in k or "running_" in k or "num_batches" in k:
             return False
         return not (k.startswith("RCNN_base.0") or k.startswith("RCNN_base.1") or k.startswith("RCNN_base.4"))
+
+    # Gradients can only be compared when both sides sampled the SAME rois. This tiny random-weight model has near ties
+    # in its proposal ranking / NMS, and fp32 round-off (a different summation order is enough) decides them: e.g. with
+    # seed 22 the bf16x6 kernels and with seed 25 the f32-MFMA kernels keep one different proposal than the oracle
+    # (tools/rois_cmp.py). So: the first input seed for which the HIP forward and the oracle agree on every roi.
+    m.save_for_backward = True
+    for seed in (23, 24, 26, 27, 29, 30):
+        inputs = S.episode_inputs(B, way, shot, H, W, seed=seed)
+        np.random.seed(33)
+        with torch.no_grad():
+            res = m(*[t.to(dev) for t in inputs])
+        np.random.seed(33)
+        with torch.no_grad():
+            probe = O.forward(sd, *inputs, training=True, n_way=way, n_shot=shot, use_ba=use_ba, nms_inclusive=True)
+        if np.array_equal(res[7].cpu().numpy(), probe[7].numpy()) and \
+                (res[0].cpu() - probe[0]).abs().max().item() < 0.05:
+            break
+    else:
+        pytest.fail("no seed on which the HIP forward and the oracle sample the same rois")
 
     osd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and trainable(k) else v.clone())
            for k, v in sd.items()}
@@ -142,14 +157,8 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba, mfma_mode):
                     differentiable=True)
     loss = sum(wt * l for wt, l in zip(weights, out[3:7]))
     loss.backward()
-
-    m.save_for_backward = True
-    np.random.seed(33)
-    with torch.no_grad():
-        res = m(*[t.to(dev) for t in inputs])
     assert np.array_equal(res[7].cpu().numpy(), out[7].numpy()), "different sampled rois: cannot compare gradients"
-    assert (res[0].cpu() - out[0].detach()).abs().max().item() < 0.05, \
-        "a different proposal was sampled (near tie in the ranking): cannot compare gradients, pick another seed"
+    assert (res[0].cpu() - out[0].detach()).abs().max().item() < 0.05
     for a, b in zip(res[3:7], out[3:7]):
         assert abs(float(a) - float(b.detach())) <= 1e-4 * max(1.0, abs(float(b.detach())))
     BW.model_backward(m, weights)
