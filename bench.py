@@ -294,7 +294,7 @@ def main():
         # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this very
         # command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py -> profiles/): bytes per launch,
         # next to the algorithmic bytes per launch (each operand / result of a launch touched once)
-        traffic, traffic_kernel = None, "igemm_split_kernel<128, 128>" if split else "igemm_f32_kernel<64, 64, 0>"
+        traffic, traffic_kernel = None, "igemm_split_kernel<128, 128, 0>" if split else "igemm_f32_kernel<64, 64, 0>"
         try:
             with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
                 traffic = round(json.load(fh)[traffic_kernel]["hbm_bytes_per_launch_corrected"])

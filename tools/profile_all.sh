@@ -1,0 +1,25 @@
+#!/bin/bash
+# rocprofv3 evidence for profiles/: kernel stats (default multi-stream, single-stream, training iteration) and the two
+# PMC passes (FETCH_SIZE / WRITE_SIZE) -> gpurun_out/prof_final/. Run on the GPU box: bash tools/profile_all.sh
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof_final
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+run_stats() {  # name, bench args...
+  name=$1; shift
+  rm -rf /tmp/rp_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$name -o bench -- python $R/bench.py "$@" > $O/$name.log 2>&1
+  f=$(find /tmp/rp_$name -name "*kernel_stats.csv" | head -1)
+  cp $f $O/${name}_kernel_stats.csv
+  tail -1 $O/$name.log | cut -c1-300
+}
+run_stats default --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-train-step
+run_stats single_stream --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-train-step --single-stream
+run_stats train_step --mode step --steps 10 --warmup 5 --no-cpu-baseline
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-train-step --single-stream > $O/pmc_$c.log 2>&1
+  cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) /tmp/pmc_$c.csv
+done
+python $R/tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE.csv /tmp/pmc_WRITE_SIZE.csv 4 $O/pmc_traffic.json | tee $O/pmc_traffic.txt
+cd $R && python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-400 $O/bench.json
