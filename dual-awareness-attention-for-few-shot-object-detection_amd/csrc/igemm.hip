@@ -485,9 +485,9 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   auto load_tile = [&](float4(&ra)[RA], float4(&rb)[RB]) {
     next_tap();
 #pragma unroll
-    for (int j = 0; j < RA; ++j) load_a(j, ra[j]);
-#pragma unroll
     for (int j = 0; j < RB; ++j) load_b(j, rb[j]);
+#pragma unroll
+    for (int j = 0; j < RA; ++j) load_a(j, ra[j]);
     lt_k0 += SBK;
     lt_cin += SBK;
   };
@@ -586,9 +586,12 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
         if constexpr (it * NM / NI != q) {
         } else if constexpr (it < I_LD) {
         } else if constexpr (it < I_RD) {
+          // filters first: they are L2 hits and in front of the in-order load counter, the activation rows (possible
+          // HBM misses) behind them -- and the split below takes the filters first, so an activation row has until the
+          // last third of the NEXT step to land
           constexpr int f = it - I_LD;
-          if constexpr (f < RA) load_a(f < RA ? f : 0, ld_a[f < RA ? f : 0]);
-          else load_b(f < RA ? 0 : f - RA, ld_b[f < RA ? 0 : f - RA]);
+          if constexpr (f < RB) load_b(f < RB ? f : 0, ld_b[f < RB ? f : 0]);
+          else load_a(f < RB ? 0 : f - RB, ld_a[f < RB ? 0 : f - RB]);
           if constexpr (f == NF - 1) {
             lt_k0 += SBK;
             lt_cin += SBK;
@@ -599,7 +602,8 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
           if constexpr (x < TM) na[pc][x < TM ? x : 0] = *(const u32x4*)(as + (pc * BM + x * 32) * SLD);
           else nb[pc][x < TM ? 0 : x - TM] = *(const u32x4*)(bs + (pc * BN + (x - TM) * 32) * SLD);
         } else {
-          constexpr int f = (it - I_CV) / 7, r = (it - I_CV) % 7;
+          constexpr int fo = (it - I_CV) / 7, r = (it - I_CV) % 7;
+          constexpr int f = fo < RB ? RA + fo : fo - RB;  // order of work: B floats, then A floats (f indexes A then B)
           const float4 v = f < RA ? cv_a[f < RA ? f : 0] : cv_b[f < RA ? 0 : f - RA];
           if constexpr (r == 0 || r == 1 || r == 3 || r == 4) {
             constexpr int e = r < 2 ? r : r - 1;
