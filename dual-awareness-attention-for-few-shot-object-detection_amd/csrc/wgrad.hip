@@ -219,6 +219,165 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_128_kernel(WgradParams p) {
     }
 }
 
+// ---- the same 128 x 128 tile on the bf16 matrix cores (exact three-way split of the fp32 operands, six products, fp32
+// accumulation: see igemm.hip) -------------------------------------------------------------------------------------
+// The contraction index (pixels) is the ROW index of both operands in HBM, while the 32x32x16 MFMA wants 8 consecutive
+// contraction values per lane. The transpose happens in registers on the way into LDS: a staging thread loads a
+// 4 (pixels) x 4 (channels) block -- four float4 along the contiguous channel axis, like the f32 kernel -- splits the 16
+// values and writes, per channel and plane, the four pixel-consecutive bf16 as one ds_write_b64 into that channel's LDS
+// row (rows of 16 bf16 padded to 48 B, the igemm_split layout, so the fragments are plain ds_read_b128). Waves 0-1
+// stage dY, waves 2-3 the implicit-im2col X slab. Channel c of the tile lives in LDS row (c & 3) * 32 + (c >> 2):
+// consecutive lanes write consecutive rows (no 8-way bank conflict), and the epilogue undoes the permutation.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int WSLD = 12;  // dwords per LDS row of one plane
+constexpr int WSK = 16;   // pixels per step
+
+__global__ void __launch_bounds__(256, 2) wgrad_split_128_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned wsm[];  // [2 operands][2 buffers][3 planes][128 rows][WSLD]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int plane = blockIdx.z / p.nsplit, slice = blockIdx.z - plane * p.nsplit;
+  const int m_begin = slice * p.m_chunk;
+  const int m_end = min(p.M, m_begin + p.m_chunk);
+  const int op = tid >> 7;                  // 0: dY (waves 0, 1), 1: X (waves 2, 3) -- wave-uniform
+  const int cq = tid & 31, mg = (tid >> 5) & 3;  // column quad, pixel group of 4
+  const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(op ? p.X + plane * p.batch_x : p.dY + plane * p.batch_y), 0, (int)(op ? p.x_bytes : p.y_bytes), 0x00020000);
+  unsigned* const stage = wsm + op * (2 * 3 * 128 * WSLD) + cq * WSLD + mg * 2;  // + buf*3*128*WSLD + (plane*128 + e*32)*WSLD
+
+  // per-thread geometry of its four rows (pixels m_begin + 4 mg + i, advancing by 16 per step)
+  const int col = (op ? k0 : n0) + cq * 4;
+  const bool col_ok = col < (op ? p.K : p.N);
+  const int tap = op ? col / p.Cin : 0, cin_off = op ? col - tap * p.Cin : col;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const bool plain = !op || (p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0);  // row m of the operand is pixel m
+  const int ld4 = (op ? p.ldx : p.ldy) * 4;
+  int m_row[4], img[4], oh[4], ow[4];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_begin + mg * 4 + i;
+    m_row[i] = m;
+    const int mm = m < p.M ? m : 0;
+    img[i] = mm / ohw;
+    const int rem = mm - img[i] * ohw;
+    oh[i] = rem / p.OW;
+    ow[i] = rem - oh[i] * p.OW;
+  }
+  const int d_ow = WSK % p.OW, d_oh = (WSK / p.OW) % p.OH, d_img = WSK / ohw;
+
+  float4 r[4];
+  auto load_slab = [&]() {  // the thread's 4 x 4 block of the next 16 pixels, then advance
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned off;
+      bool ok = col_ok && m_row[i] < m_end;
+      if (plain) {
+        off = (unsigned)(m_row[i] * ld4 + cin_off * 4);
+      } else {
+        const int ih = oh[i] * p.stride - p.pad + kh, iw = ow[i] * p.stride - p.pad + kw;
+        ok = ok && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+        off = (unsigned)(((img[i] * p.IH + ih) * p.IW + iw) * ld4 + cin_off * 4);
+        ow[i] += d_ow;
+        const int c1 = ow[i] >= p.OW ? 1 : 0;
+        ow[i] -= c1 ? p.OW : 0;
+        oh[i] += d_oh + c1;
+        const int c2 = oh[i] >= p.OH ? 1 : 0;
+        oh[i] -= c2 ? p.OH : 0;
+        img[i] += d_img + c2;
+      }
+      r[i] = ldg_b128(src, ok ? off : OOB);
+      m_row[i] += WSK;
+    }
+  };
+  auto store_slab = [&](int buf) {
+    unsigned* w = stage + buf * (3 * 128 * WSLD);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // channel e of the quad: its four pixels -> 4 bf16 per plane
+      unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x = e == 0 ? r[i].x : e == 1 ? r[i].y : e == 2 ? r[i].z : r[i].w;
+        hb[i] = __float_as_uint(x) & 0xffff0000u;
+        const float r1 = x - __uint_as_float(hb[i]);  // exact
+        mb[i] = __float_as_uint(r1) & 0xffff0000u;
+        lb[i] = __float_as_uint(r1 - __uint_as_float(mb[i]));  // exact; <= 8 significant bits
+      }
+      uint2 h, m, l;
+      h.x = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
+      h.y = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+      m.x = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+      m.y = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+      l.x = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+      l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+      *(uint2*)(w + (0 * 128 + e * 32) * WSLD) = h;
+      *(uint2*)(w + (1 * 128 + e * 32) * WSLD) = m;
+      *(uint2*)(w + (2 * 128 + e * 32) * WSLD) = l;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const int steps = (m_end - m_begin + WSK - 1) / WSK;
+  if (steps > 0) {
+    load_slab();
+    store_slab(0);
+    __syncthreads();
+    load_slab();
+    for (int s = 0; s < steps; ++s) {
+      const int buf = s & 1;
+      const unsigned* g = wsm + buf * (3 * 128 * WSLD) + (wn * 64 + li) * WSLD + lh * 4;
+      const unsigned* x = wsm + (2 + buf) * (3 * 128 * WSLD) + (wk * 64 + li) * WSLD + lh * 4;
+      u32x4 gf[3][2], xf[3][2];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          gf[pc][i] = *(const u32x4*)(g + (pc * 128 + i * 32) * WSLD);
+          xf[pc][i] = *(const u32x4*)(x + (pc * 128 + i * 32) * WSLD);
+        }
+      constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
+      constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gf[PA[q]][i]),
+                                                               __builtin_bit_cast(bf16x8, xf[PB[q]][j]), acc[i][j], 0, 0, 0);
+      store_slab(buf ^ 1);  // pixels of step s + 1 (zeros past the end)
+      load_slab();          // step s + 2
+      __syncthreads();
+    }
+  }
+  // C/D map: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5) within a 32x32 tile; LDS row rho <-> channel
+  // 4*(rho & 31) + (rho >> 5) of the 128-wide tile
+  float* out = p.partial + (long)blockIdx.z * p.N * p.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rk = wk * 64 + j * 32 + li;
+      const int k = k0 + 4 * (rk & 31) + (rk >> 5);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rn = wn * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        const int n = n0 + 4 * (rn & 31) + (rn >> 5);
+        if (n < p.N && k < p.K) out[(long)n * p.K + k] = acc[i][j][q];
+      }
+    }
+}
+
 // dW[i] = (accumulate ? dW[i] : 0) + row_scale[row(i)] * sum_s partial[s][i], fixed order. row_scale (optional) is the
 // frozen-BN scale of the output channel: with it the launch writes straight into the parameter's gradient.
 // A block = 64 float4 outputs x 4 slice-lanes (lane q sums slices q, q+4, ...; the four are combined in a fixed order
@@ -348,6 +507,21 @@ WgradShape wgrad_shape(int N, int K, int M, int planes = 1) {
   return best;
 }
 
+// 128 x 128 tile: bf16x6 split kernel unless dana_set_mfma_mode(0)
+void launch_wgrad_128(const WgradParams& p, dim3 grid, hipStream_t s) {
+  if (dana_get_mfma_mode() != 0) {
+    constexpr int lds = 2 * 2 * 3 * 128 * WSLD * (int)sizeof(unsigned);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)wgrad_split_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    wgrad_split_128_kernel<<<grid, 256, lds, s>>>(p);
+  } else {
+    wgrad_f32_128_kernel<<<grid, 256, 0, s>>>(p);
+  }
+}
+
 }  // namespace
 
 // ---- internal (common.h): batched "TN" GEMM out[z][N][K] = dY[z]^T . X[z] over M rows, for the Winograd-domain weight
@@ -397,7 +571,7 @@ int dana_wgrad_tn_batched(const float* dY, const float* X, float* out, int plane
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ws.tn, ws.tk, planes * S);
   if (ws.tile == 128)
-    wgrad_f32_128_kernel<<<grid, 256, 0, s>>>(p);
+    launch_wgrad_128(p, grid, s);
   else
     wgrad_f32_kernel<<<grid, 256, 0, s>>>(p);
   DANA_CHECK_LAUNCH("dana_wgrad_tn_batched");
@@ -471,7 +645,7 @@ int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* gra
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(tn, tk, S);
   if (ws.tile == 128)
-    wgrad_f32_128_kernel<<<grid, 256, 0, s>>>(p);
+    launch_wgrad_128(p, grid, s);
   else
     wgrad_f32_kernel<<<grid, 256, 0, s>>>(p);
   DANA_CHECK_LAUNCH("dana_conv2d_wgrad_nhwc");
