@@ -48,8 +48,18 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+@pytest.fixture(params=[1, 0], ids=["bf16x6", "f32mfma"])
+def mfma_mode(request):
+    """the reference-golden end-to-end tests run with the contractions on the bf16 matrix cores (exact 3-way split, the
+    default) and on the f32 MFMA: both kernels are pinned against the reference's own outputs"""
+    import dana_amd
+    prev = dana_amd.ops.set_mfma_mode(request.param)
+    yield request.param
+    dana_amd.ops.set_mfma_mode(prev)
+
+
 @pytest.mark.parametrize("tag", ["eval_small_cisa", "eval_small_ba", "eval_full_ba"])
-def test_eval_forward_matches_reference_golden(golden_dir, dev, tag):
+def test_eval_forward_matches_reference_golden(golden_dir, dev, tag, mfma_mode):
     import dana_amd
     ops = dana_amd.ops
     g = _load(golden_dir, tag)
@@ -74,7 +84,7 @@ def test_eval_forward_matches_reference_golden(golden_dir, dev, tag):
     assert np.abs(bbox_pred.cpu().numpy() - g["bbox_pred"])[matched].max() <= 1e-4
 
 
-def test_train_forward_matches_reference_golden(golden_dir, dev):
+def test_train_forward_matches_reference_golden(golden_dir, dev, mfma_mode):
     g = _load(golden_dir, "train_small_ba")
     m, sd, din, _, (use_ba, training, B, way, shot, nseed) = _build(g["meta"], dev)
     np.random.seed(nseed)
