@@ -150,7 +150,7 @@ int dana_conv2d_nhwc_dual(const float* input, const float* weight, float* out0, 
 
 /* Winograd F(2x2,3x3) path for the stride-1 pad-1 3x3 convs with many channels (layer3/layer4 conv2,
  * RPN_Conv): u = dana_winograd_filter_transform(packed weight [cout][3][3][cin]) -> [16][cout][cin], then
- * out = relu?(conv3x3(input) * scale + shift) with 2.25x fewer multiplies (exact-fp32 MFMA GEMMs). */
+ * out = relu?(conv3x3(input) * scale + shift) with 2.25x fewer multiplies (the 16 GEMMs run on the igemm kernels, see dana_set_mfma_mode). */
 int dana_winograd_filter_transform(const float* w_packed, float* u, int cout, int cin, dana_stream_t stream);
 size_t dana_conv3x3_winograd_workspace_bytes(int batch, int h, int w, int cin, int cout);
 int dana_conv3x3_winograd_nhwc(const float* input, const float* u, float* output, const float* scale,
