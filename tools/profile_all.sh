@@ -22,4 +22,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) /tmp/pmc_$c.csv
 done
 python $R/tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE.csv /tmp/pmc_WRITE_SIZE.csv 4 $O/pmc_traffic.json | tee $O/pmc_traffic.txt
+rm -rf /tmp/pmc_mfma
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_mfma -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-train-step --single-stream > $O/pmc_mfma.log 2>&1
+python $R/tools/secondary_rooflines.py $O/single_stream_kernel_stats.csv $O/pmc_traffic.json $(find /tmp/pmc_mfma -name "*counter_collection.csv" | head -1) 13 $O/secondary_rooflines.md | tail -30
 cd $R && python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-400 $O/bench.json
