@@ -174,6 +174,8 @@ def _block_convs(prefix, bp):
 def grad_stages(model):
     """[(stage, [parameter names])] in the order model_backward FINISHES the gradients: the trainer lays its flat
     gradient buffer out in this order so that all-reduce buckets can leave while the rest of the backward runs."""
+    if type(model).__name__ == "FasterRCNN":
+        return frcnn_grad_stages(model)
     plan = model._get_plan()
     lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
     st = [("box branch", lin("RCNN_bbox_pred") + [n for bi in (2, 1, 0)
@@ -241,6 +243,8 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     RCNN_loss_cls, RCNN_loss_bbox) of the last `save_for_backward` forward: what train.py:141-143's
     `loss.backward()` computes, accumulated into `.grad` of the trainable parameters (BN, conv1 and layer1 are
     frozen: dana.py:350-385)."""
+    if type(model).__name__ == "FasterRCNN":
+        return frcnn_backward(model, grad_losses)
     ctx = model._ctx
     plan = ctx["plan"]
     B, shot, way, R, Ns = ctx["B"], ctx["shot"], ctx["way"], ctx["R"], ctx["Ns"]
@@ -435,6 +439,84 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
         gq = bottleneck_backward(gq, sq, sq["n"], sq["h"], sq["w"], sq["bp"], grads, sq["key"], need_dx=i > 0,
                                  g_masked=i < nblk - 1)
         gs = bottleneck_backward(gs, s_, s_["n"], s_["h"], s_["w"], s_["bp"], grads, s_["key"], need_dx=i > 0,
+                                 g_masked=i < nblk - 1)
+        grads.finish_all(model, sq["key"] + ".")
+        _ready(model, _block_convs(sq["key"], sq["bp"]))
+    assert not grads.packed
+    model._ctx = None
+
+
+# ---- sibling model `frcnn` (lib/model/framework/faster_rcnn.py): the same adjoints without the attention ----------------
+def frcnn_grad_stages(model):
+    plan = model._get_plan()
+    lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
+    st = [("roi head", lin("RCNN_bbox_pred") + lin("RCNN_cls_score")
+           + [n for bi in (2, 1, 0) for n in _block_convs("RCNN_top.0.%d" % bi, plan["layer4"][bi])])]
+    st.append(("rpn", lin("RCNN_rpn.RPN_cls_score") + lin("RCNN_rpn.RPN_bbox_pred") + lin("RCNN_rpn.RPN_Conv")))
+    for li in (2, 1):
+        layer = plan["layers"][li]
+        for bi in reversed(range(len(layer))):
+            key = "RCNN_base.%d.%d" % (4 + li, bi)
+            st.append((key, _block_convs(key, layer[bi])))
+    return st
+
+
+def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
+    """d(sum_i grad_losses[i] * loss_i)/d(parameters) of the last training forward of FasterRCNN (faster_rcnn.py:31-105):
+    RCNN_cls_score / RCNN_bbox_pred <- mean <- layer4 <- RoIAlign, RPN losses <- heads <- 3x3 conv, both into base_feat,
+    then layer3 / layer2 of the trunk (conv1, layer1 and every BN are frozen: faster_rcnn.py:129-160)."""
+    ctx = model._ctx
+    plan, B, R, fh, fw = ctx["plan"], ctx["B"], ctx["R"], ctx["fh"], ctx["fw"]
+    n_roi, hw = B * R, fh * fw
+    if isinstance(grad_losses, torch.Tensor):
+        g1, g2, g3, g4 = [float(x) for x in grad_losses.detach().cpu()]
+    else:
+        g1, g2, g3, g4 = [float(x) for x in grad_losses]
+    d_cls, d_bbox = ctx["loss_seeds"]  # d(loss_cls + loss_bbox) / d(cls_score, bbox_pred)
+    dev = d_cls.device
+    grads = WeightGrads(None if getattr(model, "_single_stream", False) else model._stream("wgrad", dev), model)
+    stages = frcnn_grad_stages(model)
+    C = d_cls.size(1)
+    fc7 = ctx["fc7"]
+    _acc(model.RCNN_bbox_pred.weight, ops.gemm_small(d_bbox, (1, 4), fc7, (2048, 1), 4, 2048, n_roi, alpha=g4))
+    _acc(model.RCNN_bbox_pred.bias, ops.colsum(d_bbox, n_roi, 4, alpha=g4))
+    _acc(model.RCNN_cls_score.weight, ops.gemm_small(d_cls, (1, C), fc7, (2048, 1), C, 2048, n_roi, alpha=g3))
+    _acc(model.RCNN_cls_score.bias, ops.colsum(d_cls, n_roi, C, alpha=g3))
+    d_fc7 = ops.gemm_small(d_bbox, (4, 1), model.RCNN_bbox_pred.weight.detach(), (2048, 1), n_roi, 2048, 4, alpha=g4)
+    d_fc7.add_(ops.gemm_small(d_cls, (C, 1), model.RCNN_cls_score.weight.detach(), (2048, 1), n_roi, 2048, C, alpha=g3))
+    l4 = ctx["l4_saved"]
+    npos = l4[-1]["h1"] * l4[-1]["w1"]
+    g = ops.broadcast_rows(d_fc7, n_roi, npos, 2048, alpha=1.0 / npos)
+    for i, sv in enumerate(reversed(l4)):  # the first block's input is the RoIAlign output: no ReLU in front of it
+        g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"], mask_dx=i < len(l4) - 1,
+                                g_masked=i > 0)
+    grads.finish_all(model, "RCNN_top")
+    _ready(model, stages[0][1])
+    d_bf = ops.roi_align_backward(g.view(n_roi, 7, 7, 1024), ctx["rois"].view(-1, 5), 1.0 / 16.0, 7, 7, B, 1024, fh, fw,
+                                  0, layout=ops.NHWC).view(B * hw, 1024)
+    # -- RPN (rpn.py:58-115) on base_feat --
+    rpn = model.RCNN_rpn
+    nh = ctx["nh"]
+    d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
+                                    inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0])
+    dwh, dbh, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512)
+    ns = rpn.nc_score_out
+    _acc(rpn.RPN_cls_score.weight, dwh[:ns])
+    _acc(rpn.RPN_cls_score.bias, dbh[:ns])
+    _acc(rpn.RPN_bbox_pred.weight, dwh[ns:])
+    _acc(rpn.RPN_bbox_pred.bias, dbh[ns:])
+    ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
+    c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None, u=plan["rpn_conv_u"])
+    grads.add_conv("RCNN_rpn.RPN_Conv", d_x, ctx["rpn_feat"], B, fh, fw, c_rpn)
+    _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
+    gq = conv_dgrad(d_x, B, fh, fw, c_rpn, residual=d_bf)  # d base_feat = RPN path + RoIAlign path
+    grads.finish_all(model, "RCNN_rpn")
+    _ready(model, stages[1][1])
+    qs = ctx["q_saved"]
+    nblk = len(qs)
+    for i in range(nblk - 1, -1, -1):
+        sq = qs[i]
+        gq = bottleneck_backward(gq, sq, sq["n"], sq["h"], sq["w"], sq["bp"], grads, sq["key"], need_dx=i > 0,
                                  g_masked=i < nblk - 1)
         grads.finish_all(model, sq["key"] + ".")
         _ready(model, _block_convs(sq["key"], sq["bp"]))

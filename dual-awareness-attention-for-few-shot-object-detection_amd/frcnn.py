@@ -2,7 +2,8 @@
 lib/model/framework/faster_rcnn.py:17-203 on the SAME HIP operators as the DAnA path --
 Caffe ResNet-50 trunk -> RPN -> proposal layer -> (train) anchor / proposal targets -> RoIAlign or RoIPool ->
 layer4 -> RCNN_cls_score / RCNN_bbox_pred -> losses. Same parameter tree and state_dict keys as the reference class.
-Forward only: its losses are not connected to the HIP backward (that covers the DAnA path)."""
+`frcnn` is trainable on the HIP kernels too: a training forward saves its context and hands the four losses to autograd
+(`_LossBridge`), `loss.backward()` runs backward.frcnn_backward (POOLING_MODE 'align'); `meta` below is forward only."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -11,7 +12,7 @@ import torch.nn.functional as F
 from . import ops
 from . import targets as T
 from .config import cfg
-from .dana import DAnARCNN, _RPNParams
+from .dana import DAnARCNN, _LossBridge, _RPNParams
 
 
 class FasterRCNN(DAnARCNN):
@@ -47,7 +48,7 @@ class FasterRCNN(DAnARCNN):
         self.RCNN_cls_score.bias.data.zero_()
 
     # ---- shared stages of the sibling detectors (frcnn, meta): trunk -> RPN -> targets -> RoI features -> layer4 ----
-    def _stages(self, im_data, im_info, gt_boxes, anchor_gt_boxes=None, rpn_input=None):
+    def _stages(self, im_data, im_info, gt_boxes, anchor_gt_boxes=None, rpn_input=None, ctx=None):
         """-> dict(B, R, n_roi, rois, rpn losses, rois_label / targets (train), pooled, fc7 [n_roi][2048]).
         anchor_gt_boxes: boxes the anchor-target layer sees (meta.py:65 passes ALL classes' boxes); default gt_boxes.
         rpn_input(base, B, fh, fw, plan) -> (feature [B*h*w][1024], h, w): what the RPN runs on instead of base_feat
@@ -62,7 +63,8 @@ class FasterRCNN(DAnARCNN):
         inputs_ready = torch.cuda.Event()
         inputs_ready.record()
         main = torch.cuda.current_stream()
-        base, fh, fw = self._rcnn_base(im_data, plan)  # [B*fh*fw][1024] NHWC (faster_rcnn.py:43)
+        # ctx (frcnn only): everything backward.frcnn_backward needs is saved into it
+        base, fh, fw = self._rcnn_base(im_data, plan, save=ctx["q_saved"] if ctx is not None else None)  # faster_rcnn.py:43
         # -- RPN (rpn.py:58-115) on base_feat (or on the model's own RPN input) --
         rfeat, rh, rw = (base, fh, fw) if rpn_input is None else rpn_input(base, B, fh, fw, plan)
         base_hw = (fh, fw)
@@ -96,6 +98,8 @@ class FasterRCNN(DAnARCNN):
             main.wait_stream(side)
             rpn_l = ops.rpn_losses(heads, nh, at, sigma=3.0, inside_weight=tr_.RPN_BBOX_INSIDE_WEIGHTS[0])
             st["rpn_loss_cls"], st["rpn_loss_bbox"] = rpn_l[0], rpn_l[1]
+            if ctx is not None:
+                ctx.update(rpn_x=x, rpn_heads=heads, at=at, rpn_l=rpn_l, nh=nh, rpn_feat=rfeat, rfh=fh, rfw=fw)
             fg_per = int(np.round(tr_.FG_FRACTION * tr_.BATCH_SIZE)) or 1
             rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_layer(
                 rois, gt_boxes.float(), int(tr_.BATCH_SIZE), fg_per, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
@@ -119,18 +123,27 @@ class FasterRCNN(DAnARCNN):
             pooled = ops.nchw_to_nhwc(pooled_nchw)
         else:
             raise NotImplementedError("POOLING_MODE '%s'" % cfg.POOLING_MODE)
-        st.update(rois=rois, R=R, n_roi=n_roi, pooled=pooled, fc7=self._head_to_tail(pooled, n_roi, P, P, plan),
-                  plan=plan)
+        st.update(rois=rois, R=R, n_roi=n_roi, pooled=pooled, plan=plan,
+                  fc7=self._head_to_tail(pooled, n_roi, P, P, plan, save=ctx["l4_saved"] if ctx is not None else None))
+        if ctx is not None:
+            ctx.update(plan=plan, B=B, R=R, rois=rois, fh=fh, fw=fw, fc7=st["fc7"])
         return st
 
-    def _head_to_tail(self, x, n, h, w, plan):
+    def _head_to_tail(self, x, n, h, w, plan, save=None):
         """layer4 + spatial mean (faster_rcnn.py:183-185) on an NHWC batch of n maps -> [n][2048]"""
-        for bp in plan["layer4"]:
-            x, h, w = self._bottleneck(x, n, h, w, bp)
+        for bi, bp in enumerate(plan["layer4"]):
+            x, h, w = self._bottleneck(x, n, h, w, bp, save=save, key="RCNN_top.0.%d" % bi)
         return ops.spatial_mean(x, n, h * w, 2048)
 
     def forward(self, im_data, im_info, gt_boxes, num_boxes):
-        st = self._stages(im_data, im_info, gt_boxes)
+        ctx = None
+        bridge = self.training and torch.is_grad_enabled() and type(self) is FasterRCNN
+        if self.training and type(self) is FasterRCNN and (bridge or getattr(self, "save_for_backward", False)):
+            if cfg.POOLING_MODE != "align":
+                raise NotImplementedError("the HIP backward of frcnn covers POOLING_MODE 'align'")
+            ctx = dict(q_saved=[], l4_saved=[])
+        self._ctx = None
+        st = self._stages(im_data, im_info, gt_boxes, ctx=ctx)
         B, R, n_roi, fc7 = st["B"], st["R"], st["n_roi"], st["fc7"]
         wb, bb = self._w(self.RCNN_bbox_pred)
         wc, bc = self._w(self.RCNN_cls_score)
@@ -138,10 +151,29 @@ class FasterRCNN(DAnARCNN):
         cls_score = ops.gemm_nt(fc7, wc, n_roi, self.n_classes, 2048, shift=bc)
         cls_prob = ops.softmax_rows_(cls_score.clone(), n_roi, self.n_classes)
         RCNN_loss_cls = RCNN_loss_bbox = 0
+        rpn_loss_cls, rpn_loss_bbox = st["rpn_loss_cls"], st["rpn_loss_bbox"]
         if self.training:  # faster_rcnn.py:93-98
-            RCNN_loss_cls = F.cross_entropy(cls_score, st["rois_label"])
-            RCNN_loss_bbox = T._smooth_l1_loss(bbox_pred, st["rois_target"], st["rois_inside_ws"], st["rois_outside_ws"])
-        return (st["rois"], cls_prob.view(B, R, -1), bbox_pred.view(B, R, -1), st["rpn_loss_cls"], st["rpn_loss_bbox"],
+            if ctx is None:
+                RCNN_loss_cls = F.cross_entropy(cls_score, st["rois_label"])
+                RCNN_loss_bbox = T._smooth_l1_loss(bbox_pred, st["rois_target"], st["rois_inside_ws"],
+                                                   st["rois_outside_ws"])
+            else:
+                # the two tiny loss tails ([n_roi][2], [n_roi][4]) give their own gradient seeds through torch
+                cs, bp_ = cls_score.detach().requires_grad_(True), bbox_pred.detach().requires_grad_(True)
+                with torch.enable_grad():
+                    lc = F.cross_entropy(cs, st["rois_label"])
+                    lb = T._smooth_l1_loss(bp_, st["rois_target"], st["rois_inside_ws"], st["rois_outside_ws"])
+                    d_cls, d_bbox = torch.autograd.grad(lc + lb, [cs, bp_])
+                RCNN_loss_cls, RCNN_loss_bbox = lc.detach(), lb.detach()
+                ctx.update(loss_seeds=(d_cls.contiguous(), d_bbox.contiguous()))
+                self._ctx = ctx
+                if bridge:  # loss.backward() (train.py:141-143) runs backward.frcnn_backward on the HIP kernels
+                    dev = im_data.device
+                    if self._grad_anchor is None or self._grad_anchor.device != dev:
+                        self._grad_anchor = torch.zeros(1, device=dev, requires_grad=True)
+                    rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox = _LossBridge.apply(
+                        self._grad_anchor, self, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox)
+        return (st["rois"], cls_prob.view(B, R, -1), bbox_pred.view(B, R, -1), rpn_loss_cls, rpn_loss_bbox,
                 RCNN_loss_cls, RCNN_loss_bbox, st["rois_label"])
 
 

@@ -169,11 +169,12 @@ class Trainer:
         self.steps += 1
         self.model._epoch += 1  # weights changed under the packed / Winograd-transformed copies: re-derive those
 
-    def step(self, im_data, im_info, gt_boxes, num_boxes, support_ims):
-        """one training iteration; returns the model's 8-tuple (losses detached)"""
+    def step(self, *inputs):
+        """one training iteration on the model's own forward arguments (DAnA: im_data, im_info, gt_boxes, num_boxes,
+        support_ims; frcnn: without the supports); returns the model's 8-tuple (losses detached)"""
         self.zero_grad()
         with torch.enable_grad():
-            out = self.model(im_data, im_info, gt_boxes, num_boxes, support_ims)
+            out = self.model(*inputs)
             loss = out[3].mean() + out[4].mean() + out[5].mean() + out[6].mean()  # train.py:138-139
         loss.backward()
         self.optimizer_step()

@@ -733,7 +733,9 @@ def fgn_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training
 # ------------------------------------------------------------------------------------------------
 # sibling model on the same ops: plain Faster R-CNN, lib/model/framework/faster_rcnn.py:35-103
 # ------------------------------------------------------------------------------------------------
-def frcnn_forward(sd, im_data, im_info, gt_boxes, num_boxes, training, nms_inclusive=True, pooling="align"):
+def frcnn_forward(sd, im_data, im_info, gt_boxes, num_boxes, training, nms_inclusive=True, pooling="align",
+                  differentiable=False):
+    """differentiable: RoIAlign as torch ops (roi_align_torch) so that autograd reaches the trunk (gradient tests)"""
     B = im_data.shape[0]
     base_feat = rcnn_base(im_data, sd)
     cls, prob, bbox = rpn_head(base_feat, sd)
@@ -751,7 +753,10 @@ def frcnn_forward(sd, im_data, im_info, gt_boxes, num_boxes, training, nms_inclu
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
     r5 = rois.view(-1, 5).numpy()
-    if pooling == "align":
+    if differentiable:
+        assert pooling == "align"
+        pooled = roi_align_torch(base_feat, rois.view(-1, 5), 1.0 / 16.0, 7)
+    elif pooling == "align":
         pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), r5, 1.0 / 16.0, 7, 7, 0))
     else:
         pooled = torch.from_numpy(native.roi_pool_forward(base_feat.detach().numpy(), r5, 1.0 / 16.0, 7, 7)[0])

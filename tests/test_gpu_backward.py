@@ -321,3 +321,74 @@ def test_trainer_adam_matches_torch_adam(dev):
         # share of such elements and the bulk tightly
         frac = (diff > 0.05 * lr).float().mean().item()
         assert frac <= 2e-3 and diff.mean().item() <= 2e-3 * lr, (k, frac, diff.max().item(), diff.mean().item())
+
+
+def test_frcnn_sibling_backward_vs_oracle_autograd_and_trainer_step(dev, mfma_mode):
+    """row N4 widened: the plain Faster R-CNN sibling (utils.py:109-110) trains on the HIP kernels too. Every trainable
+    parameter's gradient vs autograd through oracle.frcnn_forward (same sampled rois), then one Trainer.step through
+    the reference's `loss.backward()` contract."""
+    import dana_amd
+    from dana_amd import synthetic as S, backward as BW
+    from dana_amd.trainer import Trainer
+    from oracle import model_ref as O
+    B, H, W = 2, 192, 256
+    m = dana_amd.get_model("frcnn", pretrained=False, classes=["fg", "bg"])
+    sd = S.fill_state_dict(m.state_dict(), seed=21, profile="test")
+    m.load_state_dict(sd)
+    m.to(dev).train()
+    m.nms_inclusive = True
+    weights = (1.0, 0.5, 2.0, 1.5)
+
+    def trainable(k):
+        if "bn" in k or "downsample.1" in k or "running_" in k or "num_batches" in k:
+            return False
+        return not (k.startswith("RCNN_base.0") or k.startswith("RCNN_base.1") or k.startswith("RCNN_base.4"))
+
+    m.save_for_backward = True
+    for seed in (23, 24, 26, 27, 29, 30):  # a seed without a near tie in the proposal ranking (see the DAnA test above)
+        inputs = S.episode_inputs(B, 1, 1, H, W, seed=seed)[:4]
+        np.random.seed(33)
+        with torch.no_grad():
+            res = m(*[t.to(dev) for t in inputs])
+        np.random.seed(33)
+        with torch.no_grad():
+            probe = O.frcnn_forward(sd, *inputs, training=True, nms_inclusive=True)
+        if np.array_equal(res[7].cpu().numpy(), probe[7].numpy()) and (res[0].cpu() - probe[0]).abs().max().item() < 0.05:
+            break
+    else:
+        pytest.fail("no seed on which the HIP forward and the oracle sample the same rois")
+    osd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and trainable(k) else v.clone())
+           for k, v in sd.items()}
+    np.random.seed(33)
+    out = O.frcnn_forward(osd, *inputs, training=True, nms_inclusive=True, differentiable=True)
+    sum(wt * l for wt, l in zip(weights, out[3:7])).backward()
+    for a, b in zip(res[3:7], out[3:7]):
+        assert abs(float(a) - float(b.detach())) <= 1e-4 * max(1.0, abs(float(b.detach())))
+    BW.model_backward(m, weights)
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    gmax = max(v.grad.abs().max().item() for v in osd.values() if v.dtype.is_floating_point and v.requires_grad)
+    worst = []
+    for k, v in osd.items():
+        if not (v.dtype.is_floating_point and v.requires_grad):
+            continue
+        g = params[k].grad
+        assert g is not None, "no HIP gradient for %s" % k
+        scale = v.grad.abs().max().item() + 1e-3 * gmax
+        worst.append(((g.cpu() - v.grad).abs().max().item() / scale, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-3, "largest relative gradient errors: %s" % (worst[:8],)
+    assert len(worst) == sum(1 for p in m.parameters() if p.requires_grad)
+
+    # one iteration through the trainer (zero_grad -> forward -> summed loss -> loss.backward() -> fused SGD)
+    m.save_for_backward = False
+    for p in m.parameters():
+        p.grad = None
+    tr = Trainer(m, lr=1e-3)
+    before = {k: v.detach().clone() for k, v in m.named_parameters() if v.requires_grad}
+    np.random.seed(33)
+    o = tr.step(*[t.to(dev) for t in inputs])
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(x.detach())) for x in o[3:7])
+    moved = sum(1 for k, v in m.named_parameters() if v.requires_grad and not torch.equal(v.detach(), before[k]))
+    assert moved >= len(before) - 2, "only %d of %d trainable tensors moved" % (moved, len(before))
