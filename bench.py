@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--model", default="DAnA", choices=["DAnA", "frcnn", "fsod", "meta", "fgn"],
                     help="DAnA: the hot path (default); frcnn / fsod / meta / fgn: the sibling detectors of utils.py:109-116 (row N4) "
-                         "on the same operators -- forward modes (frcnn: the training iteration too)")
+                         "on the same operators -- forward modes (frcnn, meta: the training iteration too)")
     ap.add_argument("--support-size", type=int, default=320,
                     help="support image side. 320 = the only size the reference can run (it hard-codes the 20x20 map); "
                          "224 (BASELINE.json's wording) runs the opt-in generalised pooling: NO oracle, no parity claim")
@@ -122,8 +122,8 @@ def main():
     from dana_amd import ops, synthetic as S
     training = args.mode in ("train", "step")
     way = args.way if training else 1
-    if args.model != "DAnA" and args.mode not in ("train", "eval") and not (args.model == "frcnn" and args.mode == "step"):
-        raise SystemExit("--model %s supports --mode train / eval only (frcnn: also step)" % args.model)
+    if args.model != "DAnA" and args.mode not in ("train", "eval") and not (args.model in ("frcnn", "meta") and args.mode == "step"):
+        raise SystemExit("--model %s supports --mode train / eval only (frcnn, meta: also step)" % args.model)
     model = dana_amd.get_model(args.model, pretrained=False, use_BA_block=args.ba, way=args.way, shot=args.shot,
                                classes=["fg", "bg"])
     sd = S.fill_state_dict(model.state_dict(), seed=11, profile="test")  # random init, O(1) activations
@@ -151,8 +151,8 @@ def main():
         inputs = inputs[:4]  # faster_rcnn.py:35: (im_data, im_info, gt_boxes, num_boxes)
     elif args.model == "meta":
         inputs = inputs + [inputs[2].clone()]  # meta.py:39,48: all_cls_gt_boxes (one class in the synthetic episodes)
-    if args.model not in ("DAnA", "frcnn"):
-        args.no_train_step = True  # the HIP backward covers DAnA and the plain Faster R-CNN sibling
+    if args.model not in ("DAnA", "frcnn", "meta"):
+        args.no_train_step = True  # the HIP backward covers DAnA and the frcnn / meta siblings
 
     def fwd_step():
         with torch.no_grad():

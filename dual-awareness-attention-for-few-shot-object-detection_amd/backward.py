@@ -174,7 +174,7 @@ def _block_convs(prefix, bp):
 def grad_stages(model):
     """[(stage, [parameter names])] in the order model_backward FINISHES the gradients: the trainer lays its flat
     gradient buffer out in this order so that all-reduce buckets can leave while the rest of the backward runs."""
-    if type(model).__name__ == "FasterRCNN":
+    if type(model).__name__ in ("FasterRCNN", "MetaRCNN"):
         return frcnn_grad_stages(model)
     plan = model._get_plan()
     lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
@@ -243,7 +243,7 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     RCNN_loss_cls, RCNN_loss_bbox) of the last `save_for_backward` forward: what train.py:141-143's
     `loss.backward()` computes, accumulated into `.grad` of the trainable parameters (BN, conv1 and layer1 are
     frozen: dana.py:350-385)."""
-    if type(model).__name__ == "FasterRCNN":
+    if type(model).__name__ in ("FasterRCNN", "MetaRCNN"):
         return frcnn_backward(model, grad_losses)
     ctx = model._ctx
     plan = ctx["plan"]
@@ -450,7 +450,8 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
 def frcnn_grad_stages(model):
     plan = model._get_plan()
     lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
-    st = [("roi head", lin("RCNN_bbox_pred") + lin("RCNN_cls_score")
+    cls = "RCNN_cls_score.0" if type(model).__name__ == "MetaRCNN" else "RCNN_cls_score"  # meta.py:199-201: a Sequential
+    st = [("roi head", lin("RCNN_bbox_pred") + lin(cls)
            + [n for bi in (2, 1, 0) for n in _block_convs("RCNN_top.0.%d" % bi, plan["layer4"][bi])])]
     st.append(("rpn", lin("RCNN_rpn.RPN_cls_score") + lin("RCNN_rpn.RPN_bbox_pred") + lin("RCNN_rpn.RPN_Conv")))
     for li in (2, 1):
@@ -462,28 +463,64 @@ def frcnn_grad_stages(model):
 
 
 def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
-    """d(sum_i grad_losses[i] * loss_i)/d(parameters) of the last training forward of FasterRCNN (faster_rcnn.py:31-105):
-    RCNN_cls_score / RCNN_bbox_pred <- mean <- layer4 <- RoIAlign, RPN losses <- heads <- 3x3 conv, both into base_feat,
-    then layer3 / layer2 of the trunk (conv1, layer1 and every BN are frozen: faster_rcnn.py:129-160)."""
+    """d(sum_i grad_losses[i] * loss_i)/d(parameters) of the last training forward of FasterRCNN (faster_rcnn.py:31-105)
+    or MetaRCNN (meta.py:39-142): RoI head <- mean <- layer4 <- RoIAlign, RPN losses <- heads <- 3x3 conv, both into
+    base_feat, then layer3 / layer2 of the trunk (conv1, layer1 and every BN are frozen: faster_rcnn.py:129-160).
+    meta adds the class-attentive vectors: score = Linear(fc7 * mean_shots(sigmoid(mean(layer4(maxpool2(trunk(support)))))))
+    for the positive and the negative supports, so its support batch is differentiated through layer4 and the trunk too."""
     ctx = model._ctx
+    meta = type(model).__name__ == "MetaRCNN"
     plan, B, R, fh, fw = ctx["plan"], ctx["B"], ctx["R"], ctx["fh"], ctx["fw"]
     n_roi, hw = B * R, fh * fw
     if isinstance(grad_losses, torch.Tensor):
         g1, g2, g3, g4 = [float(x) for x in grad_losses.detach().cpu()]
     else:
         g1, g2, g3, g4 = [float(x) for x in grad_losses]
-    d_cls, d_bbox = ctx["loss_seeds"]  # d(loss_cls + loss_bbox) / d(cls_score, bbox_pred)
-    dev = d_cls.device
+    fc7 = ctx["fc7"]
+    dev = fc7.device
     grads = WeightGrads(None if getattr(model, "_single_stream", False) else model._stream("wgrad", dev), model)
     stages = frcnn_grad_stages(model)
-    C = d_cls.size(1)
-    fc7 = ctx["fc7"]
+    gs = None
+    if meta:
+        d_pos, d_neg, d_bbox = ctx["loss_seeds"]  # written by the fused mined-loss kernel (dana_rcnn_loss)
+        lin_c = model.RCNN_cls_score[0]
+        wc = lin_c.weight.detach()
+        d_fc7 = ops.gemm_small(d_bbox, (4, 1), model.RCNN_bbox_pred.weight.detach(), (2048, 1), n_roi, 2048, 4, alpha=g4)
+        Ns, shot, way = ctx["Ns"], ctx["shot"], ctx["way"]
+        att = ctx["att"]
+        d_att = torch.zeros((B, way * shot, 2048), dtype=torch.float32, device=dev)
+        for hc in ctx["heads"]:
+            ds = d_pos if hc["offset"] == 0 else d_neg
+            _acc(lin_c.weight, ops.gemm_small(ds, (1, 2), hc["comb"], (2048, 1), 2, 2048, n_roi, alpha=g3))
+            _acc(lin_c.bias, ops.colsum(ds, n_roi, 2, alpha=g3))
+            d_comb = ops.gemm_small(ds, (2, 1), wc, (2048, 1), n_roi, 2048, 2, alpha=g3)
+            d_fc7.add_(ops.scale_rows_by_group(d_comb, hc["vec"], n_roi, R, 2048))
+            # the shots' mean of the attentive vectors: d vec[b] = sum over the image's rois of d_comb * fc7
+            d_vec = (d_comb * fc7).view(B, R, 2048).sum(1) / shot
+            d_att[:, hc["offset"]:hc["offset"] + shot] += d_vec.unsqueeze(1)
+        d_pre = (d_att.view(Ns, 2048) * att * (1.0 - att)).contiguous()  # sigmoid adjoint (meta.py:250)
+        sl4 = ctx["sl4_saved"]
+        npos_s = sl4[-1]["h1"] * sl4[-1]["w1"]
+        g = ops.broadcast_rows(d_pre, Ns, npos_s, 2048, alpha=1.0 / npos_s)
+        for i, sv in enumerate(reversed(sl4)):  # the first block's input is the max-pooled map: its ReLU adjoint is the trunk's
+            g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"], mask_dx=i < len(sl4) - 1,
+                                    g_masked=i > 0)
+        # 2x2 / 2 max pool (meta.py:247) back onto the support maps: the window's (first) maximum takes the gradient
+        (sh_, sw_), (mh, mw) = ctx["sup_hw"], ctx["mp_hw"]
+        x = ctx["sup"].view(Ns, sh_, sw_, 1024).permute(0, 3, 1, 2).detach().requires_grad_(True)
+        with torch.enable_grad():
+            y = torch.nn.functional.max_pool2d(x, 2)
+        gs, = torch.autograd.grad(y, x, g.view(Ns, mh, mw, 1024).permute(0, 3, 1, 2))
+        gs = gs.permute(0, 2, 3, 1).contiguous().view(Ns * sh_ * sw_, 1024)
+    else:
+        d_cls, d_bbox = ctx["loss_seeds"]  # d(loss_cls + loss_bbox) / d(cls_score, bbox_pred)
+        C = d_cls.size(1)
+        _acc(model.RCNN_cls_score.weight, ops.gemm_small(d_cls, (1, C), fc7, (2048, 1), C, 2048, n_roi, alpha=g3))
+        _acc(model.RCNN_cls_score.bias, ops.colsum(d_cls, n_roi, C, alpha=g3))
+        d_fc7 = ops.gemm_small(d_bbox, (4, 1), model.RCNN_bbox_pred.weight.detach(), (2048, 1), n_roi, 2048, 4, alpha=g4)
+        d_fc7.add_(ops.gemm_small(d_cls, (C, 1), model.RCNN_cls_score.weight.detach(), (2048, 1), n_roi, 2048, C, alpha=g3))
     _acc(model.RCNN_bbox_pred.weight, ops.gemm_small(d_bbox, (1, 4), fc7, (2048, 1), 4, 2048, n_roi, alpha=g4))
     _acc(model.RCNN_bbox_pred.bias, ops.colsum(d_bbox, n_roi, 4, alpha=g4))
-    _acc(model.RCNN_cls_score.weight, ops.gemm_small(d_cls, (1, C), fc7, (2048, 1), C, 2048, n_roi, alpha=g3))
-    _acc(model.RCNN_cls_score.bias, ops.colsum(d_cls, n_roi, C, alpha=g3))
-    d_fc7 = ops.gemm_small(d_bbox, (4, 1), model.RCNN_bbox_pred.weight.detach(), (2048, 1), n_roi, 2048, 4, alpha=g4)
-    d_fc7.add_(ops.gemm_small(d_cls, (C, 1), model.RCNN_cls_score.weight.detach(), (2048, 1), n_roi, 2048, C, alpha=g3))
     l4 = ctx["l4_saved"]
     npos = l4[-1]["h1"] * l4[-1]["w1"]
     g = ops.broadcast_rows(d_fc7, n_roi, npos, 2048, alpha=1.0 / npos)
@@ -512,12 +549,16 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
     gq = conv_dgrad(d_x, B, fh, fw, c_rpn, residual=d_bf)  # d base_feat = RPN path + RoIAlign path
     grads.finish_all(model, "RCNN_rpn")
     _ready(model, stages[1][1])
-    qs = ctx["q_saved"]
+    qs, ss = ctx["q_saved"], ctx.get("s_saved") or []
     nblk = len(qs)
-    for i in range(nblk - 1, -1, -1):
+    for i in range(nblk - 1, -1, -1):  # query batch and (meta) support batch, block by block: shared weights
         sq = qs[i]
         gq = bottleneck_backward(gq, sq, sq["n"], sq["h"], sq["w"], sq["bp"], grads, sq["key"], need_dx=i > 0,
                                  g_masked=i < nblk - 1)
+        if gs is not None:
+            s_ = ss[i]
+            gs = bottleneck_backward(gs, s_, s_["n"], s_["h"], s_["w"], s_["bp"], grads, s_["key"], need_dx=i > 0,
+                                     g_masked=i < nblk - 1)
         grads.finish_all(model, sq["key"] + ".")
         _ready(model, _block_convs(sq["key"], sq["bp"]))
     assert not grads.packed

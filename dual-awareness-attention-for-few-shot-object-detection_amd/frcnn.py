@@ -2,8 +2,8 @@
 lib/model/framework/faster_rcnn.py:17-203 on the SAME HIP operators as the DAnA path --
 Caffe ResNet-50 trunk -> RPN -> proposal layer -> (train) anchor / proposal targets -> RoIAlign or RoIPool ->
 layer4 -> RCNN_cls_score / RCNN_bbox_pred -> losses. Same parameter tree and state_dict keys as the reference class.
-`frcnn` is trainable on the HIP kernels too: a training forward saves its context and hands the four losses to autograd
-(`_LossBridge`), `loss.backward()` runs backward.frcnn_backward (POOLING_MODE 'align'); `meta` below is forward only."""
+`frcnn` and `meta` are trainable on the HIP kernels too: a training forward saves its context and hands the four losses
+to autograd (`_LossBridge`), `loss.backward()` runs backward.frcnn_backward / meta_backward (POOLING_MODE 'align')."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -181,7 +181,7 @@ class MetaRCNN(FasterRCNN):
     """Sibling model `meta` (utils.py:113-114): Meta R-CNN, lib/model/framework/meta.py:18-251. The Predictor-head
     Remodeling Network turns every support image into a class-attentive vector, sigmoid(mean(layer4(maxpool2(trunk)))),
     the shots' mean multiplies the RoI features channel-wise in front of a 2-way Linear; positive + negative supports
-    and the 1:2:1 hard-negative-mined loss as in DAnA. Forward only."""
+    and the 1:2:1 hard-negative-mined loss as in DAnA. Trainable: backward.meta_backward."""
 
     def __init__(self, classes, num_layers=50, pretrained=False, num_way=2, num_shot=5):
         self.n_way, self.n_shot = num_way, num_shot
@@ -201,16 +201,23 @@ class MetaRCNN(FasterRCNN):
         training = self.training
         shot = self.n_shot
         way = self.n_way if training else 1
-        st = self._stages(im_data, im_info, gt_boxes, anchor_gt_boxes=all_cls_gt_boxes)
+        ctx = None
+        bridge = training and torch.is_grad_enabled()
+        if training and (bridge or getattr(self, "save_for_backward", False)):
+            if cfg.POOLING_MODE != "align":
+                raise NotImplementedError("the HIP backward of meta covers POOLING_MODE 'align'")
+            ctx = dict(q_saved=[], l4_saved=[], s_saved=[], sl4_saved=[], heads=[])
+        self._ctx = None
+        st = self._stages(im_data, im_info, gt_boxes, anchor_gt_boxes=all_cls_gt_boxes, ctx=ctx)
         B, R, n_roi, fc7, plan = st["B"], st["R"], st["n_roi"], st["fc7"], st["plan"]
         # PRN (meta.py:241-251) on every support image
         sup_ims = support_ims.reshape(-1, support_ims.size(2), support_ims.size(3), support_ims.size(4))
         Ns = sup_ims.size(0)
         if Ns != B * way * shot:
             raise RuntimeError("support_ims must hold batch*way*shot = %d images, got %d" % (B * way * shot, Ns))
-        sup, sh_, sw_ = self._rcnn_base(sup_ims, plan)
+        sup, sh_, sw_ = self._rcnn_base(sup_ims, plan, save=ctx["s_saved"] if ctx is not None else None)
         mp, mh, mw = ops.maxpool2x2s2(sup, Ns, sh_, sw_, 1024)
-        att = ops.sigmoid_(self._head_to_tail(mp, Ns, mh, mw, plan))  # [Ns][2048]
+        att = ops.sigmoid_(self._head_to_tail(mp, Ns, mh, mw, plan, save=ctx["sl4_saved"] if ctx is not None else None))
         wb, bb = self._w(self.RCNN_bbox_pred)
         wc, bc = self._w(self.RCNN_cls_score[0])
         bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
@@ -221,17 +228,29 @@ class MetaRCNN(FasterRCNN):
                 vec[b:b + 1] = ops.spatial_mean(att.view(-1)[(b * way * shot + offset) * 2048:], 1, shot, 2048)
             comb = ops.scale_rows_by_group(fc7, vec, n_roi, R, 2048)
             score = ops.gemm_nt(comb, wc, n_roi, 2, 2048, shift=bc)
+            if ctx is not None:
+                ctx["heads"].append(dict(offset=offset, vec=vec, comb=comb))
             return ops.softmax_rows_(score.clone(), n_roi, 2), score
 
         cls_prob, cls_score = head(0)
         RCNN_loss_cls = RCNN_loss_bbox = 0
         rois_label = st["rois_label"]
+        rpn_loss_cls, rpn_loss_bbox = st["rpn_loss_cls"], st["rpn_loss_bbox"]
         if training:
             neg_prob, neg_score = head(shot)
             cls_prob = torch.cat([cls_prob, neg_prob], 0)
             rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
-            rl, _ = ops.rcnn_losses(cls_score, neg_score, st["labels_f"], bbox_pred, st["rois_target"].contiguous(),
-                                    st["rois_inside_ws"].contiguous(), st["rois_outside_ws"].contiguous())
+            rl, seeds = ops.rcnn_losses(cls_score, neg_score, st["labels_f"], bbox_pred, st["rois_target"].contiguous(),
+                                        st["rois_inside_ws"].contiguous(), st["rois_outside_ws"].contiguous(),
+                                        with_grad=ctx is not None)
             RCNN_loss_cls, RCNN_loss_bbox = rl[0], rl[1]
-        return (st["rois"], cls_prob, bbox_pred, st["rpn_loss_cls"], st["rpn_loss_bbox"], RCNN_loss_cls, RCNN_loss_bbox,
-                rois_label)
+            if ctx is not None:
+                ctx.update(loss_seeds=seeds, att=att, sup=sup, sup_hw=(sh_, sw_), mp_hw=(mh, mw), Ns=Ns, shot=shot, way=way)
+                self._ctx = ctx
+                if bridge:  # loss.backward() (train.py:141-143) runs backward.meta_backward on the HIP kernels
+                    dev = im_data.device
+                    if self._grad_anchor is None or self._grad_anchor.device != dev:
+                        self._grad_anchor = torch.zeros(1, device=dev, requires_grad=True)
+                    rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox = _LossBridge.apply(
+                        self._grad_anchor, self, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox)
+        return (st["rois"], cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox, rois_label)

@@ -323,16 +323,17 @@ def test_trainer_adam_matches_torch_adam(dev):
         assert frac <= 2e-3 and diff.mean().item() <= 2e-3 * lr, (k, frac, diff.max().item(), diff.mean().item())
 
 
-def test_frcnn_sibling_backward_vs_oracle_autograd_and_trainer_step(dev, mfma_mode):
-    """row N4 widened: the plain Faster R-CNN sibling (utils.py:109-110) trains on the HIP kernels too. Every trainable
-    parameter's gradient vs autograd through oracle.frcnn_forward (same sampled rois), then one Trainer.step through
-    the reference's `loss.backward()` contract."""
+@pytest.mark.parametrize("name", ["frcnn", "meta"])
+def test_sibling_backward_vs_oracle_autograd_and_trainer_step(dev, mfma_mode, name):
+    """row N4 widened: the plain Faster R-CNN (utils.py:109-110) and the Meta R-CNN (utils.py:113-114) siblings train on
+    the HIP kernels too. Every trainable parameter's gradient vs autograd through the oracle's forward of that model
+    (same sampled rois), then one Trainer.step through the reference's `loss.backward()` contract."""
     import dana_amd
     from dana_amd import synthetic as S, backward as BW
     from dana_amd.trainer import Trainer
     from oracle import model_ref as O
-    B, H, W = 2, 192, 256
-    m = dana_amd.get_model("frcnn", pretrained=False, classes=["fg", "bg"])
+    B, H, W, way, shot = 2, 192, 256, 2, 2
+    m = dana_amd.get_model(name, pretrained=False, way=way, shot=shot, classes=["fg", "bg"])
     sd = S.fill_state_dict(m.state_dict(), seed=21, profile="test")
     m.load_state_dict(sd)
     m.to(dev).train()
@@ -344,15 +345,24 @@ def test_frcnn_sibling_backward_vs_oracle_autograd_and_trainer_step(dev, mfma_mo
             return False
         return not (k.startswith("RCNN_base.0") or k.startswith("RCNN_base.1") or k.startswith("RCNN_base.4"))
 
+    def episode(seed):
+        e = S.episode_inputs(B, way, shot, H, W, seed=seed)
+        return e[:4] if name == "frcnn" else list(e) + [e[2].clone()]  # meta.py:39,48: all_cls_gt_boxes
+
+    def oracle(state, inputs, **kw):
+        if name == "frcnn":
+            return O.frcnn_forward(state, *inputs, training=True, nms_inclusive=True, **kw)
+        return O.meta_forward(state, *inputs, training=True, n_way=way, n_shot=shot, nms_inclusive=True, **kw)
+
     m.save_for_backward = True
     for seed in (23, 24, 26, 27, 29, 30):  # a seed without a near tie in the proposal ranking (see the DAnA test above)
-        inputs = S.episode_inputs(B, 1, 1, H, W, seed=seed)[:4]
+        inputs = episode(seed)
         np.random.seed(33)
         with torch.no_grad():
             res = m(*[t.to(dev) for t in inputs])
         np.random.seed(33)
         with torch.no_grad():
-            probe = O.frcnn_forward(sd, *inputs, training=True, nms_inclusive=True)
+            probe = oracle(sd, inputs)
         if np.array_equal(res[7].cpu().numpy(), probe[7].numpy()) and (res[0].cpu() - probe[0]).abs().max().item() < 0.05:
             break
     else:
@@ -360,7 +370,7 @@ def test_frcnn_sibling_backward_vs_oracle_autograd_and_trainer_step(dev, mfma_mo
     osd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and trainable(k) else v.clone())
            for k, v in sd.items()}
     np.random.seed(33)
-    out = O.frcnn_forward(osd, *inputs, training=True, nms_inclusive=True, differentiable=True)
+    out = oracle(osd, inputs, differentiable=True)
     sum(wt * l for wt, l in zip(weights, out[3:7])).backward()
     for a, b in zip(res[3:7], out[3:7]):
         assert abs(float(a) - float(b.detach())) <= 1e-4 * max(1.0, abs(float(b.detach())))
