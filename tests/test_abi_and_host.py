@@ -44,6 +44,19 @@ def test_argument_errors_are_reported_without_a_gpu():
     L.call("dana_roi_align_forward", None, None, None, 1, 8, 8, 8, 0, 1.0, 7, 7, 0, 0, 0, 0, None, None, 0, None)
 
 
+def test_mfma_mode_switch_roundtrip_and_errors():
+    """dana_set_mfma_mode / dana_get_mfma_mode (host-side state only: no GPU needed)"""
+    L = _lib.lib()
+    prev = ops.get_mfma_mode()
+    assert prev in (0, 1, 2, 3, 4)
+    assert ops.set_mfma_mode(0) == prev and ops.get_mfma_mode() == 0
+    assert ops.set_mfma_mode(1) == 0 and ops.get_mfma_mode() == 1
+    with pytest.raises(_lib.DanaError, match="mode must be"):
+        L.call("dana_set_mfma_mode", 7)
+    assert ops.get_mfma_mode() == 1
+    ops.set_mfma_mode(prev)
+
+
 def test_ops_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU"):
         ops.roi_align_forward(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 1.0, 7, 7, 0)
