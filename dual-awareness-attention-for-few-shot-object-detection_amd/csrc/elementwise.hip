@@ -187,6 +187,50 @@ avgpool_rows_kernel(const float4* __restrict__ in, float4* __restrict__ out, int
   }
 }
 
+// stride-1 pooling of a small map (the 20x20 -> 7x7 support pooling, dana.py:105-108) as a separable box filter through
+// LDS: a workgroup owns (image, 16 channels), reads its H x W x 16 slab ONCE (the rows kernel above re-read every input
+// row from up to 7 output rows and ran 168 workgroups of 280 dependent loads: 150 us for a 39 MB input), sums the k
+// columns of every window into a second LDS image and the k rows of that into the output.
+constexpr int AP_CH4 = 4;  // float4s (= 16 channels) per workgroup
+__global__ void __launch_bounds__(256)
+avgpool_tile_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, int W, int OH, int OW, int C4, int k) {
+  extern __shared__ __attribute__((aligned(16))) float4 ap_lds[];  // [H*W][AP_CH4] then [H*OW][AP_CH4]
+  float4* tile = ap_lds;
+  float4* hsum = ap_lds + H * W * AP_CH4;
+  const int groups = C4 / AP_CH4;
+  const long b = blockIdx.x / groups;
+  const int c0 = (blockIdx.x % groups) * AP_CH4;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < H * W * AP_CH4; i += 256) tile[i] = in[(b * H * W + i / AP_CH4) * C4 + c0 + (i % AP_CH4)];
+  __syncthreads();
+  for (int i = tid; i < H * OW * AP_CH4; i += 256) {
+    const int q = i % AP_CH4, ox = (i / AP_CH4) % OW, y = i / AP_CH4 / OW;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dx = 0; dx < k; ++dx) {
+      const float4 v = tile[(y * W + ox + dx) * AP_CH4 + q];
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+    hsum[i] = s;
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)(k * k);
+  for (int i = tid; i < OH * OW * AP_CH4; i += 256) {
+    const int q = i % AP_CH4, ox = (i / AP_CH4) % OW, oy = i / AP_CH4 / OW;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy = 0; dy < k; ++dy) {
+      const float4 v = hsum[((oy + dy) * OW + ox) * AP_CH4 + q];
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+    out[((b * OH + oy) * OW + ox) * C4 + c0 + q] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+
 // out[g][c] = mean_p in[g][p][c]
 __global__ void __launch_bounds__(256)
 spatial_mean_kernel(const float4* __restrict__ in, float4* __restrict__ out, int P, int C4, long ldi4, long total) {
@@ -416,7 +460,11 @@ int dana_avgpool_nhwc(const float* in, float* out, int batch, int height, int wi
   DANA_CHECK_ARG(in && out, "dana_avgpool_nhwc: null pointer");
   const int oh = (height - k) / stride + 1, ow = (width - k) / stride + 1;
   const long total = (long)batch * oh * ow * (channels / 4);
-  if (stride == 1 && ow <= 8) {
+  const size_t tile_lds = (size_t)(height * width + height * ow) * AP_CH4 * sizeof(float4);
+  if (stride == 1 && (channels / 4) % AP_CH4 == 0 && tile_lds <= 48 * 1024 && height * width >= 64) {
+    avgpool_tile_kernel<<<(unsigned)((long)batch * (channels / 4 / AP_CH4)), 256, tile_lds, (hipStream_t)stream>>>(
+        (const float4*)in, (float4*)out, height, width, oh, ow, channels / 4, k);
+  } else if (stride == 1 && ow <= 8) {
     const long rows_total = (long)batch * oh * (channels / 4);
     avgpool_rows_kernel<<<grid_for(rows_total, 256), 256, 0, (hipStream_t)stream>>>(
         (const float4*)in, (float4*)out, height, width, oh, ow, channels / 4, k, rows_total);
