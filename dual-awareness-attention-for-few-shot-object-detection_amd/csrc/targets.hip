@@ -508,7 +508,7 @@ rcnn_loss_a_kernel(const float* __restrict__ sp, const float* __restrict__ sn, c
 
 __global__ void __launch_bounds__(256)
 rcnn_loss_b_kernel(const float* __restrict__ sp, const float* __restrict__ sn, const float* __restrict__ labels, int n,
-                   int blocks, RcnnLossWs ws, float* __restrict__ gsp, float* __restrict__ gsn) {
+                   int blocks, RcnnLossWs ws, float* __restrict__ gsp, float* __restrict__ gsn, int use_lds) {
   __shared__ float red[2][4];
   __shared__ int s_fg;
   if (threadIdx.x == 0) {
@@ -516,8 +516,15 @@ rcnn_loss_b_kernel(const float* __restrict__ sp, const float* __restrict__ sn, c
     for (int i = 0; i < blocks; ++i) c += ws.partial[i * 4];
     s_fg = (int)c;
   }
+  // the rank loop below reads every background probability of the row's half: staged in LDS once per workgroup (a row
+  // that is not background gets -inf, so the loop needs no label test); from global memory the 2n dependent-latency
+  // iterations made this kernel 115 us of the step's serial tail
+  extern __shared__ float s_p1[];  // [2n] when use_lds
+  const int n_all = 2 * n;
+  if (use_lds)
+    for (int j = threadIdx.x; j < n_all; j += 256) s_p1[j] = (j < n ? labels[j] : 0.f) == 0.f ? ws.p1[j] : -INFINITY;
   __syncthreads();
-  const int n_all = 2 * n, nfg = s_fg;
+  const int nfg = s_fg;
   const int bg0 = max(1, min(nfg * 2, (int)(n_all * 0.25)));  // dana.py:207-208
   const int bg1 = max(1, min(nfg, bg0));
   const int r = blockIdx.x * 256 + threadIdx.x;
@@ -529,10 +536,17 @@ rcnn_loss_b_kernel(const float* __restrict__ sp, const float* __restrict__ sn, c
       const int h0 = r < n ? 0 : n, h1 = r < n ? n : n_all;
       const float mine = ws.p1[r];
       int rank = 0;
-      for (int j = h0; j < h1; ++j) {
-        const float lj = j < n ? labels[j] : 0.f;
-        const float pj = ws.p1[j];
-        rank += (lj == 0.f && (pj > mine || (pj == mine && j < r))) ? 1 : 0;
+      if (use_lds) {
+        for (int j = h0; j < h1; ++j) {
+          const float pj = s_p1[j];
+          rank += (pj > mine || (pj == mine && j < r)) ? 1 : 0;
+        }
+      } else {
+        for (int j = h0; j < h1; ++j) {
+          const float lj = j < n ? labels[j] : 0.f;
+          const float pj = ws.p1[j];
+          rank += (lj == 0.f && (pj > mine || (pj == mine && j < r))) ? 1 : 0;
+        }
       }
       sel = rank < (r < n ? bg0 : bg1);
     }
@@ -617,7 +631,10 @@ int dana_rcnn_loss(const float* score_pos, const float* score_neg, const float* 
   rcnn_loss_a_kernel<<<blocks, 256, 0, s>>>(score_pos, score_neg, labels, bbox_pred, bbox_targets, inside_weights,
                                             outside_weights, n, sigma, ws, grad_bbox);
   DANA_CHECK_LAUNCH("dana_rcnn_loss(a)");
-  rcnn_loss_b_kernel<<<blocks, 256, 0, s>>>(score_pos, score_neg, labels, n, blocks, ws, grad_score_pos, grad_score_neg);
+  const size_t b_lds = (size_t)2 * n * sizeof(float);
+  const int use_lds = b_lds <= 48 * 1024;
+  rcnn_loss_b_kernel<<<blocks, 256, use_lds ? b_lds : 0, s>>>(score_pos, score_neg, labels, n, blocks, ws, grad_score_pos,
+                                                             grad_score_neg, use_lds);
   DANA_CHECK_LAUNCH("dana_rcnn_loss(b)");
   rcnn_loss_c_kernel<<<blocks, 256, 0, s>>>(n, blocks, ws, losses3, grad_score_pos, grad_score_neg);
   DANA_CHECK_LAUNCH("dana_rcnn_loss(c)");
