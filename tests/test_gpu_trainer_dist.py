@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, same_inputs, q):
+def _worker(rank, world, port, same_inputs, q, name="DAnA"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
@@ -33,13 +33,15 @@ def _worker(rank, world, port, same_inputs, q):
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         dev = torch.device("cuda:0")
-        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=2, shot=2, classes=["fg", "bg"])
+        m = dana_amd.get_model(name, pretrained=False, use_BA_block=False, way=2, shot=2, classes=["fg", "bg"])
         # rank 1 starts from DIFFERENT weights: the trainer's broadcast must overwrite them with rank 0's
         m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=5 + rank, profile="test"))
         m.to(dev).train()
         tr = Trainer(m, 0.01, bucket_bytes=8 << 20)
         seed = 6 if same_inputs else 6 + rank
         inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=seed)]
+        if name == "frcnn":
+            inputs = inputs[:4]  # faster_rcnn.py:35: no supports
         for it in range(2):
             np.random.seed(40 + it)
             tr.step(*inputs)
@@ -55,12 +57,12 @@ def _worker(rank, world, port, same_inputs, q):
             dist.destroy_process_group()
 
 
-def _run(world, same_inputs):
+def _run(world, same_inputs, name="DAnA"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, same_inputs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, same_inputs, q, name)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
@@ -83,3 +85,13 @@ def test_two_rank_training_iteration_over_gloo_on_one_gpu(dev):
     diff = _run(2, False)
     assert np.array_equal(diff[0][2], diff[1][2])  # different shards: replicas stay bit-identical
     assert np.abs(diff[0][2] - single[2]).max() > 0  # and the other shard's gradient did arrive
+
+
+def test_two_rank_training_iteration_of_the_frcnn_sibling(dev):
+    """the same exchange for the plain Faster R-CNN sibling (backward.frcnn_backward marks its own gradient stages)"""
+    single = _run(1, True, "frcnn")[0]
+    same = _run(2, True, "frcnn")
+    for r in same:
+        d = np.abs(r[2] - single[2]).max()
+        assert d <= 1e-6 + 1e-5 * np.abs(single[2]).max(), d
+    assert same[0][3] >= 2
