@@ -79,9 +79,9 @@ def test_two_rank_training_iteration_over_gloo_on_one_gpu(dev):
     assert same[0][3] >= 3  # several buckets: the exchange really was bucketed
     # identical shards on both ranks: the averaged gradient IS the single-rank gradient (and rank 1's different
     # initial weights were replaced by rank 0's)
-    for r in same:
+    for r in same:  # (up to the order of the RoIAlign-backward atomics; a missing 1/world would be >= 1e-2)
         d = np.abs(r[2] - single[2]).max()
-        assert d <= 1e-6 + 1e-5 * np.abs(single[2]).max(), d
+        assert d <= 1e-6 + 1e-4 * np.abs(single[2]).max(), d
     diff = _run(2, False)
     assert np.array_equal(diff[0][2], diff[1][2])  # different shards: replicas stay bit-identical
     assert np.abs(diff[0][2] - single[2]).max() > 0  # and the other shard's gradient did arrive
@@ -91,7 +91,10 @@ def test_two_rank_training_iteration_of_the_frcnn_sibling(dev):
     """the same exchange for the plain Faster R-CNN sibling (backward.frcnn_backward marks its own gradient stages)"""
     single = _run(1, True, "frcnn")[0]
     same = _run(2, True, "frcnn")
+    assert np.array_equal(same[0][2], same[1][2])  # the replicas stay bit-identical
     for r in same:
+        # identical shards: the averaged gradient is the single-rank gradient up to the order of the RoIAlign-backward
+        # atomics (run-to-run ~1e-5 after two steps at lr 0.01; a missing 1/world or a lost bucket would be >= 1e-2)
         d = np.abs(r[2] - single[2]).max()
-        assert d <= 1e-6 + 1e-5 * np.abs(single[2]).max(), d
+        assert d <= 5e-4 * np.abs(single[2]).max(), d
     assert same[0][3] >= 2
