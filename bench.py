@@ -36,8 +36,8 @@ PEAK_SPLIT_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="episodes per GPU per step")
     ap.add_argument("--way", type=int, default=2)
     ap.add_argument("--shot", type=int, default=3)
@@ -49,7 +49,14 @@ def parse():
     ap.add_argument("--support-size", type=int, default=320,
                     help="support image side. 320 = the only size the reference can run (it hard-codes the 20x20 map); "
                          "224 (BASELINE.json's wording) runs the opt-in generalised pooling: NO oracle, no parity claim")
-    ap.add_argument("--ba", action="store_true", help="full BA+CISA (configs[2]); default CISA only (configs[1])")
+    ap.add_argument("--ba", dest="ba", action="store_true", default=True,
+                    help="full BA+CISA attention = BASELINE configs[2], the reference's own default (utils.py:108, "
+                         "train.py:72 never passes use_BA_block): the headline")
+    ap.add_argument("--no-ba", dest="ba", action="store_false", help="CISA only (configs[1])")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the nested rocprofv3 --pmc passes (HBM traffic / MFMA busy of the dominant kernel); "
+                         "roofline.traffic then comes from profiles/ and says so")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs[1] (CISA only) measurement")
     ap.add_argument("--mode", default="train", choices=["train", "eval", "infer", "step"],
                     help="train: train-mode forward (variant F, the headline); eval: inference forward; infer: inference "
                          "forward + per-image detection post-processing (the loop of inference.py:96-142); step: the full "
@@ -92,6 +99,64 @@ def cpu_baseline(args, sd):
                                                                           way * args.shot, args.mode, cores, dt)}
 
 
+def pmc_passes(args, kernel):
+    """Nested `rocprofv3 --pmc <group> --kernel-trace` runs of this script (few steps, single stream, no roofline / CPU
+    legs), one counter group per pass -> per-launch HBM bytes and matrix-core busy fraction of `kernel`.
+    Returns None when rocprofv3 is unavailable or a pass fails (the caller then falls back to profiles/)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+            "--no-train-step", "--single-stream", "--no-pmc", "--no-secondary", "--batch", str(args.batch),
+            "--way", str(args.way), "--shot", str(args.shot), "--height", str(args.height), "--width", str(args.width),
+            "--mode", args.mode] + ([] if args.ba else ["--no-ba"])
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    short = kernel.replace(" ", "")
+    sums = {}
+    for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]):
+        out = tempfile.mkdtemp(prefix="dana_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc"] + group + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + base
+        try:
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                  start_new_session=True)
+            try:
+                pr.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                return None
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if pr.returncode != 0 or not files:
+                return None
+            with open(files[0]) as fh:
+                for r in csv.DictReader(fh):
+                    if r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace(" ", "").startswith(short):
+                        a = sums.setdefault(r["Counter_Name"], [0.0, 0])
+                        a[0] += float(r["Counter_Value"])
+                        a[1] += 1
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    if "FETCH_SIZE" not in sums or "WRITE_SIZE" not in sums:
+        return None
+    kb = 2.0 * sums["FETCH_SIZE"][0] / sums["FETCH_SIZE"][1] + sums["WRITE_SIZE"][0] / sums["WRITE_SIZE"][1]
+    res = {"traffic": round(kb * 1024.0),
+           "traffic_unit": "HBM bytes per %s launch: (2 x FETCH_SIZE + WRITE_SIZE) KB, rocprofv3 --pmc, this run" % kernel,
+           "traffic_launches_sampled": sums["FETCH_SIZE"][1]}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in sums and "GRBM_GUI_ACTIVE" in sums and sums["GRBM_GUI_ACTIVE"][0] > 0:
+        # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMD matrix pipes (256 CUs x 4); rocprofv3 sums
+        # GRBM_GUI_ACTIVE over the 8 XCDs, so /8 is the launch's duration in shader cycles -> fraction of the chip's
+        # matrix-pipe cycles spent executing MFMAs (clock-independent)
+        res["mfma_busy"] = round(sums["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (sums["GRBM_GUI_ACTIVE"][0] / 8.0 * 1024.0), 4)
+        res["mfma_busy_is"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) over the %s launches" % kernel
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +182,12 @@ def main():
             dist.barrier(device_ids=[local])
         else:
             dist.barrier()
+
+    rccl_ranks_seen = None
+    if world > 1:  # one tiny all_reduce before anything else: how many ranks does the collective backend really span?
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        rccl_ranks_seen = int(one.item())
 
     import dana_amd
     from dana_amd import ops, synthetic as S
@@ -207,6 +278,8 @@ def main():
         "value": round(world * args.batch * args.steps / dt, 3),
         "unit": "query-images/sec",
         "n_gpus": world,
+        "rccl_ranks_seen": rccl_ranks_seen,  # sum of ones over the process group (None at N = 1: no group)
+        "collective_backend": (("RCCL (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(1000.0 * dt / args.steps, 3),
@@ -215,7 +288,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32 (operands, accumulation, results; multiplies as an exact bf16x3 split, six bf16 MFMA products each)"
+                 if ops.get_mfma_mode() else "f32",
         "data": "synthetic (seeded N(0,64^2) query/support pixels, 3 gt boxes/image, random-init weights)",
         "config": {"workload": ("" if args.model == "DAnA" else "[sibling detector '%s'] " % args.model) +
                                "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d %dx%d "
@@ -279,80 +353,132 @@ def main():
             prof, ops.PROFILE = ops.PROFILE, None
             return prof
 
+        def family(rows):
+            f = sum(r[1] for r in rows)
+            x = sum(r[5] for r in rows)
+            t = sum(r[2].elapsed_time(r[3]) for r in rows) * 1e-3
+            return f, x, t
+
         split = ops.get_mfma_mode() != 0
         prof = contraction_pass()
-        flops = sum(p[1] for p in prof)
-        ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+        flops, executed, secs = family(prof)
+        ms = secs * 1e3
         launches = len(prof) // args.steps
-        achieved = flops / (ms * 1e-3) / 1e12
+        achieved = flops / secs / 1e12
         by = {}
-        for tag, f, e0, e1, _nb in prof:
-            a = by.setdefault(tag.split(" ")[0], [0.0, 0.0, 0])
-            a[0] += f
-            a[1] += e0.elapsed_time(e1)
+        for row in prof:
+            a = by.setdefault(row[0].split(" ")[0], [0.0, 0.0, 0])
+            a[0] += row[1]
+            a[1] += row[2].elapsed_time(row[3])
             a[2] += 1
-        # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this very
-        # command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py -> profiles/): bytes per launch,
-        # next to the algorithmic bytes per launch (each operand / result of a launch touched once)
-        traffic, traffic_kernel = None, "igemm_split_kernel<128, 128, 0>" if split else "igemm_f32_kernel<64, 64, 0>"
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
-                traffic = round(json.load(fh)[traffic_kernel]["hbm_bytes_per_launch_corrected"])
-        except (OSError, KeyError, ValueError):
-            pass
-        mfma = [p for p in prof if not p[0].startswith("conv7x7") and " N=2 " not in p[0] and " N=4 " not in p[0]]
+        mfma = [r for r in prof if not r[0].startswith("conv7x7") and " N=2 " not in r[0] and " N=4 " not in r[0]]
         peak = PEAK_SPLIT_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+        wino = [r for r in prof if r[0].startswith("wino")]
+        direct = [r for r in prof if not r[0].startswith("wino")]
+        fw, xw, tw = family(wino) if wino else (0.0, 0.0, 1e-9)
+        fd, xd, td = family(direct)
+        traffic_kernel = "igemm_split_kernel<128, 128, 0>" if split else "igemm_f32_kernel<64, 64, 0>"
         result["roofline"] = {
             "bound": "mfma",
             "kernel": ("igemm_split_kernel (fp32 operands split exactly into 3 bf16 each, 6 x v_mfma_f32_32x32x16_bf16 per "
                        "K=16, fp32 accumulation)" if split else
                        "igemm_f32_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)"),
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_unit": "HBM bytes per %s launch (PMC, profiles/r1_pmc_traffic.json)" % traffic_kernel,
-            "algorithmic_bytes_per_launch": round(sum(p[4] for p in mfma) / max(len(mfma), 1)),
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": round(sum(r[4] for r in mfma) / max(len(mfma), 1)),
             "launches_per_step": launches,
             "algorithmic_gflop_per_step": round(flops / args.steps / 1e9, 1),
+            "executed_gflop_per_step": round(executed / args.steps / 1e9, 1),
             "kernel_ms_per_step": round(ms / args.steps, 3),
+            # the two sub-families, separately: launches that run the DIRECT contraction (algorithmic == executed
+            # multiply-adds) and the Winograd F(4x4,3x3) launches (input transform + 36 plane GEMMs + output transform
+            # in one timed bracket: 4x fewer multiply-adds than the algorithmic figure they are priced at)
+            "families": {
+                "direct": {"algorithmic_tflops": round(fd / td / 1e12, 2), "frac_of_peak": round(fd / td / 1e12 / peak, 4),
+                           "ms_per_step": round(td * 1e3 / args.steps, 3), "gflop_per_step": round(fd / args.steps / 1e9, 1)},
+                "winograd": {"algorithmic_tflops": round(fw / tw / 1e12, 2), "executed_tflops": round(xw / tw / 1e12, 2),
+                             "executed_frac_of_peak": round(xw / tw / 1e12 / peak, 4),
+                             "ms_per_step": round(tw * 1e3 / args.steps, 3),
+                             "algorithmic_gflop_per_step": round(fw / args.steps / 1e9, 1),
+                             "executed_gflop_per_step": round(xw / args.steps / 1e9, 1)} if wino else None,
+            },
             "by_kind_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in by.items()},
             "whole_step_tflops": round(flops / args.steps / (dt / args.steps) / 1e12, 2),
         }
         if split:
-            # `achieved` counts ALGORITHMIC fp32 FLOPs (2 per multiply-add of the convolution); the matrix cores issue
-            # six bf16 products for each, so the peak is the bf16 dense peak / 6. For reference: the same step and the
-            # same contraction pass with every contraction on the f32 MFMA (dana_set_mfma_mode(0)).
+            # `achieved` counts ALGORITHMIC fp32 FLOPs (2 per multiply-add of the direct convolution); the matrix cores
+            # issue six bf16 products for each EXECUTED multiply-add, so the peak is the bf16 dense peak / 6.
             result["roofline"]["peak_is"] = "%.1f TFLOP/s bf16 dense MFMA / 6 products per fp32 multiply" % PEAK_BF16_MFMA_TFLOPS
-            result["roofline"]["mfma_issued_tflops"] = round(6.0 * achieved, 1)
+            result["roofline"]["mfma_issued_tflops"] = round(6.0 * executed / secs / 1e12, 1)  # what the matrix cores ran
+            result["roofline"]["mfma_issued_frac_of_bf16_peak"] = round(6.0 * executed / secs / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
             result["roofline"]["vs_f32_mfma_peak"] = round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)
+        if args.dump_launches:
+            per = {}
+            for i, row in enumerate(prof):
+                a = per.setdefault((i % launches, row[0]), [row[1], 0.0, row[5]])
+                a[1] += row[2].elapsed_time(row[3]) / args.steps
+            with open(args.dump_launches, "w") as fh:
+                for (i, tag), (f, t, x) in sorted(per.items()):
+                    fh.write("%3d %-40s %9.2f GF %9.1f us %7.2f TF/s (executed %7.2f)\n" % (
+                        i, tag, f / 1e9, t * 1e3, f / t / 1e9, x / t / 1e9))
+        # HBM traffic and matrix-core busy cycles of the dominant kernel from PMC counters, measured NOW: nested
+        # rocprofv3 --pmc passes over this very command (short, single-stream), one counter group per pass, corrected as
+        # MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 64 B per 128-B request of wide reads: doubled).
+        pmc = None if args.no_pmc else pmc_passes(args, traffic_kernel)
+        if pmc is not None:
+            result["roofline"].update(pmc)
+        else:
+            try:
+                with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as fh:
+                    j = json.load(fh)
+                result["roofline"]["traffic"] = round(j[traffic_kernel]["hbm_bytes_per_launch_corrected"])
+                result["roofline"]["traffic_source"] = "profiles/r2_pmc_traffic.json (committed PMC run, not this run)"
+            except (OSError, KeyError, ValueError):
+                pass
+        if split and not args.no_secondary:
+            # For reference: the same step and the same contraction pass with every contraction on the f32 MFMA.
             ops.set_mfma_mode(0)
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
+            k0 = max(5, args.steps // 4)
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(k0):
                 step()
             torch.cuda.synchronize()
             dt0 = time.perf_counter() - t0
+            keep_steps, args.steps = args.steps, k0
             prof0 = contraction_pass()
-            ms0 = sum(p[2].elapsed_time(p[3]) for p in prof0)
-            ach0 = sum(p[1] for p in prof0) / (ms0 * 1e-3) / 1e12
+            args.steps = keep_steps
+            f0, _x0, t0s = family(prof0)
             ops.set_mfma_mode(1)
             result["f32_mfma_only"] = {
-                "value": round(args.batch * args.steps / dt0, 3), "unit": result["unit"],
-                "ms_per_step": round(dt0 / args.steps * 1e3, 3),
+                "value": round(args.batch * k0 / dt0, 3), "unit": result["unit"],
+                "ms_per_step": round(dt0 / k0 * 1e3, 3),
                 "roofline": {"bound": "mfma", "kernel": "igemm_f32_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)",
-                             "achieved": round(ach0, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(ach0 / PEAK_FP32_MFMA_TFLOPS, 4),
-                             "kernel_ms_per_step": round(ms0 / args.steps, 3)},
+                             "achieved": round(f0 / t0s / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(f0 / t0s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                             "kernel_ms_per_step": round(t0s * 1e3 / k0, 3)},
             }
-        if args.dump_launches:
-            per = {}
-            for i, (tag, f, e0, e1, _nb) in enumerate(prof):
-                a = per.setdefault((i % launches, tag), [f, 0.0])
-                a[1] += e0.elapsed_time(e1) / args.steps
-            with open(args.dump_launches, "w") as fh:
-                for (i, tag), (f, t) in sorted(per.items()):
-                    fh.write("%3d %-40s %9.2f GF %9.1f us %7.2f TF/s\n" % (i, tag, f / 1e9, t * 1e3, f / t / 1e9))
+    if rank == 0 and world == 1 and args.mode == "train" and args.ba and not args.no_secondary and args.model == "DAnA":
+        # secondary object: BASELINE configs[1] (CISA only, use_BA_block=False) on the same episodes
+        m1 = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=args.way, shot=args.shot, classes=["fg", "bg"])
+        m1.load_state_dict(S.fill_state_dict(m1.state_dict(), seed=11, profile="test"))
+        m1.to(dev).train()
+        m1.device_rng = bool(args.device_rng)
+        k1 = max(10, args.steps // 2)
+        with torch.no_grad():
+            for _ in range(5):
+                m1(*inputs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k1):
+                m1(*inputs)
+            torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t0
+        result["configs_1_cisa_only"] = {"value": round(args.batch * k1 / dt1, 3), "unit": "query-images/sec",
+                                         "ms_per_step": round(1e3 * dt1 / k1, 3), "steps": k1}
+        del m1
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.support_size == 320 and args.model == "DAnA":
         result["cpu_baseline"] = cpu_baseline(args, sd)  # (the oracle, like the reference, only runs 320x320 supports)
     if rank == 0:

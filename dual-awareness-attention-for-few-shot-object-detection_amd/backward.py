@@ -238,14 +238,33 @@ def _attention_backward(d_dense, ld_dd, a, unary, q, k_, s_mat, Bn, rows_b, nseg
     return d_q.view(Bn * rows_b, dq)
 
 
-def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
+def _take_ctx(model, ctx):
+    """the saved-for-backward context to differentiate: the one handed in (the loss bridge captured it at forward time)
+    or the model's latest. A context is consumed exactly once; its tensors are released here."""
+    if ctx is None:
+        ctx = model._ctx
+    if ctx is None or ctx.get("consumed"):
+        raise RuntimeError("no saved training forward to differentiate (run a train-mode forward with grad enabled "
+                           "or model.save_for_backward = True first; each forward can be differentiated once)")
+    return ctx
+
+
+def _release_ctx(model, ctx):
+    keep = {"consumed": True}
+    ctx.clear()
+    ctx.update(keep)
+    if model._ctx is ctx:
+        model._ctx = None
+
+
+def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     """d(sum_i grad_losses[i] * loss_i)/d(parameters) for the four training losses (rpn_loss_cls, rpn_loss_bbox,
     RCNN_loss_cls, RCNN_loss_bbox) of the last `save_for_backward` forward: what train.py:141-143's
     `loss.backward()` computes, accumulated into `.grad` of the trainable parameters (BN, conv1 and layer1 are
     frozen: dana.py:350-385)."""
     if type(model).__name__ in ("FasterRCNN", "MetaRCNN"):
-        return frcnn_backward(model, grad_losses)
-    ctx = model._ctx
+        return frcnn_backward(model, grad_losses, ctx=ctx)
+    ctx = _take_ctx(model, ctx)
     plan = ctx["plan"]
     B, shot, way, R, Ns = ctx["B"], ctx["shot"], ctx["way"], ctx["R"], ctx["Ns"]
     fh, fw = ctx["fh"], ctx["fw"]
@@ -443,7 +462,7 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
         grads.finish_all(model, sq["key"] + ".")
         _ready(model, _block_convs(sq["key"], sq["bp"]))
     assert not grads.packed
-    model._ctx = None
+    _release_ctx(model, ctx)
 
 
 # ---- sibling model `frcnn` (lib/model/framework/faster_rcnn.py): the same adjoints without the attention ----------------
@@ -462,13 +481,13 @@ def frcnn_grad_stages(model):
     return st
 
 
-def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
+def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     """d(sum_i grad_losses[i] * loss_i)/d(parameters) of the last training forward of FasterRCNN (faster_rcnn.py:31-105)
     or MetaRCNN (meta.py:39-142): RoI head <- mean <- layer4 <- RoIAlign, RPN losses <- heads <- 3x3 conv, both into
     base_feat, then layer3 / layer2 of the trunk (conv1, layer1 and every BN are frozen: faster_rcnn.py:129-160).
     meta adds the class-attentive vectors: score = Linear(fc7 * mean_shots(sigmoid(mean(layer4(maxpool2(trunk(support)))))))
     for the positive and the negative supports, so its support batch is differentiated through layer4 and the trunk too."""
-    ctx = model._ctx
+    ctx = _take_ctx(model, ctx)
     meta = type(model).__name__ == "MetaRCNN"
     plan, B, R, fh, fw = ctx["plan"], ctx["B"], ctx["R"], ctx["fh"], ctx["fw"]
     n_roi, hw = B * R, fh * fw
@@ -562,4 +581,4 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0)):
         grads.finish_all(model, sq["key"] + ".")
         _ready(model, _block_convs(sq["key"], sq["bp"]))
     assert not grads.packed
-    model._ctx = None
+    _release_ctx(model, ctx)

@@ -120,13 +120,21 @@ class _LossBridge(torch.autograd.Function):
     @staticmethod
     def forward(fctx, anchor, model, l1, l2, l3, l4):
         fctx.model = model
+        # the context of THIS forward: a later forward replaces model._ctx, and lossA.backward() after forward B must
+        # still differentiate A (or fail loudly once A's context has been consumed), never silently use B's
+        fctx.saved = model._ctx
         return l1.clone(), l2.clone(), l3.clone(), l4.clone()
 
     @staticmethod
     def backward(fctx, g1, g2, g3, g4):
         from . import backward as BW
+        ctx = fctx.saved
+        if ctx is None or ctx.get("consumed"):
+            raise RuntimeError("the saved activations of this training forward were already consumed by a backward pass "
+                               "(each forward can be differentiated once; run the forward again)")
         gs = [torch.zeros((), device=fctx.model._grad_anchor.device) if g is None else g.reshape(()) for g in (g1, g2, g3, g4)]
-        BW.model_backward(fctx.model, torch.stack(gs))  # the four upstream scalars stay in device memory
+        fctx.saved = None  # drop the reference: the activations are freed with the context
+        BW.model_backward(fctx.model, torch.stack(gs), ctx=ctx)  # the four upstream scalars stay in device memory
         return None, None, None, None, None, None
 
 
@@ -659,6 +667,13 @@ class DAnARCNN(nn.Module):
                 rois, gt_boxes.float(), int(tr_.BATCH_SIZE), fg_per, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
                 tr_.BBOX_NORMALIZE_MEANS, tr_.BBOX_NORMALIZE_STDS, tr_.BBOX_INSIDE_WEIGHTS,
                 tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED, device_rng=rng and (rng[0], rng[1] + 1))
+            inj = getattr(self, "_inject_sampled", None)
+            if inj is not None:
+                # stage-wise parity hook (SURVEY.md 7 "feed reference intermediates"): the 5-tuple an EXTERNAL
+                # _ProposalTargetLayer produced (the oracle's / the reference's own sampled batch) replaces this
+                # forward's draw, so everything downstream is compared on identical rois. Tests only.
+                rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = [
+                    t_.to(dev).float().contiguous() for t_ in inj]
             if tl is not None:
                 tl.append(("rpn losses + proposal targets (waits for rois)", _time.perf_counter()))
             labels_f = rois_label.reshape(-1).contiguous()

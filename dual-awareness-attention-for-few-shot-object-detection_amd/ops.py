@@ -24,13 +24,14 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, tag, flops, nbytes=0.0):
-    """tag: (format, args) -- formatted only when profiling; nbytes: algorithmic HBM bytes of the launch (every operand
-    and result touched exactly once)"""
+def _prof_end(e0, tag, flops, nbytes=0.0, executed=None):
+    """tag: (format, args) -- formatted only when profiling; flops: ALGORITHMIC flops (2 per multiply-add of the direct
+    formulation); nbytes: algorithmic HBM bytes of the launch (every operand and result touched exactly once);
+    executed: multiply-add flops the matrix cores actually run (differs for the Winograd-domain launches: 4x fewer)"""
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((tag[0] % tag[1], flops, e0, e1, nbytes))
+        PROFILE.append((tag[0] % tag[1], flops, e0, e1, nbytes, flops if executed is None else executed))
 
 
 def _stream():
@@ -460,7 +461,9 @@ def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=
                h, w, cin, cout, in_stride, out_stride, mask_stride, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
     _prof_end(e0, ("wino3x3 M=%d N=%d K=%d s1", (batch * h * w, cout, 9 * cin)), 2.0 * batch * h * w * cout * 9 * cin,
               # bytes of the batched GEMM launch itself: V[planes][tiles][cin], U[planes][cout][cin], M[planes][tiles][cout]
-              4.0 * (m + 2) * (m + 2) * (batch * ((h + m - 1) // m) * ((w + m - 1) // m) * (cin + cout) + cout * cin))
+              4.0 * (m + 2) * (m + 2) * (batch * ((h + m - 1) // m) * ((w + m - 1) // m) * (cin + cout) + cout * cin),
+              # what the matrix cores execute: (m+2)^2 plane GEMMs of [tiles x cin] . [cin x cout]
+              executed=2.0 * (m + 2) * (m + 2) * batch * ((h + m - 1) // m) * ((w + m - 1) // m) * cin * cout)
     return out, h, w
 
 

@@ -20,7 +20,7 @@ from .config import cfg
 class FlatBuckets:
     """Flat storage for an ordered list of (name, tensor) + bucketed asynchronous all-reduce of the gradients."""
 
-    def __init__(self, named_params, bucket_bytes=32 << 20, process_group=None, world_size=None):
+    def __init__(self, named_params, bucket_bytes=32 << 20, process_group=None, world_size=None, always_reduce=False):
         named_params = list(named_params)
         if not named_params:
             raise ValueError("FlatBuckets: no parameters")
@@ -51,6 +51,9 @@ class FlatBuckets:
         self._pending = [len(ns) for _, _, ns in self.buckets]
         self._works = []
         self.launch_order = []
+        # always_reduce: issue the collectives even in a 1-rank group (a single-GPU box still drives RCCL end to end)
+        self.collective = (self.world > 1 or always_reduce) and dist.is_available() and dist.is_initialized()
+        self._comm = None  # the stream every bucket's all_reduce is issued from (see _launch)
         for n, p in named_params:  # re-point parameter and gradient storage into the flat buffers
             o, k = self.offsets[n]
             if p.dim() == 4:
@@ -86,8 +89,27 @@ class FlatBuckets:
 
     def _launch(self, i):
         self.launch_order.append(i)
-        if self.world > 1:
-            s, e, _ = self.buckets[i]
+        if not self.collective:
+            return
+        s, e, _ = self.buckets[i]
+        if not self.grads.is_cuda:
+            self._works.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        # RCCL orders a collective behind whatever stream is CURRENT when it is issued. The gradients of a bucket are
+        # final on the caller's stream at this point (backward joins its weight-gradient / box-branch side streams
+        # into it before marking a stage ready), but which stream that is depends on where in the backward the stage
+        # ends. So: pin that moment with an event and issue every bucket from ONE dedicated stream behind it -- the
+        # exchange no longer depends on the caller's stream context, and all buckets (weights and biases) leave in one
+        # program order on every rank.
+        owner = getattr(self, "_comm_owner", None)
+        if self._comm is None:
+            if owner is not None and owner._comm is None:
+                owner._comm = torch.cuda.Stream(device=self.grads.device)
+            self._comm = owner._comm if owner is not None else torch.cuda.Stream(device=self.grads.device)
+        final = torch.cuda.Event()
+        final.record()
+        self._comm.wait_event(final)
+        with torch.cuda.stream(self._comm):
             self._works.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait_all(self):
@@ -97,7 +119,9 @@ class FlatBuckets:
             raise RuntimeError("FlatBuckets: gradients never marked ready in buckets %s (e.g. %s)"
                                % (missing, self.buckets[missing[0]][2][:3]))
         for w in self._works:
-            w.wait()
+            w.wait()  # nccl: the CURRENT stream waits for the collective; gloo: the host does
+        if self._works and self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
         self._works = []
 
     def broadcast_params(self, src=0):
@@ -107,7 +131,7 @@ class FlatBuckets:
 
 class Trainer:
     def __init__(self, model, lr, momentum=None, weight_decay=None, double_bias=None, bias_decay=None,
-                 process_group=None, bucket_bytes=32 << 20, optimizer="sgd"):
+                 process_group=None, bucket_bytes=32 << 20, optimizer="sgd", always_reduce=False):
         if optimizer not in ("sgd", "adam"):  # train.py:84-87
             raise ValueError("optimizer must be 'sgd' or 'adam'")
         self.optimizer = optimizer
@@ -125,8 +149,11 @@ class Trainer:
         # train.py:79-84: 'bias' in key -> lr * (DOUBLE_BIAS + 1), weight decay only if BIAS_DECAY
         w_names = [n for n in order if "bias" not in n]
         b_names = [n for n in order if "bias" in n]
-        self.weights = FlatBuckets([(n, params[n]) for n in w_names], bucket_bytes, process_group)
-        self.biases = FlatBuckets([(n, params[n]) for n in b_names], bucket_bytes, process_group)
+        self.weights = FlatBuckets([(n, params[n]) for n in w_names], bucket_bytes, process_group,
+                                   always_reduce=always_reduce)
+        self.biases = FlatBuckets([(n, params[n]) for n in b_names], bucket_bytes, process_group,
+                                  always_reduce=always_reduce)
+        self.biases._comm_owner = self.weights  # one issue stream for both groups
         self.groups = [(self.weights, 1.0, wd), (self.biases, float(double_bias) + 1.0, wd if bias_decay else 0.0)]
         self.bufs = [torch.zeros_like(fb.params) for fb, _, _ in self.groups]  # SGD momentum / Adam exp_avg
         self.bufs2 = [torch.zeros_like(fb.params) for fb, _, _ in self.groups] if optimizer == "adam" else None

@@ -155,3 +155,58 @@ void oracle_decode_clip(const float* base_anchors, const float* deltas, float* o
         memcpy(out + 4 * i, o, sizeof(o));
       }
 }
+
+/* ---- RoIAlign backward, NCHW: lib/model/csrc/cuda/ROIAlign_cuda.cu:125-254
+ * (bilinear_interpolate_gradient + RoIAlignBackwardFeature). The reference scatters with float
+ * atomicAdd in an unspecified order; this restatement visits (n, c, ph, pw, iy, ix) in index order
+ * and accumulates in DOUBLE, so it is the order-free value any atomics order rounds towards.
+ * gin[B][C][H][W] must be zeroed by the caller (ROIAlign_cuda.cu:318 at::zeros). */
+void oracle_roi_align_backward(const float* gout, const float* rois, double* gin, int C, int H, int W, int R,
+                               float scale, int PH, int PW, int sampling_ratio) {
+  for (int n = 0; n < R; ++n) {
+    const float* r = rois + 5 * n;
+    const int b = (int)r[0];
+    const float roi_start_w = r[1] * scale, roi_start_h = r[2] * scale;
+    const float roi_end_w = r[3] * scale, roi_end_h = r[4] * scale;
+    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.f);
+    const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.f);
+    const float bin_size_h = roi_height / (float)PH, bin_size_w = roi_width / (float)PW;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / PH);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / PW);
+    const float count = (float)(grid_h * grid_w);
+    for (int c = 0; c < C; ++c) {
+      double* g = gin + ((size_t)b * C + c) * H * W;
+      for (int ph = 0; ph < PH; ++ph)
+        for (int pw = 0; pw < PW; ++pw) {
+          const float top = gout[(((size_t)n * C + c) * PH + ph) * PW + pw];
+          for (int iy = 0; iy < grid_h; ++iy) {
+            float y = roi_start_h + ph * bin_size_h + (float)(iy + .5f) * bin_size_h / (float)grid_h;
+            for (int ix = 0; ix < grid_w; ++ix) {
+              float x = roi_start_w + pw * bin_size_w + (float)(ix + .5f) * bin_size_w / (float)grid_w;
+              float yy = y;
+              if (yy < -1.0 || yy > H || x < -1.0 || x > W) continue; /* :137-142: weights 0, indices -1 */
+              if (yy <= 0) yy = 0;
+              if (x <= 0) x = 0;
+              int y_low = (int)yy, x_low = (int)x, y_high, x_high;
+              if (y_low >= H - 1) {
+                y_high = y_low = H - 1;
+                yy = (float)y_low;
+              } else
+                y_high = y_low + 1;
+              if (x_low >= W - 1) {
+                x_high = x_low = W - 1;
+                x = (float)x_low;
+              } else
+                x_high = x_low + 1;
+              const float ly = yy - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
+              const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+              g[y_low * W + x_low] += (double)(top * w1 / count);
+              g[y_low * W + x_high] += (double)(top * w2 / count);
+              g[y_high * W + x_low] += (double)(top * w3 / count);
+              g[y_high * W + x_high] += (double)(top * w4 / count);
+            }
+          }
+        }
+    }
+  }
+}

@@ -377,6 +377,22 @@ def proposal_target_layer(all_rois, gt_boxes):
     return rois_b, labels_b, targets, w_in, w_out
 
 
+def sampled_targets(rois_b, labels_b, gt_boxes):
+    """The deterministic tail of proposal_target_layer_cascade.py:176-213 for an ALREADY sampled batch: given the sampled
+    rois [B,R,5] and their labels [B,R] (e.g. the reference's own, from a golden fixture) recompute the gt assignment
+    (:113-117) and the normalised regression targets / weights (:61-110,205-211). -> the 5-tuple of proposal_target_layer."""
+    t = CFG["TRAIN"]
+    B, R = labels_b.shape
+    ov = bbox_overlaps_batch(rois_b, gt_boxes)
+    _, assign = ov.max(2)
+    gt_b = torch.stack([gt_boxes[i][assign[i]] for i in range(B)], 0)
+    tg = bbox_transform_batch(rois_b[:, :, 1:5], gt_b[:, :, :4])
+    tg = (tg - torch.tensor(t["BBOX_NORMALIZE_MEANS"])) / torch.tensor(t["BBOX_NORMALIZE_STDS"])
+    fgm = (labels_b > 0).unsqueeze(2).float()
+    w_in = fgm.expand(B, R, 4).clone()
+    return rois_b, labels_b, tg * fgm, w_in, (w_in > 0).float()
+
+
 # ------------------------------------------------------------------------------------------------
 # RoI-level head: dana.py:244-292
 # ------------------------------------------------------------------------------------------------
@@ -461,8 +477,10 @@ def roi_align_torch(feat, rois, scale, P):
 
 
 def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_way=2, n_shot=3, use_ba=False,
-            nms_inclusive=True, inter=None, differentiable=False):
-    """differentiable=True: the state-dict tensors may require grad (RoIAlign through roi_align_torch; the proposal
+            nms_inclusive=True, inter=None, differentiable=False, sampled=None):
+    """sampled: optional (rois [B,R,5], labels [B,R], targets [B,R,4], w_in, w_out) used INSTEAD of this call's own
+    proposal_target_layer draw (everything downstream of the sampling is then a deterministic function of it).
+    differentiable=True: the state-dict tensors may require grad (RoIAlign through roi_align_torch; the proposal
     layer sees detached inputs, as rpn.py:73 passes .data)"""
     B = im_data.shape[0]
     base_feat = rcnn_base(im_data, sd)
@@ -496,7 +514,12 @@ def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_
         keep = lab.view(-1).ne(-1).nonzero().view(-1)
         rpn_loss_cls = F.cross_entropy(sc.reshape(-1, 2)[keep], lab.view(-1)[keep].long())
         rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
-        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if sampled is not None:  # stage-wise parity: the caller supplies the sampled batch (see sampled_targets)
+            rois, rois_label, rois_target, rw_in, rw_out = sampled
+        else:
+            rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if inter is not None:
+            inter["sampled"] = (rois.clone(), rois_label.clone(), rois_target.clone(), rw_in.clone(), rw_out.clone())
         rois_label = rois_label.view(-1).long()
         rois_target = rois_target.view(-1, 4)
         rw_in = rw_in.view(-1, 4)
@@ -574,7 +597,12 @@ def meta_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, all_cls
         keep = lab.view(-1).ne(-1).nonzero().view(-1)
         rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
         rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
-        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if sampled is not None:  # stage-wise parity: the caller supplies the sampled batch (see sampled_targets)
+            rois, rois_label, rois_target, rw_in, rw_out = sampled
+        else:
+            rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if inter is not None:
+            inter["sampled"] = (rois.clone(), rois_label.clone(), rois_target.clone(), rw_in.clone(), rw_out.clone())
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
     if differentiable:
@@ -629,7 +657,12 @@ def fsod_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, trainin
         keep = lab.view(-1).ne(-1).nonzero().view(-1)
         rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
         rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
-        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if sampled is not None:  # stage-wise parity: the caller supplies the sampled batch (see sampled_targets)
+            rois, rois_label, rois_target, rw_in, rw_out = sampled
+        else:
+            rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if inter is not None:
+            inter["sampled"] = (rois.clone(), rois_label.clone(), rois_target.clone(), rw_in.clone(), rw_out.clone())
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
     pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
@@ -699,7 +732,12 @@ def fgn_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training
         keep = lab.view(-1).ne(-1).nonzero().view(-1)
         rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
         rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
-        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if sampled is not None:  # stage-wise parity: the caller supplies the sampled batch (see sampled_targets)
+            rois, rois_label, rois_target, rw_in, rw_out = sampled
+        else:
+            rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if inter is not None:
+            inter["sampled"] = (rois.clone(), rois_label.clone(), rois_target.clone(), rw_in.clone(), rw_out.clone())
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
     pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
@@ -753,7 +791,12 @@ def frcnn_forward(sd, im_data, im_info, gt_boxes, num_boxes, training, nms_inclu
         keep = lab.view(-1).ne(-1).nonzero().view(-1)
         rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
         rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
-        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if sampled is not None:  # stage-wise parity: the caller supplies the sampled batch (see sampled_targets)
+            rois, rois_label, rois_target, rw_in, rw_out = sampled
+        else:
+            rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
+        if inter is not None:
+            inter["sampled"] = (rois.clone(), rois_label.clone(), rois_target.clone(), rw_in.clone(), rw_out.clone())
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
     r5 = rois.view(-1, 5).numpy()

@@ -84,3 +84,15 @@ def decode_clip(base_anchors, deltas, H, W, feat_stride, im_h, im_w):
     _l().oracle_decode_clip(_fp(base_anchors), _fp(deltas), _fp(out), A, H, W, feat_stride, ctypes.c_float(im_h),
                             ctypes.c_float(im_w))
     return out
+
+
+def roi_align_backward(gout, rois, scale, ph, pw, batch, channels, height, width, sampling_ratio):
+    """lib/model/csrc/cuda/ROIAlign_cuda.cu:125-254 (the reference has no CPU backward, ROIAlign.h:44): every per-sample
+    contribution exactly as the CUDA kernel forms it (fp32), summed in float64 -> [B,C,H,W] float64."""
+    gout = np.ascontiguousarray(gout, dtype=np.float32)
+    rois = np.ascontiguousarray(rois, dtype=np.float32)
+    gin = np.zeros((batch, channels, height, width), dtype=np.float64)
+    if rois.shape[0]:
+        _l().oracle_roi_align_backward(_fp(gout), _fp(rois), _fp(gin), channels, height, width, rois.shape[0],
+                                       ctypes.c_float(scale), ph, pw, sampling_ratio)
+    return gin

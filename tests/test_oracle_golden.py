@@ -232,3 +232,22 @@ def test_oracle_fgn_reproduces_reference_outputs(golden_dir, tag):
         assert np.array_equal(out[7].numpy(), g["rois_label"])
         for i, name in ((3, "rpn_loss_cls"), (4, "rpn_loss_bbox"), (5, "RCNN_loss_cls"), (6, "RCNN_loss_bbox")):
             assert abs(float(out[i]) - float(g[name])) <= 2e-5, name
+
+
+def test_roi_align_backward_oracle_is_the_adjoint_of_the_pinned_forward():
+    """oracle.native.roi_align_backward (restating the reference's CUDA scatter, ROIAlign_cuda.cu:125-254; the reference
+    has no CPU backward to run, ROIAlign.h:44) == autograd through the differentiable restatement of the forward, which
+    is itself pinned bit-exactly to the reference's CPU op via the C forward"""
+    import torch
+    from oracle import native, model_ref as O
+    torch.manual_seed(0)
+    feat = torch.randn(2, 3, 20, 30, dtype=torch.float64, requires_grad=True)
+    rois = torch.tensor([[0, 10., 20., 200., 180.], [1, 0., 0., 479., 319.], [1, 100., 50., 130., 90.],
+                         [0, -30., -20., 40., 60.], [1, 300., 200., 700., 500.], [0, 0., 0., 0., 0.]])
+    y = O.roi_align_torch(feat, rois, 1 / 16., 7)
+    assert np.abs(y.detach().float().numpy() -
+                  native.roi_align_forward(feat.detach().float().numpy(), rois.numpy(), 1 / 16., 7, 7, 0)).max() < 1e-5
+    g = torch.randn_like(y)
+    y.backward(g)
+    got = native.roi_align_backward(g.float().numpy(), rois.numpy(), 1 / 16., 7, 7, 2, 3, 20, 30, 0)
+    assert np.abs(got - feat.grad.numpy()).max() <= 1e-6 * np.abs(got).max()

@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 print("step (with per-launch events): %.2f ms" % ((time.perf_counter() - t0) / K * 1e3))
 prof, ops.PROFILE = ops.PROFILE, None
 per = {}
-for tag, f, e0, e1, _nb in prof:
+for tag, f, e0, e1, _nb, _ex in prof:
     a = per.setdefault(tag, [0.0, 0.0, 0])
     a[0] += f / K
     a[1] += e0.elapsed_time(e1) / K
