@@ -5,4 +5,4 @@ repository root points its ``__path__`` here)."""
 from .config import cfg, cfg_from_file, cfg_from_list  # noqa: F401
 from .utils import get_model  # noqa: F401
 from .dana import DAnARCNN  # noqa: F401
-from . import ops, roi_layers, _C, postprocess  # noqa: F401
+from . import ops, roi_layers, _C, postprocess, graphs  # noqa: F401

@@ -258,12 +258,23 @@ def _release_ctx(model, ctx):
 
 
 def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
-    """d(sum_i grad_losses[i] * loss_i)/d(parameters) for the four training losses (rpn_loss_cls, rpn_loss_bbox,
+    """model_backward_gen run to completion (the eager path and single-graph captures)"""
+    for _ in model_backward_gen(model, grad_losses, ctx=ctx):
+        pass
+
+
+def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
+    """(generator; pauses ONCE, where the gradients of everything except the trunk are final and every side stream is
+    joined into the caller's stream: graphs.GraphedTrainer ends one hipGraph there and starts the next, so that the
+    RCCL all-reduce of the finished buckets overlaps the trunk's backward)
+
+    d(sum_i grad_losses[i] * loss_i)/d(parameters) for the four training losses (rpn_loss_cls, rpn_loss_bbox,
     RCNN_loss_cls, RCNN_loss_bbox) of the last `save_for_backward` forward: what train.py:141-143's
     `loss.backward()` computes, accumulated into `.grad` of the trainable parameters (BN, conv1 and layer1 are
     frozen: dana.py:350-385)."""
     if type(model).__name__ in ("FasterRCNN", "MetaRCNN"):
-        return frcnn_backward(model, grad_losses, ctx=ctx)
+        frcnn_backward(model, grad_losses, ctx=ctx)
+        return
     ctx = _take_ctx(model, ctx)
     plan = ctx["plan"]
     B, shot, way, R, Ns = ctx["B"], ctx["shot"], ctx["way"], ctx["R"], ctx["Ns"]
@@ -443,6 +454,7 @@ def model_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         ops.axpy_rows_(d_sup.view(-1)[b * way * shot * L * 1024:], d_s_pe[b], K1, 1024)
     grads.finish_all(model, "RCNN_rpn")
     _ready(model, stages[2][1])
+    yield "heads, RPN and attention done; trunk next"
 
     # -- trunk: query (RoIAlign + RPN paths meet in base_feat) and supports; layer3, layer2 (layer1 is frozen) --
     ops.axpy_rows_(d_corr, d_bf, B * hw, 1024, ld_y=2048)

@@ -51,10 +51,16 @@ __device__ void floyd_subset(unsigned* bits, int n, int k, const Philox& rng, un
   }
 }
 
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += inc;
+}
+
 // grid = B, block = 256, LDS bitmap of `cand` bits. picks[b][R]; fg_taken[b]
 __global__ void __launch_bounds__(256)
 proposal_target_sample_kernel(const int* __restrict__ counts, int cand, int R, int fg_per, unsigned long long seed,
-                              unsigned long long offset, int* __restrict__ picks, int* __restrict__ fg_taken) {
+                              unsigned long long offset, const unsigned long long* __restrict__ offset_dev,
+                              int* __restrict__ picks, int* __restrict__ fg_taken) {
+  if (offset_dev) offset += offset_dev[0];  // call counter kept in device memory (hipGraph replays advance it)
   extern __shared__ unsigned bits[];  // [words] bitmap | [words] exclusive prefix of the popcounts
   const int words = (cand + 31) / 32;
   unsigned* pref = bits + words;
@@ -96,7 +102,9 @@ __global__ void __launch_bounds__(1024)
 anchor_target_subsample_kernel(float* __restrict__ labels, const int* __restrict__ fg_list,
                                const int* __restrict__ bg_list, const int* __restrict__ counts, int B, int total,
                                int batchsize, int num_fg, unsigned long long seed, unsigned long long offset,
+                               const unsigned long long* __restrict__ offset_dev,
                                float* __restrict__ inv_num_examples) {
+  if (offset_dev) offset += offset_dev[0];
   extern __shared__ unsigned bits[];
   const int b = blockIdx.x;
   const int nf = counts[b * 2], nb = counts[b * 2 + 1];
@@ -133,9 +141,10 @@ anchor_target_subsample_kernel(float* __restrict__ labels, const int* __restrict
 
 extern "C" {
 
-int dana_proposal_target_sample(const int* counts, int B, int n_candidates, int rois_per_image, int fg_rois_per_image,
-                                unsigned long long seed, unsigned long long offset, int* picks, int* fg_taken,
-                                dana_stream_t stream) {
+static int proposal_target_sample_impl(const int* counts, int B, int n_candidates, int rois_per_image,
+                                       int fg_rois_per_image, unsigned long long seed, unsigned long long offset,
+                                       const unsigned long long* offset_dev, int* picks, int* fg_taken,
+                                       dana_stream_t stream) {
   DANA_CHECK_ARG(B >= 0 && n_candidates > 0 && rois_per_image > 0 && fg_rois_per_image >= 0,
                  "dana_proposal_target_sample: bad shape");
   if (B == 0) return DANA_OK;
@@ -143,14 +152,39 @@ int dana_proposal_target_sample(const int* counts, int B, int n_candidates, int 
   const size_t lds = (size_t)((n_candidates + 31) / 32) * 2 * sizeof(unsigned);
   DANA_CHECK_ARG(lds <= 60 * 1024, "dana_proposal_target_sample: too many candidates");
   proposal_target_sample_kernel<<<B, 256, lds, (hipStream_t)stream>>>(counts, n_candidates, rois_per_image,
-                                                                      fg_rois_per_image, seed, offset, picks, fg_taken);
+                                                                      fg_rois_per_image, seed, offset, offset_dev,
+                                                                      picks, fg_taken);
   DANA_CHECK_LAUNCH("dana_proposal_target_sample");
   return DANA_OK;
 }
 
-int dana_anchor_target_subsample(float* labels, const int* fg_list, const int* bg_list, const int* counts, int B,
-                                 int anchors_per_image, int rpn_batchsize, int num_fg, unsigned long long seed,
-                                 unsigned long long offset, float* inv_num_examples, dana_stream_t stream) {
+int dana_proposal_target_sample(const int* counts, int B, int n_candidates, int rois_per_image, int fg_rois_per_image,
+                                unsigned long long seed, unsigned long long offset, int* picks, int* fg_taken,
+                                dana_stream_t stream) {
+  return proposal_target_sample_impl(counts, B, n_candidates, rois_per_image, fg_rois_per_image, seed, offset, nullptr,
+                                     picks, fg_taken, stream);
+}
+
+int dana_proposal_target_sample_ctr(const int* counts, int B, int n_candidates, int rois_per_image,
+                                    int fg_rois_per_image, unsigned long long seed, unsigned long long offset,
+                                    const unsigned long long* counter_dev, int* picks, int* fg_taken,
+                                    dana_stream_t stream) {
+  DANA_CHECK_ARG(counter_dev, "dana_proposal_target_sample_ctr: null counter");
+  return proposal_target_sample_impl(counts, B, n_candidates, rois_per_image, fg_rois_per_image, seed, offset,
+                                     counter_dev, picks, fg_taken, stream);
+}
+
+int dana_counter_add(unsigned long long* counter_dev, unsigned long long inc, dana_stream_t stream) {
+  DANA_CHECK_ARG(counter_dev, "dana_counter_add: null pointer");
+  counter_add_kernel<<<1, 64, 0, (hipStream_t)stream>>>(counter_dev, inc);
+  DANA_CHECK_LAUNCH("dana_counter_add");
+  return DANA_OK;
+}
+
+static int anchor_target_subsample_impl(float* labels, const int* fg_list, const int* bg_list, const int* counts, int B,
+                                        int anchors_per_image, int rpn_batchsize, int num_fg, unsigned long long seed,
+                                        unsigned long long offset, const unsigned long long* offset_dev,
+                                        float* inv_num_examples, dana_stream_t stream) {
   DANA_CHECK_ARG(B > 0 && anchors_per_image > 0 && rpn_batchsize > 0 && num_fg >= 0 && num_fg <= rpn_batchsize,
                  "dana_anchor_target_subsample: bad shape");
   DANA_CHECK_ARG(labels && fg_list && bg_list && counts && inv_num_examples, "dana_anchor_target_subsample: null pointer");
@@ -158,9 +192,25 @@ int dana_anchor_target_subsample(float* labels, const int* fg_list, const int* b
   DANA_CHECK_ARG(lds <= 60 * 1024, "dana_anchor_target_subsample: too many anchors per image");
   anchor_target_subsample_kernel<<<B, 1024, lds, (hipStream_t)stream>>>(labels, fg_list, bg_list, counts, B,
                                                                         anchors_per_image, rpn_batchsize, num_fg, seed,
-                                                                        offset, inv_num_examples);
+                                                                        offset, offset_dev, inv_num_examples);
   DANA_CHECK_LAUNCH("dana_anchor_target_subsample");
   return DANA_OK;
+}
+
+int dana_anchor_target_subsample(float* labels, const int* fg_list, const int* bg_list, const int* counts, int B,
+                                 int anchors_per_image, int rpn_batchsize, int num_fg, unsigned long long seed,
+                                 unsigned long long offset, float* inv_num_examples, dana_stream_t stream) {
+  return anchor_target_subsample_impl(labels, fg_list, bg_list, counts, B, anchors_per_image, rpn_batchsize, num_fg, seed,
+                                      offset, nullptr, inv_num_examples, stream);
+}
+
+int dana_anchor_target_subsample_ctr(float* labels, const int* fg_list, const int* bg_list, const int* counts, int B,
+                                     int anchors_per_image, int rpn_batchsize, int num_fg, unsigned long long seed,
+                                     unsigned long long offset, const unsigned long long* counter_dev,
+                                     float* inv_num_examples, dana_stream_t stream) {
+  DANA_CHECK_ARG(counter_dev, "dana_anchor_target_subsample_ctr: null counter");
+  return anchor_target_subsample_impl(labels, fg_list, bg_list, counts, B, anchors_per_image, rpn_batchsize, num_fg, seed,
+                                      offset, counter_dev, inv_num_examples, stream);
 }
 
 }  // extern "C"

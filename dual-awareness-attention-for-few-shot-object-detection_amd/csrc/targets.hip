@@ -130,7 +130,9 @@ proposal_target_gather_kernel(const float* __restrict__ rois, const float* __res
   const int n_all = n_rois + n_gt;
   const bool is_fg = r < fg_n[b];
   const int pick = picks[b * R + r];
-  const int i = (is_fg ? fg_list : bg_list)[(long)b * n_all + pick];
+  // (clamped: a pick into an EMPTY list -- fg and bg both empty, which the reference refuses with a ValueError,
+  // proposal_target_layer_cascade.py:186-187 -- must not turn an uninitialised list entry into a wild read)
+  const int i = min(max((is_fg ? fg_list : bg_list)[(long)b * n_all + min(max(pick, 0), n_all - 1)], 0), n_all - 1);
   const float4 ex = cand_box(rois, gt, b, i, n_rois, n_gt);
   const float* g = gt + ((long)b * n_gt + assign[(long)b * n_all + i]) * 5;
   const float label = is_fg ? g[4] : 0.f;  // labels_batch[i][fg_rois_per_this_image:] = 0 (:180-181)
@@ -330,6 +332,21 @@ anchor_target_disable_kernel(float* __restrict__ labels, const int* __restrict__
   const int b = which[e] >> 1;
   const int* list = (which[e] & 1) ? bg_list : fg_list;
   labels[(long)b * total + list[(long)b * total + pos[e]]] = -1.f;
+}
+
+// the same with the entry count in device memory and (which, pos) interleaved: a captured hipGraph replays this launch
+// with whatever the host drew for THIS step (the count is data, not a launch parameter)
+__global__ void __launch_bounds__(256)
+anchor_target_disable_dev_kernel(float* __restrict__ labels, const int* __restrict__ fg_list,
+                                 const int* __restrict__ bg_list, const int* __restrict__ n_dev,
+                                 const int2* __restrict__ pairs, int cap, int total) {
+  const int n = min(n_dev[0], cap);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int2 wp = pairs[e];
+    const int b = wp.x >> 1;
+    const int* list = (wp.x & 1) ? bg_list : fg_list;
+    labels[(long)b * total + list[(long)b * total + wp.y]] = -1.f;
+  }
 }
 
 // bbox_transform_batch of (anchor, matched gt) (bbox_transform.py:36-75)
@@ -705,6 +722,20 @@ int dana_anchor_target_disable(float* labels, const int* fg_list, const int* bg_
   anchor_target_disable_kernel<<<dana_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(labels, fg_list, bg_list,
                                                                                     which, pos, n, anchors_per_image);
   DANA_CHECK_LAUNCH("dana_anchor_target_disable");
+  return DANA_OK;
+}
+
+int dana_anchor_target_disable_dev(float* labels, const int* fg_list, const int* bg_list, const int* n_dev,
+                                   const int* which_pos_pairs, int capacity, int anchors_per_image,
+                                   dana_stream_t stream) {
+  DANA_CHECK_ARG(capacity >= 0 && anchors_per_image > 0, "dana_anchor_target_disable_dev: bad shape");
+  if (capacity == 0) return DANA_OK;
+  DANA_CHECK_ARG(labels && fg_list && bg_list && n_dev && which_pos_pairs, "dana_anchor_target_disable_dev: null pointer");
+  DANA_CHECK_ARG(((uintptr_t)which_pos_pairs & 7) == 0, "dana_anchor_target_disable_dev: pairs must be 8-byte aligned");
+  const int blocks = dana_ceil_div(capacity, 256) < 1024 ? dana_ceil_div(capacity, 256) : 1024;
+  anchor_target_disable_dev_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(
+      labels, fg_list, bg_list, n_dev, (const int2*)which_pos_pairs, capacity, anchors_per_image);
+  DANA_CHECK_LAUNCH("dana_anchor_target_disable_dev");
   return DANA_OK;
 }
 

@@ -448,6 +448,22 @@ class DAnARCNN(nn.Module):
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, im_data, im_info, gt_boxes, num_boxes, support_ims, all_cls_gt_boxes=None):
+        """dana.py:87-220. The body is `_forward_gen`, a generator that pauses at the ONE host round trip of the
+        training forward (the fg / bg counts the reference's np.random draws need): eagerly that is a D2H read, the
+        draws and one pinned upload right here; `graphs.GraphedDAnA` captures the two halves as hipGraphs instead."""
+        gen = self._forward_gen(im_data, im_info, gt_boxes, num_boxes, support_ims)
+        try:
+            req = next(gen)
+        except StopIteration as done:
+            return done.value
+        drawn = ops.upload_draws(ops.draw_targets_host(req), im_data.device)
+        try:
+            gen.send(drawn)
+        except StopIteration as done:
+            return done.value
+        raise RuntimeError("DAnARCNN._forward_gen paused twice")
+
+    def _forward_gen(self, im_data, im_info, gt_boxes, num_boxes, support_ims):
         plan = self._get_plan()
         dev = im_data.device
         training = self.training
@@ -638,35 +654,69 @@ class DAnARCNN(nn.Module):
         rpn_loss_cls = rpn_loss_bbox = 0
         rois_label = None
         if training:
-            # anchor targets depend on the inputs only: they are computed on a side stream so that their
-            # host syncs (np.random needs the counts) never drain the main stream's kernel queue
+            # Target layers, first halves (everything up to the fg / bg counts; nothing random yet). The anchor side
+            # depends on the inputs only: it runs on a side stream, concurrently with the trunk.
             rng = None
+            capturing = torch.cuda.is_current_stream_capturing()
             if self.device_rng:  # counter-based device RNG (opt-in): (seed, 2 * forward counter [+ 1])
                 rng = (int(self.rng_seed), 2 * self._rng_calls)
                 self._rng_calls += 1
+            ctr = None
+            if self.device_rng and capturing:
+                # inside a hipGraph the call counter must be DATA: a uint64 in device memory, advanced by the graph itself
+                ctr = self._consts.get(("rng_counter", str(dev)))
+                if ctr is None:
+                    ctr = self._consts[("rng_counter", str(dev))] = torch.zeros(1, dtype=torch.int64, device=dev)
+                rng = (int(self.rng_seed), 0)
             side = self._stream("targets", dev)
             side.wait_event(inputs_ready)  # NOT wait_stream(main): the trunk is already queued there
             tr_ = cfg.TRAIN
+            num_fg = int(tr_.RPN_FG_FRACTION * tr_.RPN_BATCHSIZE)
+            counts_all = torch.empty((2, B, 2), dtype=torch.int32, device=dev)  # [anchor | proposal][image][fg, bg]
+            counts_all.record_stream(side)
+            gt_f = gt_boxes.float().contiguous()
+            gt_f.record_stream(side)
             with torch.cuda.stream(side):
-                at = ops.anchor_target_assign(gt_boxes.float(), im_info, plan["anchors"], fh, fw, rpn.feat_stride,
-                                              tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP, tr_.RPN_BATCHSIZE,
-                                              tr_.RPN_FG_FRACTION, device_rng=rng and (rng[0], rng[1]))
+                at = ops.anchor_target_prepare(gt_f, im_info, plan["anchors"], fh, fw, rpn.feat_stride,
+                                               tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP, counts=counts_all[0])
+                if rng is not None:
+                    ops.anchor_target_subsample_device(at, tr_.RPN_BATCHSIZE, num_fg, rng[0], rng[1], counter=ctr)
+                    at["inv_ne_dev"].record_stream(main)
             at["ibuf"].record_stream(main)
             at["labels"].record_stream(main)
+            at["max_ov"].record_stream(main)
             main.wait_stream(side)
+            fg_per = int(np.round(tr_.FG_FRACTION * tr_.BATCH_SIZE)) or 1
+            R_t = int(tr_.BATCH_SIZE)
+            pt = ops.proposal_target_prepare(rois, gt_f, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
+                                             counts=counts_all[1])
             if tl is not None:
-                tl.append(("anchor targets (host)", _time.perf_counter()))
+                tl.append(("target layers enqueued (first halves)", _time.perf_counter()))
+            if rng is None:
+                # -- the one host round trip: counts -> np.random draws (the reference's stream) -> one upload --
+                if capturing:  # a captured graph must end with every side stream joined
+                    main.wait_event(support_roi_done)
+                    support_roi_done = None
+                lay = ops.draw_layout(B, R_t, at["total"])
+                drawn = yield dict(counts=counts_all, B=B, R=R_t, fg_per=fg_per, rpn_batchsize=int(tr_.RPN_BATCHSIZE),
+                                   num_fg=num_fg, total=at["total"], layout=lay)
+                ops.anchor_target_apply_draws(at, drawn, lay)
+                picks_ptr, taken_ptr = drawn.data_ptr() + 4 * lay["picks"], drawn.data_ptr() + 4 * lay["taken"]
+            else:
+                host = ops.proposal_target_sample_device(pt, R_t, fg_per, rng[0], rng[1] + 1, counter=ctr)
+                if ctr is not None:
+                    ops.counter_add_(ctr, 2)
+                picks_ptr, taken_ptr = host.data_ptr(), host.data_ptr() + 4 * B * R_t
+            if tl is not None:
+                tl.append(("draws (host sync)", _time.perf_counter()))
             # fused RPN losses (rpn.py:97-115) straight from the head buffer [B*hw][2A | 4A]
             rpn_l = ops.rpn_losses(heads, nh, at, sigma=3.0, inside_weight=tr_.RPN_BBOX_INSIDE_WEIGHTS[0])
             rpn_loss_cls, rpn_loss_bbox = rpn_l[0], rpn_l[1]
             if ctx is not None:
                 ctx.update(rpn_x=x, rpn_heads=heads, nh=nh, at=at, rpn_l=rpn_l)
-            tr_ = cfg.TRAIN
-            fg_per = int(np.round(tr_.FG_FRACTION * tr_.BATCH_SIZE)) or 1
-            rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_layer(
-                rois, gt_boxes.float(), int(tr_.BATCH_SIZE), fg_per, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
-                tr_.BBOX_NORMALIZE_MEANS, tr_.BBOX_NORMALIZE_STDS, tr_.BBOX_INSIDE_WEIGHTS,
-                tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED, device_rng=rng and (rng[0], rng[1] + 1))
+            rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_finish(
+                pt, picks_ptr, taken_ptr, R_t, tr_.BBOX_NORMALIZE_MEANS, tr_.BBOX_NORMALIZE_STDS,
+                tr_.BBOX_INSIDE_WEIGHTS, tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)
             inj = getattr(self, "_inject_sampled", None)
             if inj is not None:
                 # stage-wise parity hook (SURVEY.md 7 "feed reference intermediates"): the 5-tuple an EXTERNAL
@@ -717,7 +767,8 @@ class DAnARCNN(nn.Module):
         # -- RoI-level CISA (dana.py:248-292). Query side once: Q projection and the q half of
         #    rcnn_transform_layer (cat([q, attended]) @ Wt^T = q @ Wt[:, :1024]^T + attended @ Wt[:, 1024:]^T,
         #    so the [n*49][2048] concat of dana.py:284 is never materialised). --
-        main.wait_event(support_roi_done)
+        if support_roi_done is not None:
+            main.wait_event(support_roi_done)
         wq2, bq2 = self._w(self.rcnn_adapt_q_layer)
         q2 = ops.gemm_nt(q_pe, wq2, n_roi * P2, dq, 1024, shift=bq2)
         ops.colmean_sub_(q2, n_roi, P2, dq)

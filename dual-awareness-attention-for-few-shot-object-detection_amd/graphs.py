@@ -1,0 +1,232 @@
+"""hipGraph replay of the DAnA forward and of the whole training iteration.
+
+Eagerly, one bs-4 train-mode forward is ~430 C-ABI calls issued from Python (6.5 ms of host time for 7.5 ms of GPU
+work in round 1), a training iteration ~1 500: with one process per GPU and eight of them on one host that is the wall
+every further kernel gain runs into. The launch sequence is static -- shapes, pointers and parameters do not depend on
+the data -- except for ONE host round trip: the reference's `np.random` draws in the two target layers need the fg / bg
+counts (anchor_target_layer.py:137-156, proposal_target_layer_cascade.py:143-175). So the step is captured as
+
+    G1 = trunk .. RPN .. proposals .. target layers up to their counts
+    [host: read 4*B counts, np.random draws (the reference's stream), ONE pinned upload into a static buffer]
+    G2 = RPN losses, sampled-batch gather, RoIAlign, layer4, attention heads, RCNN losses
+         (+ backward + fused SGD for the training iteration)
+
+and replayed with two graph launches per step. With `model.device_rng = True` (Philox on the device, call counter in
+device memory) there is no host round trip and the whole step is one graph. Multi-rank training cuts the backward
+graph once more, where the gradients of everything except the trunk are final, so that the RCCL all-reduce of those
+buckets overlaps the trunk's backward (the eager path launches bucket by bucket; a collective cannot sit inside a
+captured graph portably).
+
+Capture uses torch's hipGraph wrapper (`torch.cuda.CUDAGraph`) for stream capture, the private memory pool and replay;
+every node in the graphs is one of this package's HIP kernels (plus a handful of memset / copy nodes).
+"""
+import torch
+
+from . import ops
+from . import backward as BW
+
+
+def _static_like(t):
+    return t.detach().clone() if torch.is_tensor(t) else t
+
+
+class GraphedDAnA:
+    """model(*inputs) as hipGraph replays. Inputs are copied into static buffers (skipped when the caller passes the
+    static buffers themselves: `runner.inputs`); outputs are static tensors, valid until the next call.
+
+    The graphs bake in: the model's mode (train / eval), input shapes, cfg, and the weight-derived tensors of this
+    moment (packed / Winograd-transformed weights, folded BN). Re-capture (`GraphedDAnA(model, ...)` again) after
+    changing any of them; for training use `GraphedTrainer`, whose graphs re-derive them from the live weights."""
+
+    def __init__(self, model, *example_inputs, warmup=2):
+        dev = example_inputs[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedDAnA needs HIP tensors")
+        if not hasattr(model, "_forward_gen"):
+            raise RuntimeError("GraphedDAnA drives DAnARCNN (the siblings run eagerly)")
+        self.model = model
+        self.inputs = [_static_like(t) for t in example_inputs]
+        self.stream = torch.cuda.Stream(device=dev)
+        self.req = self.drawn = self.g2 = None
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            for _ in range(warmup):  # eager: fills the plan / constant caches, sets kernel attributes
+                model(*self.inputs)
+        torch.cuda.synchronize(dev)
+        self.g1 = torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            with torch.cuda.graph(self.g1, stream=self.stream, capture_error_mode="thread_local"):
+                gen = model._forward_gen(*self.inputs)
+                try:
+                    self.req = next(gen)
+                    out = None
+                except StopIteration as done:
+                    out = done.value
+            if self.req is not None:
+                self.drawn = torch.zeros((self.req["layout"]["words"],), dtype=torch.int32, device=dev)
+                self.g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g2, pool=self.g1.pool(), stream=self.stream, capture_error_mode="thread_local"):
+                    try:
+                        gen.send(self.drawn)
+                        raise RuntimeError("the forward paused twice")
+                    except StopIteration as done:
+                        out = done.value
+        self.outputs = out
+        cur.wait_stream(self.stream)
+
+    def __call__(self, *inputs):
+        for s, t in zip(self.inputs, inputs):
+            if torch.is_tensor(t) and t is not s:
+                s.copy_(t, non_blocking=True)
+        self.g1.replay()
+        if self.g2 is not None:
+            ops.upload_draws(ops.draw_targets_host(self.req), self.drawn.device, static=self.drawn)
+            self.g2.replay()
+        return self.outputs
+
+
+class GraphedTrainer:
+    """Trainer.step (train.py:125-143: zero_grad, forward, summed loss, backward, SGD) as hipGraph replays.
+
+        gt = GraphedTrainer(trainer, *example_inputs)
+        out = gt.step(*inputs)          # the model's 8-tuple (static tensors)
+
+    SGD only (train.py's default; Adam's bias correction is a per-step launch parameter). The learning rate is baked
+    in: call `recapture()` after `trainer.adjust_learning_rate`. The graphs re-derive every weight-dependent tensor
+    (Winograd-domain filters, data-gradient weights, the merged RPN head) from the live flat parameter buffer on every
+    replay, so the optimizer's in-place updates are picked up without re-capturing."""
+
+    def __init__(self, trainer, *example_inputs, warmup=2):
+        if trainer.optimizer != "sgd":
+            raise RuntimeError("GraphedTrainer: SGD only (Adam's step count is a launch parameter)")
+        self.trainer = trainer
+        self.model = trainer.model
+        if not hasattr(self.model, "_forward_gen"):
+            raise RuntimeError("GraphedTrainer drives DAnARCNN (the siblings train eagerly)")
+        dev = example_inputs[0].device
+        self.inputs = [_static_like(t) for t in example_inputs]
+        self.stream = torch.cuda.Stream(device=dev)
+        self.ones = torch.ones(4, dtype=torch.float32, device=dev)  # d(sum of the four losses) / d(each)
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                trainer.step(*self.inputs)  # eager iterations: caches, kernel attributes, allocator pools
+        torch.cuda.synchronize(dev)
+        cur.wait_stream(self.stream)
+        self._capture()
+
+    def recapture(self):
+        self._capture()
+
+    def _capture(self):
+        tr, model = self.trainer, self.model
+        dev = self.inputs[0].device
+        self.graphs = []     # [[graph, [(FlatBuckets, bucket index) to all-reduce after it]]]
+        self.req = self.drawn = None
+        model._epoch += 1    # every trainable conv's derived tensors are re-derived INSIDE the capture
+        model._plan = None
+        prev_save = getattr(model, "save_for_backward", False)
+        model.save_for_backward = True
+        collective = tr.weights.collective
+        for fb, _, _ in tr.groups:
+            fb.capture_only = True
+            fb.zero_grad_bookkeeping()
+        pool = [None]
+
+        def graph():
+            g = torch.cuda.CUDAGraph()
+            self.graphs.append([g, []])
+            kw = {} if pool[0] is None else {"pool": pool[0]}
+            return torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local", **kw)
+
+        def ready_buckets(seen):
+            now = [(fb, i) for fb, _, _ in tr.groups for i in fb.launch_order]
+            fresh = [x for x in now if x not in seen]
+            seen.extend(fresh)
+            return fresh
+
+        torch.cuda.synchronize(dev)
+        try:
+            with torch.no_grad():
+                gen = model._forward_gen(*self.inputs)
+                out, bgen, seen = None, None, []
+                # ---- graph 1: zero the gradients, forward up to the host round trip (or to its end) ----
+                with graph():
+                    for fb, _, _ in tr.groups:
+                        fb.grads.zero_()
+                    try:
+                        self.req = next(gen)
+                    except StopIteration as done:
+                        out = done.value
+                    if out is not None:
+                        bgen = self._backward_until_cut(model._ctx, collective)
+                pool[0] = self.graphs[0][0].pool()
+                if out is None:
+                    # ---- graph 2: behind the draws: the rest of the forward, then the backward ----
+                    self.drawn = torch.zeros((self.req["layout"]["words"],), dtype=torch.int32, device=dev)
+                    with graph():
+                        try:
+                            gen.send(self.drawn)
+                            raise RuntimeError("the forward paused twice")
+                        except StopIteration as done:
+                            out = done.value
+                        bgen = self._backward_until_cut(model._ctx, collective)
+                if collective:
+                    # multi-rank: the first buckets leave here; the trunk's backward is its own graph, replayed while
+                    # they travel; the SGD launch sits behind every bucket's sum in a last graph
+                    self.graphs[-1][1] = ready_buckets(seen)
+                    with graph():
+                        for _ in bgen:
+                            raise RuntimeError("model_backward_gen paused twice")
+                    self.graphs[-1][1] = ready_buckets(seen)
+                    with graph():
+                        self._sgd()
+        finally:
+            model.save_for_backward = prev_save
+            for fb, _, _ in tr.groups:
+                fb.capture_only = False
+                fb.zero_grad_bookkeeping()
+        self.outputs = tuple(t.detach() if torch.is_tensor(t) else t for t in out)
+        self.collective = collective
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+    def _sgd(self):
+        tr = self.trainer
+        for (fb, lr_mult, wd), buf in zip(tr.groups, tr.bufs):
+            # first_step=False: with a zero momentum buffer  buf = m * 0 + g  IS torch.optim.SGD's first step
+            ops.sgd_momentum_(fb.params, fb.grads, buf, tr.lr * lr_mult, tr.momentum, wd, grad_scale=1.0 / fb.world,
+                              first_step=False)
+
+    def _backward_until_cut(self, ctx, collective):
+        """single rank: the whole backward + SGD into the current capture (returns None). Multi-rank: the backward up to
+        the point where everything but the trunk is final; returns the paused generator"""
+        if not collective:
+            BW.model_backward(self.model, self.ones, ctx=ctx)
+            self._sgd()
+            return None
+        gen = BW.model_backward_gen(self.model, self.ones, ctx=ctx)
+        next(gen)
+        return gen
+
+    def step(self, *inputs):
+        tr = self.trainer
+        for s, t in zip(self.inputs, inputs):
+            if torch.is_tensor(t) and t is not s:
+                s.copy_(t, non_blocking=True)
+        works = []
+        last = len(self.graphs) - 1
+        for k, (g, buckets) in enumerate(self.graphs):
+            if k == 1 and self.req is not None:
+                ops.upload_draws(ops.draw_targets_host(self.req), self.drawn.device, static=self.drawn)
+            if k == last and self.collective:
+                for w in works:  # the SGD graph runs behind every bucket's sum
+                    w.wait()
+                for fb, _, _ in tr.groups:
+                    fb.join_comm()
+            g.replay()
+            for fb, i in buckets:
+                works.append(fb.reduce_bucket(i))
+        tr.steps += 1
+        return self.outputs

@@ -223,13 +223,9 @@ def rpn_decode(cls, cls_strides, cls_is_prob, bbox, bbox_strides, im_info, base_
     return proposals, scores
 
 
-def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_thresh, bg_hi, bg_lo, means, stds,
-                          inside_w, normalize=True, device_rng=None):
-    """_ProposalTargetLayer.forward (proposal_target_layer_cascade.py:33-213): two HIP launches around one
-    D2H read of the fg/bg counts; the sampling draws np.random exactly like the reference (:143-175).
-    device_rng = (seed, offset): draw on the device instead (Philox), no host sync, a different random stream."""
-    import ctypes
-    import numpy as np
+def proposal_target_prepare(rois, gt_boxes, fg_thresh, bg_hi, bg_lo, counts=None):
+    """first half of _ProposalTargetLayer (proposal_target_layer_cascade.py:113-141): IoU, assignment, ordered fg / bg
+    candidate lists and their counts [B,2] -- everything the sampling needs, nothing random. -> handle"""
     rois = _chk(rois.contiguous(), "rois")
     gt_boxes = _chk(gt_boxes.contiguous(), "gt_boxes")
     B, n_rois, _ = rois.shape
@@ -238,16 +234,18 @@ def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_
     dev = rois.device
     max_ov = torch.empty((B, n_all), dtype=torch.float32, device=dev)
     ibuf = torch.empty((3, B, n_all), dtype=torch.int32, device=dev)  # assign, fg_list, bg_list
-    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    if counts is None:
+        counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
     lib().call("dana_proposal_target_prepare", _p(rois), _p(gt_boxes), B, n_rois, n_gt, float(fg_thresh), float(bg_hi),
                float(bg_lo), _p(max_ov), _p(ibuf[0]), _p(ibuf[1]), _p(ibuf[2]), _p(counts), _stream())
-    R = rois_per_image
-    if device_rng is not None:
-        host = torch.empty((B * R + B,), dtype=torch.int32, device=dev)
-        lib().call("dana_proposal_target_sample", _p(counts), B, n_all, R, fg_rois_per_image, int(device_rng[0]),
-                   int(device_rng[1]), _p(host), host.data_ptr() + B * R * 4, _stream())
-        return _proposal_target_gather(rois, gt_boxes, B, n_rois, n_gt, ibuf, host, R, means, stds, inside_w, normalize)
-    cnt = counts.cpu().numpy()  # the one host sync: np.random needs the counts
+    return dict(rois=rois, gt_boxes=gt_boxes, B=B, n_rois=n_rois, n_gt=n_gt, n_all=n_all, ibuf=ibuf, max_ov=max_ov,
+                counts=counts)
+
+
+def proposal_target_draw(cnt, B, R, fg_rois_per_image):
+    """the reference's np.random draws (proposal_target_layer_cascade.py:143-175) from the host copy of the counts
+    -> (picks int32 [B, R], fg_taken int32 [B])"""
+    import numpy as np
     picks = np.zeros((B, R), dtype=np.int32)
     taken = np.zeros((B,), dtype=np.int32)
     for i in range(B):
@@ -265,34 +263,63 @@ def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_
         else:
             raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
         taken[i] = fg_n
-    host = _h2d_int32(np.concatenate([picks.reshape(-1), taken]), dev)
-    return _proposal_target_gather(rois, gt_boxes, B, n_rois, n_gt, ibuf, host, R, means, stds, inside_w, normalize)
+    return picks, taken
 
 
-def _proposal_target_gather(rois, gt_boxes, B, n_rois, n_gt, ibuf, host, R, means, stds, inside_w, normalize):
-    """host: int32 [B*R picks | B fg_taken] on the device"""
+def proposal_target_sample_device(h, R, fg_rois_per_image, seed, offset, counter=None):
+    """device Philox draws (no host sync, a different random stream); counter: uint64 device call counter (hipGraphs)"""
+    B = h["B"]
+    host = torch.empty((B * R + B,), dtype=torch.int32, device=h["rois"].device)
+    if counter is None:
+        lib().call("dana_proposal_target_sample", _p(h["counts"]), B, h["n_all"], R, fg_rois_per_image, int(seed),
+                   int(offset), _p(host), host.data_ptr() + B * R * 4, _stream())
+    else:
+        lib().call("dana_proposal_target_sample_ctr", _p(h["counts"]), B, h["n_all"], R, fg_rois_per_image, int(seed),
+                   int(offset), _p(counter), _p(host), host.data_ptr() + B * R * 4, _stream())
+    return host
+
+
+def proposal_target_finish(h, picks_dev_ptr, taken_dev_ptr, R, means, stds, inside_w, normalize=True):
+    """second half (proposal_target_layer_cascade.py:176-213): gather the sampled rois, labels, targets, weights"""
     import ctypes
-    dev = rois.device
+    dev = h["rois"].device
+    B = h["B"]
     rois_out = torch.empty((B, R, 5), dtype=torch.float32, device=dev)
     labels = torch.empty((B, R), dtype=torch.float32, device=dev)
     tgt = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
     w_in = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
     w_out = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
     f4 = ctypes.c_float * 4
-    lib().call("dana_proposal_target_gather", _p(rois), _p(gt_boxes), B, n_rois, n_gt, _p(ibuf[0]), _p(ibuf[1]),
-               _p(ibuf[2]), _p(host), host.data_ptr() + B * R * 4, R,
+    ibuf = h["ibuf"]
+    lib().call("dana_proposal_target_gather", _p(h["rois"]), _p(h["gt_boxes"]), B, h["n_rois"], h["n_gt"], _p(ibuf[0]),
+               _p(ibuf[1]), _p(ibuf[2]), picks_dev_ptr, taken_dev_ptr, R,
                ctypes.cast(f4(*means), ctypes.c_void_p), ctypes.cast(f4(*stds), ctypes.c_void_p),
                ctypes.cast(f4(*inside_w), ctypes.c_void_p), int(bool(normalize)), _p(rois_out), _p(labels), _p(tgt),
                _p(w_in), _p(w_out), _stream())
     return rois_out, labels, tgt, w_in, w_out
 
 
-def anchor_target_assign(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_stride, negative_overlap,
-                         positive_overlap, rpn_batchsize, fg_fraction, device_rng=None):
-    """_AnchorTargetLayer (anchor_target_layer.py:48-193) up to the sampled labels: one HIP launch, one D2H
-    read of the fg/bg counts, the reference's np.random.permutation draws (:137-156), one scatter launch.
-    Returns a dict consumed by rpn_losses() / anchor_target_outputs()."""
+def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_thresh, bg_hi, bg_lo, means, stds,
+                          inside_w, normalize=True, device_rng=None):
+    """_ProposalTargetLayer.forward (proposal_target_layer_cascade.py:33-213): two HIP launches around one
+    D2H read of the fg/bg counts; the sampling draws np.random exactly like the reference (:143-175).
+    device_rng = (seed, offset): draw on the device instead (Philox), no host sync, a different random stream."""
     import numpy as np
+    h = proposal_target_prepare(rois, gt_boxes, fg_thresh, bg_hi, bg_lo)
+    B, R = h["B"], rois_per_image
+    if device_rng is not None:
+        host = proposal_target_sample_device(h, R, fg_rois_per_image, device_rng[0], device_rng[1])
+    else:
+        cnt = h["counts"].cpu().numpy()  # the one host sync: np.random needs the counts
+        picks, taken = proposal_target_draw(cnt, B, R, fg_rois_per_image)
+        host = _h2d_int32(np.concatenate([picks.reshape(-1), taken]), rois.device)
+    return proposal_target_finish(h, host.data_ptr(), host.data_ptr() + B * R * 4, R, means, stds, inside_w, normalize)
+
+
+def anchor_target_prepare(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_stride, negative_overlap,
+                          positive_overlap, counts=None):
+    """_AnchorTargetLayer up to the un-subsampled labels (anchor_target_layer.py:48-136): one HIP launch -> handle with
+    labels, max overlaps, argmax, ordered fg / bg lists and their counts [B,2] on the device"""
     gt_boxes = _chk(gt_boxes.contiguous(), "gt_boxes")
     im_info = _chk(im_info.contiguous(), "im_info")
     base_anchors = _chk(base_anchors.contiguous(), "base_anchors")
@@ -303,19 +330,19 @@ def anchor_target_assign(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_s
     labels = torch.empty((B, total), dtype=torch.float32, device=dev)
     max_ov = torch.empty((B, total), dtype=torch.float32, device=dev)
     ibuf = torch.empty((3, B, total), dtype=torch.int32, device=dev)  # argmax, fg_list, bg_list
-    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    if counts is None:
+        counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
     lib().call("dana_anchor_target_prepare", _p(gt_boxes), _p(im_info), _p(base_anchors), B, A, feat_h, feat_w,
                feat_stride, n_gt, float(negative_overlap), float(positive_overlap), _p(labels), _p(max_ov), _p(ibuf[0]),
                _p(ibuf[1]), _p(ibuf[2]), _p(counts), _stream())
-    num_fg = int(fg_fraction * rpn_batchsize)
-    if device_rng is not None:  # subsample on the device (Philox): no host sync, a different random stream
-        inv_ne = torch.empty((1,), dtype=torch.float32, device=dev)
-        lib().call("dana_anchor_target_subsample", _p(labels), _p(ibuf[1]), _p(ibuf[2]), _p(counts), B, total,
-                   int(rpn_batchsize), num_fg, int(device_rng[0]), int(device_rng[1]), _p(inv_ne), _stream())
-        return dict(labels=labels, max_ov=max_ov, argmax=ibuf[0], ibuf=ibuf, gt_boxes=gt_boxes,
-                    base_anchors=base_anchors, B=B, A=A, H=feat_h, W=feat_w, stride=feat_stride, n_gt=n_gt,
-                    num_examples=1, inv_ne_dev=inv_ne)
-    cnt = counts.cpu().numpy()
+    return dict(labels=labels, max_ov=max_ov, argmax=ibuf[0], ibuf=ibuf, gt_boxes=gt_boxes, base_anchors=base_anchors,
+                B=B, A=A, H=feat_h, W=feat_w, stride=feat_stride, n_gt=n_gt, total=total, counts=counts, num_examples=1)
+
+
+def anchor_target_draw(cnt, B, rpn_batchsize, num_fg):
+    """the reference's np.random.permutation draws (anchor_target_layer.py:137-156) from the host copy of the counts
+    -> (pairs int32 [n, 2] = (image << 1 | is_bg, position in that image's list) to disable, num_examples)"""
+    import numpy as np
     which, pos = [], []
     num_examples = 0
     for i in range(B):
@@ -332,13 +359,118 @@ def anchor_target_assign(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_s
             pos.append(perm.astype(np.int32))
         num_examples = fg_after + min(nb, num_bg)  # the LAST image's count is used for all (:156)
     if which:
-        w_np, p_np = np.concatenate(which), np.concatenate(pos)
-        host = _h2d_int32(np.concatenate([w_np, p_np]), dev)
-        n = int(w_np.size)
-        lib().call("dana_anchor_target_disable", _p(labels), _p(ibuf[1]), _p(ibuf[2]), _p(host),
-                   host.data_ptr() + 4 * n, n, total, _stream())
-    return dict(labels=labels, max_ov=max_ov, argmax=ibuf[0], ibuf=ibuf, gt_boxes=gt_boxes, base_anchors=base_anchors,
-                B=B, A=A, H=feat_h, W=feat_w, stride=feat_stride, n_gt=n_gt, num_examples=max(num_examples, 1))
+        pairs = np.stack([np.concatenate(which), np.concatenate(pos)], 1).astype(np.int32)
+    else:
+        pairs = np.zeros((0, 2), dtype=np.int32)
+    return pairs, max(num_examples, 1)
+
+
+def anchor_target_subsample_device(h, rpn_batchsize, num_fg, seed, offset, counter=None):
+    """device Philox subsampling (no host sync); fills h['inv_ne_dev']"""
+    inv_ne = torch.empty((1,), dtype=torch.float32, device=h["labels"].device)
+    ibuf = h["ibuf"]
+    if counter is None:
+        lib().call("dana_anchor_target_subsample", _p(h["labels"]), _p(ibuf[1]), _p(ibuf[2]), _p(h["counts"]), h["B"],
+                   h["total"], int(rpn_batchsize), num_fg, int(seed), int(offset), _p(inv_ne), _stream())
+    else:
+        lib().call("dana_anchor_target_subsample_ctr", _p(h["labels"]), _p(ibuf[1]), _p(ibuf[2]), _p(h["counts"]), h["B"],
+                   h["total"], int(rpn_batchsize), num_fg, int(seed), int(offset), _p(counter), _p(inv_ne), _stream())
+    h["inv_ne_dev"] = inv_ne
+    return h
+
+
+# ---- the ONE host round trip of the training forward -----------------------------------------------------------------
+# Both target layers stop at their fg / bg counts (4 * B int32 in one buffer). The host reads them once, draws the
+# reference's np.random stream (anchor layer first, as dana.py:166-185 calls them) and sends everything back in ONE
+# pinned upload laid out as int32 words:
+#   [0] number of anchors to disable   [1] 1 / num_examples (float bits)   [2 .. 2+B*R) picks   [.. +B) fg_taken
+#   then (which, pos) pairs, 8-byte aligned. Every consumer reads it through device pointers, so the launches after
+#   the draw have step-independent parameters (a captured hipGraph replays them with each step's draws).
+def draw_layout(B, R, total):
+    pairs_off = (2 + B * R + B + 1) // 2 * 2
+    cap = 2 * B * total  # every fg and every bg anchor of every image could be disabled
+    return dict(picks=2, taken=2 + B * R, pairs=pairs_off, cap=cap, words=pairs_off + 2 * cap)
+
+
+def draw_targets_host(req):
+    """req: dict(counts [2,B,2] device int32, B, R, fg_per, rpn_batchsize, num_fg, total) -> int32 numpy array in
+    draw_layout order, truncated after the last used pair. Blocks until the counts are on the host."""
+    import numpy as np
+    B, R = req["B"], req["R"]
+    lay = draw_layout(B, R, req["total"])
+    cnt = req["counts"].cpu().numpy()  # host sync: np.random needs the counts
+    pairs, num_examples = anchor_target_draw(cnt[0], B, req["rpn_batchsize"], req["num_fg"])
+    picks, taken = proposal_target_draw(cnt[1], B, R, req["fg_per"])
+    n = int(pairs.shape[0])
+    out = np.zeros((lay["pairs"] + 2 * n,), dtype=np.int32)
+    out[0] = n
+    out[1:2] = np.array([1.0 / num_examples], dtype=np.float32).view(np.int32)
+    out[lay["picks"]:lay["picks"] + B * R] = picks.reshape(-1)
+    out[lay["taken"]:lay["taken"] + B] = taken
+    out[lay["pairs"]:] = pairs.reshape(-1)
+    return out
+
+
+def upload_draws(arr, device, static=None):
+    """pinned staging -> device. static: a preallocated int32 device buffer of draw_layout()['words'] words (hipGraph
+    mode: the consumers' pointers are baked into the graph); None: a fresh tensor"""
+    if static is None:
+        return _h2d_int32(arr, device)
+    n = int(arr.size)
+    ring = _PINNED["ring"]
+    if len(ring) < 4:
+        ring.append([torch.empty((max(n, 1 << 16),), dtype=torch.int32, pin_memory=True), None])
+    i = _PINNED["next"] % len(ring)
+    _PINNED["next"] += 1
+    buf, ev = ring[i]
+    if ev is not None:
+        ev.synchronize()
+    if buf.numel() < n:
+        buf = ring[i][0] = torch.empty((n * 2,), dtype=torch.int32, pin_memory=True)
+    buf[:n].numpy()[...] = arr.reshape(-1)
+    static[:n].copy_(buf[:n], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ring[i][1] = ev
+    return static
+
+
+def anchor_target_apply_draws(h, drawn, lay):
+    """labels[list[pos]] = -1 for the drawn (which, pos) pairs; 1/num_examples stays in device memory (drawn[1])"""
+    ibuf = h["ibuf"]
+    base = drawn.data_ptr()
+    lib().call("dana_anchor_target_disable_dev", _p(h["labels"]), _p(ibuf[1]), _p(ibuf[2]), base,
+               base + 4 * lay["pairs"], lay["cap"], h["total"], _stream())
+    h["inv_ne_dev"] = drawn[1:2].view(torch.float32)
+    h["_drawn"] = drawn  # keeps the buffer alive as long as the handle
+    return h
+
+
+def anchor_target_assign(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_stride, negative_overlap,
+                         positive_overlap, rpn_batchsize, fg_fraction, device_rng=None):
+    """_AnchorTargetLayer (anchor_target_layer.py:48-193) up to the sampled labels: one HIP launch, one D2H
+    read of the fg/bg counts, the reference's np.random.permutation draws (:137-156), one scatter launch.
+    Returns a dict consumed by rpn_losses() / anchor_target_outputs()."""
+    import numpy as np
+    h = anchor_target_prepare(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_stride, negative_overlap,
+                              positive_overlap)
+    num_fg = int(fg_fraction * rpn_batchsize)
+    if device_rng is not None:  # subsample on the device (Philox): no host sync, a different random stream
+        return anchor_target_subsample_device(h, rpn_batchsize, num_fg, device_rng[0], device_rng[1])
+    cnt = h["counts"].cpu().numpy()
+    pairs, num_examples = anchor_target_draw(cnt, h["B"], rpn_batchsize, num_fg)
+    n = int(pairs.shape[0])
+    if n:
+        host = _h2d_int32(np.concatenate([pairs[:, 0], pairs[:, 1]]), h["labels"].device)
+        lib().call("dana_anchor_target_disable", _p(h["labels"]), _p(h["ibuf"][1]), _p(h["ibuf"][2]), _p(host),
+                   host.data_ptr() + 4 * n, n, h["total"], _stream())
+    h["num_examples"] = num_examples
+    return h
+
+
+def counter_add_(counter, inc):
+    lib().call("dana_counter_add", _p(counter), int(inc), _stream())
+    return counter
 
 
 def anchor_target_outputs(h, inside_weight=1.0):

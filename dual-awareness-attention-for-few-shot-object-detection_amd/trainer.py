@@ -71,6 +71,9 @@ class FlatBuckets:
 
     def zero_grad(self):
         self.grads.zero_()
+        self.zero_grad_bookkeeping()
+
+    def zero_grad_bookkeeping(self):
         self._pending = [len(ns) for _, _, ns in self.buckets]
         self._works = []
         self.launch_order = []
@@ -89,12 +92,15 @@ class FlatBuckets:
 
     def _launch(self, i):
         self.launch_order.append(i)
-        if not self.collective:
-            return
+        if not self.collective or getattr(self, "capture_only", False):
+            return  # (capture_only: graphs.GraphedTrainer records the order and issues the collectives between replays)
+        self._works.append(self.reduce_bucket(i))
+
+    def reduce_bucket(self, i):
+        """issue bucket i's asynchronous all_reduce behind the current stream's work -> the work handle"""
         s, e, _ = self.buckets[i]
         if not self.grads.is_cuda:
-            self._works.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            return
+            return dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         # RCCL orders a collective behind whatever stream is CURRENT when it is issued. The gradients of a bucket are
         # final on the caller's stream at this point (backward joins its weight-gradient / box-branch side streams
         # into it before marking a stage ready), but which stream that is depends on where in the backward the stage
@@ -110,7 +116,11 @@ class FlatBuckets:
         final.record()
         self._comm.wait_event(final)
         with torch.cuda.stream(self._comm):
-            self._works.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def join_comm(self):
+        if self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
 
     def wait_all(self):
         """all buckets must have left; blocks the current stream (not the host, for nccl) until the sums arrived"""

@@ -288,6 +288,11 @@ int dana_anchor_target_prepare(const float* gt_boxes, const float* im_info, cons
 /* labels[image][list[pos]] = -1 for n subsampled-away entries; which[e] = image*2 + (0 fg | 1 bg). */
 int dana_anchor_target_disable(float* labels, const int* fg_list, const int* bg_list, const int* which,
                                const int* pos, int n, int anchors_per_image, dana_stream_t stream);
+/* the same with the number of entries read from DEVICE memory (n_dev[0] <= capacity) and the entries interleaved as
+ * (which, pos) pairs: the launch parameters never change, so a captured hipGraph can replay it with each step's draws */
+int dana_anchor_target_disable_dev(float* labels, const int* fg_list, const int* bg_list, const int* n_dev,
+                                   const int* which_pos_pairs, int capacity, int anchors_per_image,
+                                   dana_stream_t stream);
 /* _AnchorTargetLayer's four outputs in the reference layouts: labels_out[B][A*H*W] (a-major),
  * bbox_targets / inside / outside weights [B][4A][H*W] (:171-191). */
 int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, const int* argmax,
@@ -421,6 +426,18 @@ int dana_proposal_target_sample(const int* counts, int B, int n_candidates, int 
 int dana_anchor_target_subsample(float* labels, const int* fg_list, const int* bg_list, const int* counts, int B,
                                  int anchors_per_image, int rpn_batchsize, int num_fg, unsigned long long seed,
                                  unsigned long long offset, float* inv_num_examples, dana_stream_t stream);
+/* hipGraph-friendly forms of the two samplers: the per-call Philox offset is `offset + counter_dev[0]`, with the call
+ * counter living in device memory and advanced by dana_counter_add inside the same captured graph, so that every replay
+ * draws fresh samples */
+int dana_proposal_target_sample_ctr(const int* counts, int B, int n_candidates, int rois_per_image,
+                                    int fg_rois_per_image, unsigned long long seed, unsigned long long offset,
+                                    const unsigned long long* counter_dev, int* picks, int* fg_taken,
+                                    dana_stream_t stream);
+int dana_anchor_target_subsample_ctr(float* labels, const int* fg_list, const int* bg_list, const int* counts, int B,
+                                     int anchors_per_image, int rpn_batchsize, int num_fg, unsigned long long seed,
+                                     unsigned long long offset, const unsigned long long* counter_dev,
+                                     float* inv_num_examples, dana_stream_t stream);
+int dana_counter_add(unsigned long long* counter_dev, unsigned long long inc, dana_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -370,8 +370,9 @@ def proposal_target_layer(all_rois, gt_boxes):
     tg = bbox_transform_batch(rois_b[:, :, 1:5], gt_b[:, :, :4])
     tg = (tg - torch.tensor(t["BBOX_NORMALIZE_MEANS"])) / torch.tensor(t["BBOX_NORMALIZE_STDS"])
     fgm = (labels_b > 0).unsqueeze(2).float()
-    # :83-91: only fg rows keep targets; images whose labels sum to 0 keep nothing (same thing)
-    targets = tg * fgm
+    # :83-91: only fg rows are COPIED into the zero-initialised target tensor; images whose labels sum to 0 keep
+    # nothing (same thing). A select, not a product: a bg row whose raw target is inf / nan (degenerate box) stays 0.
+    targets = torch.where(fgm > 0, tg, torch.zeros_like(tg))
     w_in = fgm.expand(B, R, 4).clone()
     w_out = (w_in > 0).float()
     return rois_b, labels_b, targets, w_in, w_out
@@ -390,7 +391,7 @@ def sampled_targets(rois_b, labels_b, gt_boxes):
     tg = (tg - torch.tensor(t["BBOX_NORMALIZE_MEANS"])) / torch.tensor(t["BBOX_NORMALIZE_STDS"])
     fgm = (labels_b > 0).unsqueeze(2).float()
     w_in = fgm.expand(B, R, 4).clone()
-    return rois_b, labels_b, tg * fgm, w_in, (w_in > 0).float()
+    return rois_b, labels_b, torch.where(fgm > 0, tg, torch.zeros_like(tg)), w_in, (w_in > 0).float()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -597,12 +598,7 @@ def meta_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, all_cls
         keep = lab.view(-1).ne(-1).nonzero().view(-1)
         rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
         rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
-        if sampled is not None:  # stage-wise parity: the caller supplies the sampled batch (see sampled_targets)
-            rois, rois_label, rois_target, rw_in, rw_out = sampled
-        else:
-            rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
-        if inter is not None:
-            inter["sampled"] = (rois.clone(), rois_label.clone(), rois_target.clone(), rw_in.clone(), rw_out.clone())
+        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
     if differentiable:
@@ -657,12 +653,7 @@ def fsod_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, trainin
         keep = lab.view(-1).ne(-1).nonzero().view(-1)
         rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
         rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
-        if sampled is not None:  # stage-wise parity: the caller supplies the sampled batch (see sampled_targets)
-            rois, rois_label, rois_target, rw_in, rw_out = sampled
-        else:
-            rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
-        if inter is not None:
-            inter["sampled"] = (rois.clone(), rois_label.clone(), rois_target.clone(), rw_in.clone(), rw_out.clone())
+        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
     pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
@@ -732,12 +723,7 @@ def fgn_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training
         keep = lab.view(-1).ne(-1).nonzero().view(-1)
         rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
         rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
-        if sampled is not None:  # stage-wise parity: the caller supplies the sampled batch (see sampled_targets)
-            rois, rois_label, rois_target, rw_in, rw_out = sampled
-        else:
-            rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
-        if inter is not None:
-            inter["sampled"] = (rois.clone(), rois_label.clone(), rois_target.clone(), rw_in.clone(), rw_out.clone())
+        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
     pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
@@ -791,12 +777,7 @@ def frcnn_forward(sd, im_data, im_info, gt_boxes, num_boxes, training, nms_inclu
         keep = lab.view(-1).ne(-1).nonzero().view(-1)
         rpn_loss_cls = F.cross_entropy(sc[keep], lab.view(-1)[keep].long())
         rpn_loss_bbox = smooth_l1(bbox, tg, w_in, w_out, sigma=3, dims=(1, 2, 3))
-        if sampled is not None:  # stage-wise parity: the caller supplies the sampled batch (see sampled_targets)
-            rois, rois_label, rois_target, rw_in, rw_out = sampled
-        else:
-            rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
-        if inter is not None:
-            inter["sampled"] = (rois.clone(), rois_label.clone(), rois_target.clone(), rw_in.clone(), rw_out.clone())
+        rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
     r5 = rois.view(-1, 5).numpy()
