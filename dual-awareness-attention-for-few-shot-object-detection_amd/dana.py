@@ -672,11 +672,17 @@ class DAnARCNN(nn.Module):
             side.wait_event(inputs_ready)  # NOT wait_stream(main): the trunk is already queued there
             tr_ = cfg.TRAIN
             num_fg = int(tr_.RPN_FG_FRACTION * tr_.RPN_BATCHSIZE)
-            counts_all = torch.empty((2, B, 2), dtype=torch.int32, device=dev)  # [anchor | proposal][image][fg, bg]
-            counts_all.record_stream(side)
             gt_f = gt_boxes.float().contiguous()
+            if gt_f is not gt_boxes:  # converted on the caller's stream: the side stream must see the result
+                conv_done = torch.cuda.Event()
+                conv_done.record()
+                side.wait_event(conv_done)
             gt_f.record_stream(side)
             with torch.cuda.stream(side):
+                # allocated in the SIDE stream's pool: a block recycled from the caller's stream could still be
+                # written by kernels queued there (the trunk) after this stream has already filled it
+                counts_all = torch.empty((2, B, 2), dtype=torch.int32, device=dev)  # [anchor | proposal][image][fg, bg]
+                counts_all.record_stream(main)
                 at = ops.anchor_target_prepare(gt_f, im_info, plan["anchors"], fh, fw, rpn.feat_stride,
                                                tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP, counts=counts_all[0])
                 if rng is not None:
