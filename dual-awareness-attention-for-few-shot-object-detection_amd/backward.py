@@ -30,7 +30,21 @@ class WeightGrads:
         self.stream = stream
         self.model = model
         self.direct = {}  # key -> packed VIEW of param.grad (trainer layout): weight gradients land there directly
-        self.keep = []    # operands of in-flight side-stream launches (allocated on the caller's stream)
+        # One side stream PER CALLER STREAM (the box branch issues its weight gradients from the layer4 stream, the rest
+        # of the backward from the caller's): every side stream forks from and joins into exactly one parent, and the
+        # two families of launches no longer queue behind each other.
+        self.side = {}    # caller stream handle -> [side stream, operands kept alive while its launches are in flight]
+
+    def _side_for_current(self):
+        cur = torch.cuda.current_stream()
+        ent = self.side.get(cur.cuda_stream)
+        if ent is None:
+            if not self.side or self.model is None:
+                st = self.stream
+            else:
+                st = self.model._stream("wgrad.%d" % len(self.side), cur.device)
+            ent = self.side[cur.cuda_stream] = [st, []]
+        return ent
 
     def _direct_view(self, key):
         """the parameter's gradient as a packed [cout][kh*kw*cin] view, if the trainer stores it that way"""
@@ -51,11 +65,12 @@ class WeightGrads:
         if self.stream is None:
             self._launch(key, g, x, n, h, w, c, in_stride, grad_stride)
             return
+        st, keep = self._side_for_current()
         ready = torch.cuda.Event()
         ready.record()
-        self.stream.wait_event(ready)
-        self.keep.append((g, x))
-        with torch.cuda.stream(self.stream):
+        st.wait_event(ready)
+        keep.append((g, x))
+        with torch.cuda.stream(st):
             self._launch(key, g, x, n, h, w, c, in_stride, grad_stride)
 
     def _launch(self, key, g, x, n, h, w, c, in_stride, grad_stride):
@@ -84,11 +99,15 @@ class WeightGrads:
 
     def join(self):
         """the caller's stream waits for every weight-gradient launch issued so far"""
-        if self.stream is not None and self.keep:
-            done = torch.cuda.Event()
-            done.record(self.stream)
-            torch.cuda.current_stream().wait_event(done)
-            self.keep = []
+        if self.stream is None:
+            return
+        cur = torch.cuda.current_stream()
+        for st, keep in self.side.values():
+            if keep:
+                done = torch.cuda.Event()
+                done.record(st)
+                cur.wait_event(done)
+                del keep[:]
 
     def finish_conv(self, key, c, param):
         """apply the frozen-BN scale to the rows and add into param.grad (OIHW)"""
@@ -307,7 +326,10 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     #    the two gradients of the pooled features meet, so it runs on the forward's layer4 stream: the heads' backward
     #    (many small launches) fills the CUs its big launches leave idle in their tails. --
     main = torch.cuda.current_stream()
-    l4_stream = main if getattr(model, "_single_stream", False) else model._stream("layer4", dev)
+    # (under stream capture the box branch stays on the caller's stream: a weight-gradient side stream forked from an
+    # already forked stream crashes hipStreamEndCapture on ROCm 7.2 -- tools/graph_debug.py modes 8 / 12 / 13)
+    l4_stream = main if (getattr(model, "_single_stream", False) or torch.cuda.is_current_stream_capturing()) \
+        else model._stream("layer4", dev)
     seeds_ready = torch.cuda.Event()
     seeds_ready.record()
     stages = grad_stages(model)

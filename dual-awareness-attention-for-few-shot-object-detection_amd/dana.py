@@ -337,6 +337,13 @@ class DAnARCNN(nn.Module):
             st = self._consts[key] = torch.cuda.Stream(device=dev)
         return st
 
+    def _rng_counter(self, dev):
+        """uint64 call counter of the device RNG in device memory (hipGraph mode: the graph advances it itself)"""
+        key = ("rng_counter", str(dev))
+        if key not in self._consts:
+            self._consts[key] = torch.zeros(1, dtype=torch.int64, device=dev)
+        return self._consts[key]
+
     @staticmethod
     def _w(layer):
         return layer.weight.detach().contiguous(), layer.bias.detach().contiguous()
@@ -666,7 +673,8 @@ class DAnARCNN(nn.Module):
                 # inside a hipGraph the call counter must be DATA: a uint64 in device memory, advanced by the graph itself
                 ctr = self._consts.get(("rng_counter", str(dev)))
                 if ctr is None:
-                    ctr = self._consts[("rng_counter", str(dev))] = torch.zeros(1, dtype=torch.int64, device=dev)
+                    raise RuntimeError("capture with device_rng needs model._rng_counter(device) created BEFORE the "
+                                       "capture (inside it the zero fill would be replayed with the graph)")
                 rng = (int(self.rng_seed), 0)
             side = self._stream("targets", dev)
             side.wait_event(inputs_ready)  # NOT wait_stream(main): the trunk is already queued there

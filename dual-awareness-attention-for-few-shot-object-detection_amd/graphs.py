@@ -54,6 +54,9 @@ class GraphedDAnA:
             for _ in range(warmup):  # eager: fills the plan / constant caches, sets kernel attributes
                 model(*self.inputs)
         torch.cuda.synchronize(dev)
+        if getattr(model, "device_rng", False):
+            model._rng_counter(dev).fill_(2 * model._rng_calls)  # continues the eager call sequence
+        torch.cuda.synchronize(dev)
         self.g1 = torch.cuda.CUDAGraph()
         with torch.no_grad():
             with torch.cuda.graph(self.g1, stream=self.stream, capture_error_mode="thread_local"):
@@ -147,6 +150,8 @@ class GraphedTrainer:
             seen.extend(fresh)
             return fresh
 
+        if getattr(model, "device_rng", False):
+            model._rng_counter(dev).fill_(2 * model._rng_calls)
         torch.cuda.synchronize(dev)
         try:
             with torch.no_grad():
@@ -154,8 +159,9 @@ class GraphedTrainer:
                 out, bgen, seen = None, None, []
                 # ---- graph 1: zero the gradients, forward up to the host round trip (or to its end) ----
                 with graph():
-                    for fb, _, _ in tr.groups:
-                        fb.grads.zero_()
+                    if not __import__("os").environ.get("DANA_DBG_NOZERO"):
+                        for fb, _, _ in tr.groups:
+                            fb.grads.zero_()
                     try:
                         self.req = next(gen)
                     except StopIteration as done:

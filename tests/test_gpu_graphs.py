@@ -75,7 +75,7 @@ def test_graphed_forward_with_device_rng_is_one_graph_and_advances_its_counter(d
         eager = [[t.clone() for t in m(*inputs)] for _ in range(3)]
     run = GraphedDAnA(m, *inputs, warmup=0)
     assert run.g2 is None  # no host round trip
-    m._consts[("rng_counter", str(dev))].zero_()
+    m._rng_counter(dev).zero_()
     for k in range(3):  # replay k draws what the eager call number k drew
         out = run(*inputs)
         torch.cuda.synchronize()
