@@ -65,6 +65,11 @@ def parse():
     ap.add_argument("--device-rng", action="store_true",
                     help="sample the training targets with the device Philox RNG (no host sync; NOT the reference's "
                          "np.random stream, which is the default and what the parity tests pin)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
+                    help="graph: replay captured hipGraphs (graphs.py: ~4x less host time per step); eager: one C-ABI call "
+                         "per kernel from Python; auto (default): a short trial of both, the faster one is timed and both "
+                         "trial figures are reported")
+    ap.add_argument("--eager", action="store_true", help="= --launch eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
@@ -238,10 +243,71 @@ def main():
                                bbox_pred[i * rois.size(1):(i + 1) * rois.size(1)], inputs[1][i:i + 1])
                     for i in range(rois.size(0))]
 
-    step = {"step": train_step, "infer": infer_step}.get(args.mode, fwd_step)
+    eager_step = {"step": train_step, "infer": infer_step}.get(args.mode, fwd_step)
+    step = eager_step
+    if args.eager:
+        args.launch = "eager"
+    use_graphs = args.launch != "eager" and args.model == "DAnA" and not args.single_stream
     np.random.seed(1996 + rank)
+    graphed = {}
+    if use_graphs:
+        # hipGraph replay (graphs.py): the forward = two captured graphs around the one host round trip (the reference's
+        # np.random draws need the fg / bg counts), the training iteration likewise (+ backward + SGD; multi-rank: cut
+        # once more so that the RCCL all-reduce overlaps the trunk's backward)
+        from dana_amd.graphs import GraphedDAnA, GraphedTrainer
+        if args.mode == "step":
+            train_step()  # builds the trainer
+            gtr = graphed["trainer"] = GraphedTrainer(trainer[0], *inputs)
+            step = lambda: gtr.step(*gtr.inputs)  # noqa: E731
+        else:
+            run = graphed["forward"] = GraphedDAnA(model, *inputs)
+            if args.mode == "infer":
+                def step():
+                    from dana_amd.postprocess import detections
+                    rois, cls_prob, bbox_pred = run(*run.inputs)[:3]
+                    return [detections(rois[i:i + 1], cls_prob[i * rois.size(1):(i + 1) * rois.size(1)],
+                                       bbox_pred[i * rois.size(1):(i + 1) * rois.size(1)], inputs[1][i:i + 1])
+                            for i in range(rois.size(0))]
+            else:
+                step = lambda: run(*run.inputs)  # noqa: E731
+    graph_step = step
+
+    def trial(fn, k):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k * 1e3
+
+    launch_trial = None
+    if use_graphs and args.launch == "auto":
+        kt = max(5, min(20, args.steps))
+        launch_trial = {"graph_ms_per_step": round(trial(graph_step, kt), 3), "eager_ms_per_step": round(trial(eager_step, kt), 3),
+                        "steps_each": kt}
+        if world > 1:  # every rank must take the same path
+            t = torch.tensor([launch_trial["graph_ms_per_step"], launch_trial["eager_ms_per_step"]], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            launch_trial["graph_ms_per_step"], launch_trial["eager_ms_per_step"] = round(float(t[0]), 3), round(float(t[1]), 3)
+        if launch_trial["eager_ms_per_step"] < launch_trial["graph_ms_per_step"]:
+            step = eager_step
+    timed_graphs = use_graphs and step is not eager_step
     for _ in range(args.warmup):
         step()
+
+    def host_enqueue_ms(fn, k=20):
+        """host time per step spent ISSUING work (Python + runtime calls), excluding the time blocked on the GPU in the
+        training forward's one D2H read"""
+        torch.cuda.synchronize()
+        ops.HOST_WAIT[0] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        dt_ = time.perf_counter() - t0 - ops.HOST_WAIT[0]
+        torch.cuda.synchronize()
+        return round(1e3 * dt_ / k, 3)
 
     def barrier():
         torch.cuda.synchronize()
@@ -270,6 +336,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    host_ms_graph = host_enqueue_ms(graph_step) if use_graphs else None
+    host_ms_eager = host_enqueue_ms(eager_step, 10)
     what = {"step": "training step fwd+bwd+allreduce+SGD",
             "infer": "eval-mode forward + detection post-processing per image"}.get(args.mode, "%s-mode forward" % args.mode)
     result = {
@@ -285,6 +353,12 @@ def main():
         "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "ms_per_episode": round(1000.0 * dt / args.steps / args.batch, 3),
         "ms_per_step_median": median_interval(marks_f),
+        "launch": ("hipGraph replay, %d graph launches per step (graphs.py)" % (
+            (len(graphed["trainer"].graphs) + (graphed["trainer"].g_anchor is not None)) if args.mode == "step" else
+            (1 + (graphed["forward"].g0 is not None) + (graphed["forward"].g2 is not None))))
+        if timed_graphs else "eager (one C-ABI call per kernel from Python)",
+        "launch_trial": launch_trial,
+        "host_enqueue_ms_per_step": {"graph": host_ms_graph, "eager": host_ms_eager},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -300,6 +374,9 @@ def main():
                                    "configuration, no oracle)", "BA+CISA" if args.ba else "CISA only", what),
                    "global_batch": world * args.batch, "parallelism": "episodes sharded, %d rank(s)" % world,
                    "target_sampling": "device Philox RNG" if args.device_rng else "host np.random (reference stream)",
+                   "configs_not_run": "configs[3] (res101, way 5) cannot run on the reference (dana.py:328-337) and is not "
+                                      "built; configs[4] (800x1333, shot 10) is covered by tests/test_gpu_model.py::"
+                                      "test_config4_* and `bench.py --height 800 --width 1333 --shot 10 --batch 2`",
                    "contractions": ("fp32 operands and accumulation; multiplies as an exact 3-way bf16 split, six products on "
                                     "v_mfma_f32_32x32x16_bf16 (error vs fp64 at the f32-MFMA kernel's level; "
                                     "f32_mfma_only = the same step with v_mfma_f32_32x32x2_f32)")
@@ -309,9 +386,27 @@ def main():
     if args.mode == "train" and not args.no_train_step:
         # secondary measurement, every rank: variant S, the full training iteration with the
         # gradient all-reduce over RCCL as its one exchange step. Same episodes, same timing protocol.
-        ks, kw = max(3, min(args.steps, 10)), 5  # the first iterations grow the allocator's pools
+        ks, kw = max(3, min(args.steps, 20)), 5  # the first iterations grow the allocator's pools
         for _ in range(kw):
             train_step()
+        eager_train_step = graph_train_step = train_step
+        ts_trial = None
+        if use_graphs:
+            from dana_amd.graphs import GraphedTrainer
+            gtr = graphed["trainer"] = GraphedTrainer(trainer[0], *inputs)
+            graph_train_step = lambda: gtr.step(*gtr.inputs)  # noqa: E731
+            train_step = graph_train_step
+            if args.launch == "auto":
+                ts_trial = {"graph_ms_per_step": round(trial(graph_train_step, 8), 3),
+                            "eager_ms_per_step": round(trial(eager_train_step, 8), 3)}
+                if world > 1:
+                    t = torch.tensor([ts_trial["graph_ms_per_step"], ts_trial["eager_ms_per_step"]], device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    ts_trial["graph_ms_per_step"], ts_trial["eager_ms_per_step"] = round(float(t[0]), 3), round(float(t[1]), 3)
+                if ts_trial["eager_ms_per_step"] < ts_trial["graph_ms_per_step"]:
+                    train_step = eager_train_step
+            for _ in range(3):
+                train_step()
         barrier()
         marks_s = [torch.cuda.Event(enable_timing=True)]
         marks_s[0].record()
@@ -335,6 +430,10 @@ def main():
             "ms_per_step": round(1000.0 * dts / ks, 3), "ms_per_step_median": median_interval(marks_s),
             "gradient_mbytes": round(4e-6 * sum(fb.numel for fb, _, _ in tr.groups), 1),
             "buckets": sum(len(fb.buckets) for fb, _, _ in tr.groups),
+            "launch": "hipGraph replay" if train_step is not eager_train_step else "eager",
+            "launch_trial": ts_trial,
+            "host_enqueue_ms_per_step": {"graph": host_enqueue_ms(graph_train_step, 10) if use_graphs else None,
+                                         "eager": host_enqueue_ms(eager_train_step, 5)},
         }
 
     if rank == 0 and not args.no_roofline and args.mode != "step":
@@ -347,7 +446,7 @@ def main():
             model._single_stream = True
             torch.cuda.synchronize()
             for _ in range(args.steps):
-                step()
+                eager_step()
             torch.cuda.synchronize()
             model._single_stream = bool(args.single_stream)
             prof, ops.PROFILE = ops.PROFILE, None
@@ -439,12 +538,12 @@ def main():
             # For reference: the same step and the same contraction pass with every contraction on the f32 MFMA.
             ops.set_mfma_mode(0)
             for _ in range(3):
-                step()
+                eager_step()
             torch.cuda.synchronize()
             k0 = max(5, args.steps // 4)
             t0 = time.perf_counter()
             for _ in range(k0):
-                step()
+                eager_step()
             torch.cuda.synchronize()
             dt0 = time.perf_counter() - t0
             keep_steps, args.steps = args.steps, k0
@@ -468,12 +567,17 @@ def main():
         m1.device_rng = bool(args.device_rng)
         k1 = max(10, args.steps // 2)
         with torch.no_grad():
-            for _ in range(5):
-                m1(*inputs)
+            f1 = lambda: m1(*inputs)  # noqa: E731
+            if use_graphs:
+                from dana_amd.graphs import GraphedDAnA
+                run1 = GraphedDAnA(m1, *inputs)
+                f1 = lambda: run1(*run1.inputs)  # noqa: E731
+            for _ in range(10):
+                f1()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(k1):
-                m1(*inputs)
+                f1()
             torch.cuda.synchronize()
         dt1 = time.perf_counter() - t0
         result["configs_1_cisa_only"] = {"value": round(args.batch * k1 / dt1, 3), "unit": "query-images/sec",

@@ -461,6 +461,8 @@ class DAnARCNN(nn.Module):
         gen = self._forward_gen(im_data, im_info, gt_boxes, num_boxes, support_ims)
         try:
             req = next(gen)
+            if req["stage"] == "anchor":  # (anchor targets enqueued on their side stream: nothing to do eagerly)
+                req = next(gen)
         except StopIteration as done:
             return done.value
         drawn = ops.upload_draws(ops.draw_targets_host(req), im_data.device)
@@ -509,6 +511,52 @@ class DAnARCNN(nn.Module):
         inputs_ready = torch.cuda.Event()
         inputs_ready.record()
         sup_stream = self._stream("support", dev)
+        at = rng = ctr = side = None
+        if training:
+            # Anchor targets, first half (anchor_target_layer.py:48-136: everything up to the fg / bg counts). They depend
+            # on the inputs only, so they go FIRST, on a side stream: the counts are on the host long before the trunk
+            # is done and the reference's np.random.permutation draws over ~10^5 anchors (about a millisecond of host
+            # time) run while the GPU is busy with the trunk.
+            capturing = torch.cuda.is_current_stream_capturing()
+            if self.device_rng:  # counter-based device RNG (opt-in): (seed, 2 * forward counter [+ 1])
+                rng = (int(self.rng_seed), 2 * self._rng_calls)
+                self._rng_calls += 1
+                if capturing:
+                    # inside a hipGraph the call counter must be DATA: a uint64 in device memory, advanced by the graph
+                    ctr = self._consts.get(("rng_counter", str(dev)))
+                    if ctr is None:
+                        raise RuntimeError("capture with device_rng needs model._rng_counter(device) created BEFORE the "
+                                           "capture (inside it the zero fill would be replayed with the graph)")
+                    rng = (int(self.rng_seed), 0)
+            tr_ = cfg.TRAIN
+            num_fg = int(tr_.RPN_FG_FRACTION * tr_.RPN_BATCHSIZE)
+            afh, afw = self._feat_size(im_data.size(2), im_data.size(3))
+            # host-RNG capture: this block is its own little graph, replayed on the side stream (graphs.py)
+            side = main if (capturing and rng is None) else self._stream("targets", dev)
+            gt_f = gt_boxes.float().contiguous()
+            if side is not main:
+                side.wait_event(inputs_ready)
+                if gt_f is not gt_boxes:  # converted on the caller's stream: the side stream must see the result
+                    conv_done = torch.cuda.Event()
+                    conv_done.record()
+                    side.wait_event(conv_done)
+                gt_f.record_stream(side)
+            with torch.cuda.stream(side):
+                # allocated in the SIDE stream's pool: a block recycled from the caller's stream could still be
+                # written by kernels queued there after this stream has already filled it
+                at = ops.anchor_target_prepare(gt_f, im_info, plan["anchors"], afh, afw, self.RCNN_rpn.feat_stride,
+                                               tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP)
+                if rng is not None:
+                    ops.anchor_target_subsample_device(at, tr_.RPN_BATCHSIZE, num_fg, rng[0], rng[1], counter=ctr)
+            if side is not main:
+                for k_ in ("ibuf", "labels", "max_ov", "counts"):
+                    at[k_].record_stream(main)
+                if rng is not None:
+                    at["inv_ne_dev"].record_stream(main)
+            if rng is None:
+                yield dict(stage="anchor", counts=at["counts"], stream=side)  # (a graph driver ends its first capture here)
+                inputs_ready = torch.cuda.Event()  # an event of a finished capture cannot fork streams into the next one
+                inputs_ready.record()
 
         # -- feature extraction (dana.py:98-115): query and support batches share every trunk launch
         #    (twice the tiles -> half the tail on the 256 CUs); everything that depends only on the
@@ -661,49 +709,12 @@ class DAnARCNN(nn.Module):
         rpn_loss_cls = rpn_loss_bbox = 0
         rois_label = None
         if training:
-            # Target layers, first halves (everything up to the fg / bg counts; nothing random yet). The anchor side
-            # depends on the inputs only: it runs on a side stream, concurrently with the trunk.
-            rng = None
-            capturing = torch.cuda.is_current_stream_capturing()
-            if self.device_rng:  # counter-based device RNG (opt-in): (seed, 2 * forward counter [+ 1])
-                rng = (int(self.rng_seed), 2 * self._rng_calls)
-                self._rng_calls += 1
-            ctr = None
-            if self.device_rng and capturing:
-                # inside a hipGraph the call counter must be DATA: a uint64 in device memory, advanced by the graph itself
-                ctr = self._consts.get(("rng_counter", str(dev)))
-                if ctr is None:
-                    raise RuntimeError("capture with device_rng needs model._rng_counter(device) created BEFORE the "
-                                       "capture (inside it the zero fill would be replayed with the graph)")
-                rng = (int(self.rng_seed), 0)
-            side = self._stream("targets", dev)
-            side.wait_event(inputs_ready)  # NOT wait_stream(main): the trunk is already queued there
-            tr_ = cfg.TRAIN
-            num_fg = int(tr_.RPN_FG_FRACTION * tr_.RPN_BATCHSIZE)
-            gt_f = gt_boxes.float().contiguous()
-            if gt_f is not gt_boxes:  # converted on the caller's stream: the side stream must see the result
-                conv_done = torch.cuda.Event()
-                conv_done.record()
-                side.wait_event(conv_done)
-            gt_f.record_stream(side)
-            with torch.cuda.stream(side):
-                # allocated in the SIDE stream's pool: a block recycled from the caller's stream could still be
-                # written by kernels queued there (the trunk) after this stream has already filled it
-                counts_all = torch.empty((2, B, 2), dtype=torch.int32, device=dev)  # [anchor | proposal][image][fg, bg]
-                counts_all.record_stream(main)
-                at = ops.anchor_target_prepare(gt_f, im_info, plan["anchors"], fh, fw, rpn.feat_stride,
-                                               tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP, counts=counts_all[0])
-                if rng is not None:
-                    ops.anchor_target_subsample_device(at, tr_.RPN_BATCHSIZE, num_fg, rng[0], rng[1], counter=ctr)
-                    at["inv_ne_dev"].record_stream(main)
-            at["ibuf"].record_stream(main)
-            at["labels"].record_stream(main)
-            at["max_ov"].record_stream(main)
-            main.wait_stream(side)
+            # Proposal targets, first half (proposal_target_layer_cascade.py:113-141), behind the proposal layer
+            if side is not main:
+                main.wait_stream(side)
             fg_per = int(np.round(tr_.FG_FRACTION * tr_.BATCH_SIZE)) or 1
             R_t = int(tr_.BATCH_SIZE)
-            pt = ops.proposal_target_prepare(rois, gt_f, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO,
-                                             counts=counts_all[1])
+            pt = ops.proposal_target_prepare(rois, gt_f, tr_.FG_THRESH, tr_.BG_THRESH_HI, tr_.BG_THRESH_LO)
             if tl is not None:
                 tl.append(("target layers enqueued (first halves)", _time.perf_counter()))
             if rng is None:
@@ -712,8 +723,9 @@ class DAnARCNN(nn.Module):
                     main.wait_event(support_roi_done)
                     support_roi_done = None
                 lay = ops.draw_layout(B, R_t, at["total"])
-                drawn = yield dict(counts=counts_all, B=B, R=R_t, fg_per=fg_per, rpn_batchsize=int(tr_.RPN_BATCHSIZE),
-                                   num_fg=num_fg, total=at["total"], layout=lay)
+                drawn = yield dict(stage="draw", anchor_counts=at["counts"], anchor_stream=side,
+                                   proposal_counts=pt["counts"], B=B, R=R_t, fg_per=fg_per,
+                                   rpn_batchsize=int(tr_.RPN_BATCHSIZE), num_fg=num_fg, total=at["total"], layout=lay)
                 ops.anchor_target_apply_draws(at, drawn, lay)
                 picks_ptr, taken_ptr = drawn.data_ptr() + 4 * lay["picks"], drawn.data_ptr() + 4 * lay["taken"]
             else:

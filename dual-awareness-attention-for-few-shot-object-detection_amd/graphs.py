@@ -57,22 +57,32 @@ class GraphedDAnA:
         if getattr(model, "device_rng", False):
             model._rng_counter(dev).fill_(2 * model._rng_calls)  # continues the eager call sequence
         torch.cuda.synchronize(dev)
-        self.g1 = torch.cuda.CUDAGraph()
+        self.side = torch.cuda.Stream(device=dev)  # the anchor-target graph replays here, beside the trunk
+        self.g0 = None
+        opts = dict(stream=self.stream, capture_error_mode="thread_local")
         with torch.no_grad():
-            with torch.cuda.graph(self.g1, stream=self.stream, capture_error_mode="thread_local"):
-                gen = model._forward_gen(*self.inputs)
+            gen = model._forward_gen(*self.inputs)
+            out = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **opts):
                 try:
-                    self.req = next(gen)
-                    out = None
-                except StopIteration as done:
-                    out = done.value
-            if self.req is not None:
-                self.drawn = torch.zeros((self.req["layout"]["words"],), dtype=torch.int32, device=dev)
+                    req = next(gen)
+                except StopIteration as done:  # eval mode / device RNG: the whole forward is one graph
+                    req, out = None, done.value
+            if req is not None and req["stage"] == "anchor":
+                self.g0, g = g, torch.cuda.CUDAGraph()  # graph 0: the anchor targets' first half (inputs only)
+                with torch.cuda.graph(g, pool=self.g0.pool(), **opts):
+                    req = next(gen)
+            self.g1 = g
+            if req is not None:
+                assert req["stage"] == "draw"
+                self.req = dict(req, anchor_stream=self.side)
+                self.drawn = torch.zeros((req["layout"]["words"],), dtype=torch.int32, device=dev)
                 self.g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g2, pool=self.g1.pool(), stream=self.stream, capture_error_mode="thread_local"):
+                with torch.cuda.graph(self.g2, pool=self.g1.pool(), **opts):
                     try:
                         gen.send(self.drawn)
-                        raise RuntimeError("the forward paused twice")
+                        raise RuntimeError("the forward paused more often than expected")
                     except StopIteration as done:
                         out = done.value
         self.outputs = out
@@ -82,9 +92,16 @@ class GraphedDAnA:
         for s, t in zip(self.inputs, inputs):
             if torch.is_tensor(t) and t is not s:
                 s.copy_(t, non_blocking=True)
+        cur = torch.cuda.current_stream()
+        if self.g0 is not None:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.g0.replay()
         self.g1.replay()
         if self.g2 is not None:
+            # anchor counts: behind the side stream only -> the anchor draws overlap the trunk (graph 1) on the GPU
             ops.upload_draws(ops.draw_targets_host(self.req), self.drawn.device, static=self.drawn)
+            cur.wait_stream(self.side)
             self.g2.replay()
         return self.outputs
 
@@ -127,7 +144,8 @@ class GraphedTrainer:
         tr, model = self.trainer, self.model
         dev = self.inputs[0].device
         self.graphs = []     # [[graph, [(FlatBuckets, bucket index) to all-reduce after it]]]
-        self.req = self.drawn = None
+        self.req = self.drawn = self.g_anchor = None
+        self.side = torch.cuda.Stream(device=dev)
         model._epoch += 1    # every trainable conv's derived tensors are re-derived INSIDE the capture
         model._plan = None
         prev_save = getattr(model, "save_for_backward", False)
@@ -142,6 +160,8 @@ class GraphedTrainer:
             g = torch.cuda.CUDAGraph()
             self.graphs.append([g, []])
             kw = {} if pool[0] is None else {"pool": pool[0]}
+            if pool[0] is None and self.g_anchor is not None:
+                kw = {"pool": self.g_anchor.pool()}
             return torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local", **kw)
 
         def ready_buckets(seen):
@@ -156,26 +176,35 @@ class GraphedTrainer:
         try:
             with torch.no_grad():
                 gen = model._forward_gen(*self.inputs)
-                out, bgen, seen = None, None, []
+                out, bgen, seen, req = None, None, [], None
+                first = True
+                # ---- graph 0 (host RNG only): the anchor targets' first half; replayed on the side stream ----
                 # ---- graph 1: zero the gradients, forward up to the host round trip (or to its end) ----
-                with graph():
-                    if not __import__("os").environ.get("DANA_DBG_NOZERO"):
-                        for fb, _, _ in tr.groups:
-                            fb.grads.zero_()
-                    try:
-                        self.req = next(gen)
-                    except StopIteration as done:
-                        out = done.value
-                    if out is not None:
-                        bgen = self._backward_until_cut(model._ctx, collective)
-                pool[0] = self.graphs[0][0].pool()
+                while out is None and (req is None or req["stage"] != "draw"):
+                    with graph():
+                        if not first or self.model.device_rng:
+                            for fb, _, _ in tr.groups:
+                                fb.grads.zero_()
+                        try:
+                            req = next(gen)
+                        except StopIteration as done:
+                            out = done.value
+                        if out is not None:
+                            bgen = self._backward_until_cut(model._ctx, collective)
+                    if first and req is not None and req["stage"] == "anchor":
+                        self.g_anchor = self.graphs.pop()[0]
+                        pool[0] = self.g_anchor.pool()
+                    else:
+                        pool[0] = self.graphs[0][0].pool()
+                    first = False
                 if out is None:
                     # ---- graph 2: behind the draws: the rest of the forward, then the backward ----
-                    self.drawn = torch.zeros((self.req["layout"]["words"],), dtype=torch.int32, device=dev)
+                    self.req = dict(req, anchor_stream=self.side)
+                    self.drawn = torch.zeros((req["layout"]["words"],), dtype=torch.int32, device=dev)
                     with graph():
                         try:
                             gen.send(self.drawn)
-                            raise RuntimeError("the forward paused twice")
+                            raise RuntimeError("the forward paused more often than expected")
                         except StopIteration as done:
                             out = done.value
                         bgen = self._backward_until_cut(model._ctx, collective)
@@ -223,9 +252,15 @@ class GraphedTrainer:
                 s.copy_(t, non_blocking=True)
         works = []
         last = len(self.graphs) - 1
+        cur = torch.cuda.current_stream()
+        if self.g_anchor is not None:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.g_anchor.replay()
         for k, (g, buckets) in enumerate(self.graphs):
             if k == 1 and self.req is not None:
                 ops.upload_draws(ops.draw_targets_host(self.req), self.drawn.device, static=self.drawn)
+                cur.wait_stream(self.side)
             if k == last and self.collective:
                 for w in works:  # the SGD graph runs behind every bucket's sum
                     w.wait()

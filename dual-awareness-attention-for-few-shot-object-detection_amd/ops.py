@@ -4,9 +4,13 @@ PyTorch is used here only for device memory and streams: every function hands ra
 and the current HIP stream to a hand-written gfx950 kernel. Non-CUDA tensors are rejected -- there
 is no CPU fallback on the product path.
 """
+import time as _time
+
 import torch
 
 from ._lib import lib, DanaError  # noqa: F401
+
+HOST_WAIT = [0.0]  # seconds the host spent blocked in the training forward's one D2H read (bench.py / tools/hosttime.py)
 
 NCHW, NHWC = 0, 1
 EPI_RELU, CONV_STEM7 = 1, 2
@@ -393,14 +397,23 @@ def draw_layout(B, R, total):
 
 
 def draw_targets_host(req):
-    """req: dict(counts [2,B,2] device int32, B, R, fg_per, rpn_batchsize, num_fg, total) -> int32 numpy array in
-    draw_layout order, truncated after the last used pair. Blocks until the counts are on the host."""
+    """req: the forward's draw request (anchor / proposal counts [B,2] on the device, the stream the anchor half ran on,
+    B, R, fg_per, rpn_batchsize, num_fg, total) -> int32 numpy array in draw_layout order, truncated after the last used
+    pair. The anchor counts are final long before the proposals are: they are read behind THEIR stream only, and the
+    anchor layer's draws (the expensive ones: permutations over every bg anchor) run while the GPU still works on the
+    trunk; the proposal counts are the one read that waits for the caller's stream."""
     import numpy as np
     B, R = req["B"], req["R"]
     lay = draw_layout(B, R, req["total"])
-    cnt = req["counts"].cpu().numpy()  # host sync: np.random needs the counts
-    pairs, num_examples = anchor_target_draw(cnt[0], B, req["rpn_batchsize"], req["num_fg"])
-    picks, taken = proposal_target_draw(cnt[1], B, R, req["fg_per"])
+    t0 = _time.perf_counter()
+    with torch.cuda.stream(req["anchor_stream"]):
+        cnt_a = req["anchor_counts"].cpu().numpy()
+    HOST_WAIT[0] += _time.perf_counter() - t0  # (time the host spent BLOCKED on the GPU, for host-enqueue accounting)
+    pairs, num_examples = anchor_target_draw(cnt_a, B, req["rpn_batchsize"], req["num_fg"])
+    t0 = _time.perf_counter()
+    cnt_p = req["proposal_counts"].cpu().numpy()  # host sync: np.random needs the counts
+    HOST_WAIT[0] += _time.perf_counter() - t0
+    picks, taken = proposal_target_draw(cnt_p, B, R, req["fg_per"])
     n = int(pairs.shape[0])
     out = np.zeros((lay["pairs"] + 2 * n,), dtype=np.int32)
     out[0] = n
