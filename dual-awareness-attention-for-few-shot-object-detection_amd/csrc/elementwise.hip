@@ -315,6 +315,19 @@ transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, i
   }
 }
 
+// [cout][k0 + k1] weight of a two-segment contraction with both frozen-BN scales folded into the rows
+__global__ void pack_cat2_kernel(const float* __restrict__ w0, const float* __restrict__ s0, const float* __restrict__ b0,
+                                 int k0, const float* __restrict__ w1, const float* __restrict__ s1,
+                                 const float* __restrict__ b1, int k1, int cout, float* __restrict__ out,
+                                 float* __restrict__ shift, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int kk = k0 + k1;
+  const int n = (int)(i / kk), k = (int)(i - (long)n * kk);
+  out[i] = k < k0 ? s0[n] * w0[(long)n * k0 + k] : s1[n] * w1[(long)n * k1 + (k - k0)];
+  if (k == 0) shift[n] = b0[n] + b1[n];
+}
+
 // OIHW -> [O][KH][KW][I]
 __global__ void __launch_bounds__(256)
 pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int I, int KH, int KW, long total) {
@@ -554,6 +567,17 @@ int dana_pack_conv_weight(const float* w_oihw, float* out, int cout, int cin, in
     pack_weight_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, out, cin, kh, kw, total);
   }
   DANA_CHECK_LAUNCH("dana_pack_conv_weight");
+  return DANA_OK;
+}
+
+int dana_pack_cat2_weight(const float* w0, const float* s0, const float* b0, int k0, const float* w1, const float* s1,
+                          const float* b1, int k1, int cout, float* w_cat, float* shift, dana_stream_t stream) {
+  DANA_CHECK_ARG(k0 > 0 && k1 > 0 && cout > 0 && w0 && w1 && s0 && s1 && b0 && b1 && w_cat && shift,
+                 "dana_pack_cat2_weight: bad args");
+  const long total = (long)cout * (k0 + k1);
+  pack_cat2_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(w0, s0, b0, k0, w1, s1, b1, k1, cout, w_cat,
+                                                                          shift, total);
+  DANA_CHECK_LAUNCH("dana_pack_cat2_weight");
   return DANA_OK;
 }
 

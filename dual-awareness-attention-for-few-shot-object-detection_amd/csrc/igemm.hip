@@ -64,6 +64,13 @@ struct IgemmParams {
   int relu;
   int vec_io;  // C / residual rows are 16-byte aligned -> float4 epilogue
   int tiles_m, tiles_n;
+  // optional SECOND K segment (split kernel only): after K0 = Cin channels of A, the K walk continues through K1 channels
+  // of A2, a [batch][IH2][IW2] NHWC map sampled at (oh * stride2, ow * stride2) -- a bottleneck's 1x1 expand conv and
+  // its (strided) 1x1 downsample conv as ONE contraction over the concatenated channels (resnet.py:84-100)
+  const float* A2;
+  int lda2, IH2, IW2, stride2, K1;
+  unsigned a2_bytes;
+  unsigned long long* trace;  // debug (dana_set_igemm_trace): per block {start, first MFMA, loop end, end} in 100 MHz ticks + HW id
 };
 
 constexpr int BK = 32;
@@ -383,19 +390,20 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
+  const unsigned long long t_start = p.trace ? __builtin_readcyclecounter() : 0ull;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm_idx = tile / p.tiles_n, tn_idx = tile % p.tiles_n;
   const int m0 = tm_idx * BM, n0 = tn_idx * BN;
   const float* Ab = p.A + (long)blockIdx.z * p.batch_a;
   const float* Bb = p.Bw + (long)blockIdx.z * p.batch_b;
   float* Cb = p.C + (long)blockIdx.z * p.batch_c;
-  const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)p.b_bytes, 0x00020000);
 
   // The K walk is over "taps" of `cin_t` channels. Conv / GEMM: tap = filter tap (kh, kw), cin_t = Cin, and this
   // thread's float4 is channels c4*4.. of the pixel. 7x7 stem over NHWC4 (weights [cout][7][8][4], K = 224): a tap is
   // half a filter row -- four pixels x four channels = 16 k -- i.e. (kh, half), and the float4 is pixel kw = 4*half+c4.
-  const int cin_t = STEM ? SBK : p.Cin;
+  int cin_t = STEM ? SBK : p.Cin;
   const int kw_t = STEM ? 2 : p.KW;                // taps per filter row
   const int kh_t = STEM ? 7 : p.KH;
   const int lda4 = (STEM ? 4 : p.lda) * 4;          // bytes between pixels
@@ -407,6 +415,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   unsigned a_off[RA];   // byte offset of this lane's float4 at tap (0, 0), channel chunk 0
   unsigned a_mask[RA];  // bit t: tap t reads inside the image (and the row exists); <= 32 taps on this kernel
   int a_dseg[RA];       // bytes added per filter row on top of segment 0's row pitch (second geometry segment)
+  unsigned a_off2[RA];  // second K segment (A2): byte offset of this lane's float4 of the row's pixel, or OOB
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int m = m0 + r0 + 64 * j;
@@ -430,6 +439,8 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     a_off[j] = STEM ? (unsigned)((pix + iw0 + c4) * lda4) : (unsigned)((pix + iw0) * lda4 + c4 * 16);
     a_mask[j] = mask;
     a_dseg[j] = s1 ? (p.IW1 - p.IW) * lda4 : 0;
+    a_off2[j] = (!STEM && p.A2 && ok) ? (unsigned)((((long)img * p.IH2 + oh * p.stride2) * p.IW2 + ow * p.stride2) * p.lda2 * 4 + c4 * 16)
+                                     : OOB;
   }
   unsigned b_cur[RB];  // byte offset of this lane's float4 of the current K-step in its filter row
   int b_lim[RB];
@@ -457,6 +468,17 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   auto next_tap = [&]() {  // rare: the tap's channels are used up
     if (lt_cin >= cin_t) {
       lt_cin = 0;
+      if (!STEM && p.A2) {
+        // the second K segment: another tensor (own descriptor, own pixel map), K1 channels; nothing after it
+        ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes, 0x00020000);
+        cin_t = 0x7fffffff;  // (steps past K read nothing: k0 >= klim)
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+          a_cur[j] = a_off2[j];
+          a_lim[j] = a_off2[j] != OOB ? klim : DEAD;
+        }
+        return;
+      }
       lt_bit <<= 1;
       if (++lt_kw == kw_t) {
         lt_kw = 0;
@@ -641,10 +663,12 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   };
   // always whole pairs of K-steps (an odd count runs one extra all-zero step): no conditional between the two halves,
   // so the register sets swap roles without copies
+  const unsigned long long t_loop = p.trace ? __builtin_readcyclecounter() : 0ull;
   for (int t = 0; t < nk; t += 2) {
     k_step(t, fa0, fb0, fa1, fb1, ra0, rb0, ra1, rb1);
     k_step(t + 1, fa1, fb1, fa0, fb0, ra1, rb1, ra0, rb0);
   }
+  const unsigned long long t_loop_end = p.trace ? __builtin_readcyclecounter() : 0ull;
 
   // ---- epilogue through LDS (same C/D map as the f32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
   // The residual (and ReLU-adjoint mask) rows of the whole tile are requested BEFORE the accumulators go through LDS:
@@ -734,6 +758,15 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
         }
     }
   }
+  if (p.trace && tid == 0) {
+    unsigned long long* tr = p.trace + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 6;
+    tr[0] = t_start;
+    tr[1] = t_loop;
+    tr[2] = t_loop_end;
+    tr[3] = __builtin_readcyclecounter();
+    tr[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID | XCC_ID
+    tr[5] = wall_clock64();
+  }
 }
 
 // ---- skinny GEMM (N <= 8): one wave per output row, lanes split K (RCNN_bbox_pred 2048->4,
@@ -816,6 +849,7 @@ int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
 // granularity shortens the tail (a CU finishes ceil(tiles/256) tiles while the average is tiles/256).
 // DANA_IGEMM_TILE=1|2|3 forces 128x128 | 128x64 | 64x64 for tuning.
 int g_mfma_mode = -1;  // -1: read DANA_MFMA_SPLIT on first use
+unsigned long long* g_trace = nullptr;  // debug: per-block timestamps of the next split launches (dana_set_igemm_trace)
 
 int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   if (stem) {
@@ -831,6 +865,8 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   if (mode && p.KH * p.KW <= 32) {
     if (mode == 2) return launch_split<128, 64>(p, batch, s);
     if (mode == 3) return launch_split<64, 64>(p, batch, s);
+    if (mode == 4) return launch_split<128, 128>(p, batch, s);
+    if (mode == 5) return launch_split<64, 128>(p, batch, s);
     if (p.N <= 64) return launch_split<128, 64>(p, batch, s);
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     if (mode == 1 && t128 < 160) return launch_split<64, 64>(p, batch, s);
@@ -850,6 +886,7 @@ int run(IgemmParams& p, int batch, int stem, hipStream_t s) {
     p.IH1 = p.IH; p.IW1 = p.IW; p.OH1 = p.OH; p.OW1 = p.OW; p.pix1 = 0;
     p.C1 = p.C; p.ldc1 = p.ldc; p.residual1 = p.residual; p.ldr1 = p.ldr;
   }
+  p.trace = g_trace;
   p.vec_io = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (p.batch_c % 4 == 0) &&
              (!p.residual || ((p.ldr % 4 == 0) && (((uintptr_t)p.residual & 15) == 0))) &&
              (p.ldc1 % 4 == 0) && (((uintptr_t)p.C1 & 15) == 0) &&
@@ -862,8 +899,13 @@ int run(IgemmParams& p, int batch, int stem, hipStream_t s) {
 extern "C" {
 
 int dana_set_mfma_mode(int mode) {
-  DANA_CHECK_ARG(mode >= 0 && mode <= 4, "dana_set_mfma_mode: mode must be 0 (f32 MFMA) or 1 (bf16x6 split; 2-4: forced tiles)");
+  DANA_CHECK_ARG(mode >= 0 && mode <= 5, "dana_set_mfma_mode: mode must be 0 (f32 MFMA) or 1 (bf16x6 split; 2-5: forced tiles)");
   g_mfma_mode = mode;
+  return DANA_OK;
+}
+
+int dana_set_igemm_trace(unsigned long long* buffer) {
+  g_trace = buffer;
   return DANA_OK;
 }
 
@@ -986,6 +1028,64 @@ int dana_conv2d_nhwc_dual(const float* input, const float* weight, float* out0, 
   return conv2d_impl("dana_conv2d_nhwc_dual", input, weight, out0, out1, scale, shift, res0, res1, batch0, h0, w0,
                      batch1, h1, w1, cin, cout, kh, kw, stride, pad, in_pix_stride, out0_stride, out1_stride,
                      res0_stride, res1_stride, flags, stream);
+}
+
+int dana_conv1x1_cat2_nhwc(const float* a0, long a0_pix_stride, int k0, const float* a1, long a1_pix_stride, int k1,
+                           int batch, int h1, int w1, int stride1, const float* weight, float* output,
+                           const float* scale, const float* shift, const float* residual, long out_pix_stride,
+                           long res_pix_stride, int cout, int flags, dana_stream_t stream) {
+  const char* who = "dana_conv1x1_cat2_nhwc";
+  DANA_CHECK_ARG(batch >= 0 && h1 > 0 && w1 > 0 && stride1 > 0 && k0 > 0 && k1 > 0 && cout > 0, "%s: bad shape", who);
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(a0 && a1 && weight && output, "%s: null pointer", who);
+  DANA_CHECK_ARG(k0 % SBK == 0 && k1 % SBK == 0, "%s: k0 and k1 must be multiples of %d", who, SBK);
+  DANA_CHECK_ARG(dana_get_mfma_mode() != 0, "%s: needs the split kernel (dana_set_mfma_mode != 0)", who);
+  const int oh = (h1 - 1) / stride1 + 1, ow = (w1 - 1) / stride1 + 1;
+  const long lda0 = a0_pix_stride > 0 ? a0_pix_stride : k0, lda1 = a1_pix_stride > 0 ? a1_pix_stride : k1;
+  DANA_CHECK_ARG(lda0 % 4 == 0 && lda0 >= k0 && lda1 % 4 == 0 && lda1 >= k1, "%s: bad pixel stride", who);
+  const long a0_bytes = (long)batch * oh * ow * lda0 * 4, a1_bytes = (long)batch * h1 * w1 * lda1 * 4;
+  const long b_bytes = (long)cout * (k0 + k1) * 4;
+  DANA_CHECK_ARG(a0_bytes < (long)OOB && a1_bytes < (long)OOB && b_bytes < (long)OOB, "%s: operand spans >= 2 GiB", who);
+  DANA_CHECK_ARG(((uintptr_t)a0 & 15) == 0 && ((uintptr_t)a1 & 15) == 0 && ((uintptr_t)weight & 15) == 0,
+                 "%s: operands must be 16-byte aligned", who);
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = a0;
+  p.Bw = weight;
+  p.C = output;
+  p.scale = scale;
+  p.shift = shift;
+  p.residual = residual;
+  p.IH = p.OH = oh;
+  p.IW = p.OW = ow;
+  p.M = p.M0 = batch * oh * ow;
+  p.N = cout;
+  p.KH = p.KW = 1;
+  p.stride = 1;
+  p.pad = 0;
+  p.Cin = k0;
+  p.K = k0 + k1;
+  p.lda = (int)lda0;
+  p.ldb = p.K;
+  p.a_bytes = (unsigned)a0_bytes;
+  p.b_bytes = (unsigned)b_bytes;
+  p.A2 = a1;
+  p.lda2 = (int)lda1;
+  p.IH2 = h1;
+  p.IW2 = w1;
+  p.stride2 = stride1;
+  p.K1 = k1;
+  p.a2_bytes = (unsigned)a1_bytes;
+  p.ldc = out_pix_stride > 0 ? out_pix_stride : cout;
+  p.ldr = res_pix_stride > 0 ? res_pix_stride : cout;
+  p.ldc1 = p.ldc;
+  p.ldr1 = p.ldr;
+  p.alpha = 1.f;
+  p.relu = (flags & DANA_EPI_RELU) ? 1 : 0;
+  p.ldm = cout;
+  run(p, 1, 0, (hipStream_t)stream);
+  DANA_CHECK_LAUNCH(who);
+  return DANA_OK;
 }
 
 int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, const float* shift,

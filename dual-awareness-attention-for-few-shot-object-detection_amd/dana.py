@@ -168,6 +168,7 @@ class DAnARCNN(nn.Module):
         # are 4x the input instead of 2.25x)
         self.winograd_min_cin = int(__import__('os').environ.get('DANA_WINO_MIN_CIN',
                                                                  128 if self.winograd_tile == 4 else 256))
+        self.fuse_downsample = True  # first block of a layer: expand + downsample 1x1 convs as one contraction
         self.query_streams = 1
         self.query_sequential = False  # chunks of the query batch one after the other on the main stream
         # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
@@ -287,6 +288,16 @@ class DAnARCNN(nn.Module):
                  c3=self._conv_bn(blk.conv3, blk.bn3), ds=None)
         if blk.downsample is not None:
             d["ds"] = self._conv_bn(blk.downsample[0], blk.downsample[1])
+            # expand conv + downsample conv as ONE contraction over the concatenated channels (both BN scales folded
+            # into the weight rows): the downsample's [M][4*planes] output never goes through HBM
+            c3, ds = d["c3"], d["ds"]
+            sig = (c3["wsig"], c3["bsig"], ds["wsig"], ds["bsig"])
+            e = self._conv_cache.get(("cat", id(blk)))
+            if e is None or e["sig"] != sig:
+                w_cat, shift = ops.pack_cat2_weight(c3["w"], c3["scale"], c3["shift"], c3["cin"], ds["w"], ds["scale"],
+                                                    ds["shift"], ds["cin"], c3["cout"])
+                e = self._conv_cache[("cat", id(blk))] = dict(sig=sig, w=w_cat, shift=shift)
+            d["cat"] = e
         return d
 
     def _get_plan(self):
@@ -362,6 +373,14 @@ class DAnARCNN(nn.Module):
         """save: optional list; receives dict(x, o1, o2, o3, h1, w1, ...) for backward.bottleneck_backward"""
         o1, h1, w1 = self._conv(x, n, h, w, bp["c1"], True, in_stride=in_stride)
         o2, _, _ = self._conv(o1, n, h1, w1, bp["c2"], True)
+        if bp.get("cat") is not None and self.fuse_downsample and ops.get_mfma_mode() != 0:
+            c3, ds = bp["c3"], bp["ds"]
+            o3, _, _ = ops.conv1x1_cat2(o2, c3["cin"], x, ds["cin"], n, h, w, ds["stride"], bp["cat"]["w"],
+                                        bp["cat"]["shift"], c3["cout"], relu=True, a1_stride=in_stride, out=out,
+                                        out_stride=out_stride)
+            if save is not None:
+                save.append(dict(x=x, o1=o1, o2=o2, o3=o3, h1=h1, w1=w1, n=n, h=h, w=w, bp=bp, key=key, o3_ld=out_stride))
+            return o3, h1, w1
         if bp["ds"] is not None:
             res, _, _ = self._conv(x, n, h, w, bp["ds"], False, in_stride=in_stride)
             rs = 0

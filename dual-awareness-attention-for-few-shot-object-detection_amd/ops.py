@@ -580,6 +580,34 @@ def conv2d_nhwc_dual(x, n0, h0, w0, n1, h1, w1, cin, weight, cout, kh, kw, strid
     return out0, out1, (oh0, ow0), (oh1, ow1)
 
 
+def pack_cat2_weight(w0, s0, b0, k0, w1, s1, b1, k1, cout):
+    """-> (w_cat [cout][k0+k1] with the two frozen-BN scales folded into the rows, shift = b0 + b1)"""
+    w_cat = torch.empty((cout, k0 + k1), dtype=torch.float32, device=w0.device)
+    shift = torch.empty((cout,), dtype=torch.float32, device=w0.device)
+    lib().call("dana_pack_cat2_weight", _p(_chk(w0, "w0")), _p(s0), _p(b0), k0, _p(_chk(w1, "w1")), _p(s1), _p(b1), k1, cout,
+               _p(w_cat), _p(shift), _stream())
+    return w_cat, shift
+
+
+def conv1x1_cat2(a0, k0, a1, k1, batch, h1, w1, stride1, w_cat, shift, cout, relu=True, a0_stride=0, a1_stride=0,
+                 out=None, out_stride=0):
+    """relu(a0 . w_cat[:, :k0]^T + a1[strided pixels] . w_cat[:, k0:]^T + shift): a bottleneck's expand conv and its
+    downsample conv as one contraction (include/dana_hip.h: dana_conv1x1_cat2_nhwc). -> (out, oh, ow)"""
+    _chk(a0, "a0")
+    _chk(a1, "a1")
+    oh, ow = (h1 - 1) // stride1 + 1, (w1 - 1) // stride1 + 1
+    if out is None:
+        out = torch.empty((batch * oh * ow, cout), dtype=torch.float32, device=a0.device)
+        out_stride = cout
+    e0 = _prof_begin()
+    lib().call("dana_conv1x1_cat2_nhwc", _p(a0), a0_stride, k0, _p(a1), a1_stride, k1, batch, h1, w1, stride1, _p(w_cat),
+               _p(out), None, _p(shift), None, out_stride, 0, cout, EPI_RELU if relu else 0, _stream())
+    m = batch * oh * ow
+    _prof_end(e0, ("conv1x1cat M=%d N=%d K=%d s%d", (m, cout, k0 + k1, stride1)), 2.0 * m * cout * (k0 + k1),
+              4.0 * (m * (k0 + k1) + cout * (k0 + k1) + m * cout))
+    return out, oh, ow
+
+
 def winograd_filter_transform(w_packed, cout, cin, tile=2):
     """U of Winograd F(tile x tile, 3x3): [16][cout][cin] (tile 2) or [36][cout][cin] (tile 4)"""
     _chk(w_packed, "w_packed")

@@ -38,6 +38,10 @@ int dana_abi_version(void);
  * Replaces nothing in the reference: cuDNN picks its own algorithm / math mode there (lib/model/framework/resnet.py). */
 int dana_set_mfma_mode(int mode);
 int dana_get_mfma_mode(void);
+/* debug / profiling aid (tools/igemm_trace.py): while `buffer` is non-null every split-kernel block writes six 64-bit
+ * words {shader-clock at start, at the first K-step, after the K loop, at the end, HW_ID, 100 MHz wall clock} at
+ * buffer[(z * grid + block) * 6]. The caller sizes the buffer for the launches it traces; null switches it off. */
+int dana_set_igemm_trace(unsigned long long* buffer);
 
 /* ---- native operators: lib/model/csrc/vision.cpp:7-13 (module `model._C`) ------------------- */
 
@@ -426,6 +430,19 @@ int dana_proposal_target_sample(const int* counts, int B, int n_candidates, int 
 int dana_anchor_target_subsample(float* labels, const int* fg_list, const int* bg_list, const int* counts, int B,
                                  int anchors_per_image, int rpn_batchsize, int num_fg, unsigned long long seed,
                                  unsigned long long offset, float* inv_num_examples, dana_stream_t stream);
+/* One contraction over TWO concatenated channel segments: out[m][n] = epi(sum_{k<k0} a0[m][k] w[n][k] +
+ * sum_{k<k1} a1[pix1(m)][k] w[n][k0+k]) where a0 is an NHWC map on the OUTPUT grid [batch][oh][ow] (pixel stride
+ * a0_pix_stride) and a1 an NHWC map [batch][h1][w1] sampled at (oh*stride1, ow*stride1). This is a Caffe-ResNet
+ * bottleneck's 1x1 expand conv and its (strided) 1x1 downsample conv (resnet.py:84-100: out = relu(bn3(conv3(t)) +
+ * bn_d(downsample(x)))) with both frozen-BN scales folded into the weight rows [cout][k0 + k1] (dana_pack_cat2_weight)
+ * and the two shifts added: the downsample's output never goes through HBM. Split kernel only (dana_set_mfma_mode != 0). */
+int dana_conv1x1_cat2_nhwc(const float* a0, long a0_pix_stride, int k0, const float* a1, long a1_pix_stride, int k1,
+                           int batch, int h1, int w1, int stride1, const float* weight, float* output,
+                           const float* scale, const float* shift, const float* residual, long out_pix_stride,
+                           long res_pix_stride, int cout, int flags, dana_stream_t stream);
+/* w_cat[n][0:k0] = s0[n] * w0[n][:], w_cat[n][k0:] = s1[n] * w1[n][:], shift[n] = b0[n] + b1[n] (w0 / w1 packed [cout][k]) */
+int dana_pack_cat2_weight(const float* w0, const float* s0, const float* b0, int k0, const float* w1, const float* s1,
+                          const float* b1, int k1, int cout, float* w_cat, float* shift, dana_stream_t stream);
 /* hipGraph-friendly forms of the two samplers: the per-call Philox offset is `offset + counter_dev[0]`, with the call
  * counter living in device memory and advanced by dana_counter_add inside the same captured graph, so that every replay
  * draws fresh samples */

@@ -281,3 +281,31 @@ def test_contraction_error_vs_fp64_is_at_the_fp32_level(dev, mfma_mode, m, n, k,
     err_blas = (((a @ b.t()).double() - ref).abs() / mag).max().item()
     assert err <= 2.0 * err_blas + 2e-7, (err, err_blas)
     assert ops.get_mfma_mode() == mfma_mode
+
+
+@pytest.mark.parametrize("k0,k1,cout,stride,h,w", [(64, 64, 256, 1, 19, 23), (128, 256, 512, 2, 21, 30), (256, 512, 1024, 2, 11, 14)])
+def test_two_segment_contraction_is_expand_plus_downsample(dev, k0, k1, cout, stride, h, w):
+    """dana_conv1x1_cat2_nhwc (a bottleneck's 1x1 expand conv + its strided 1x1 downsample conv as one contraction over
+    the concatenated channels, BN scales folded into the weights) vs torch fp32 of resnet.py:84-100's tail"""
+    import torch.nn.functional as F
+    from dana_amd import ops
+    if ops.get_mfma_mode() == 0:
+        pytest.skip("the two-segment K walk lives in the split kernel; with dana_set_mfma_mode(0) the model runs the two "
+                    "convs separately")
+    torch.manual_seed(4)
+    n = 3
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    t = torch.randn(n, k0, oh, ow, device=dev)
+    x = torch.randn(n, k1, h, w, device=dev)
+    w3, wd = torch.randn(cout, k0, device=dev) * 0.05, torch.randn(cout, k1, device=dev) * 0.05
+    s3, b3 = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+    sd, bd = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+    ref = F.relu(F.conv2d(t, w3.view(cout, k0, 1, 1)) * s3.view(1, -1, 1, 1) + b3.view(1, -1, 1, 1) +
+                 F.conv2d(x, wd.view(cout, k1, 1, 1), stride=stride) * sd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1))
+    w_cat, shift = ops.pack_cat2_weight(w3, s3, b3, k0, wd, sd, bd, k1, cout)
+    t_nhwc = t.permute(0, 2, 3, 1).reshape(-1, k0).contiguous()
+    x_nhwc = x.permute(0, 2, 3, 1).reshape(-1, k1).contiguous()
+    out, oh2, ow2 = ops.conv1x1_cat2(t_nhwc, k0, x_nhwc, k1, n, h, w, stride, w_cat, shift, cout, relu=True)
+    assert (oh2, ow2) == (oh, ow)
+    got = out.view(n, oh, ow, cout).permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
