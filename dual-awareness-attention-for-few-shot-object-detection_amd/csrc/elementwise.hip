@@ -315,6 +315,41 @@ transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, i
   }
 }
 
+// out[m][n] = epi(alpha * sum_s partial[s][m][n]): the fixed-order reduction behind a split-K contraction
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ part, int S, long slab, int M, int N, float* __restrict__ out, long ldc,
+                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ residual,
+                     long ldr, float alpha, int relu) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the [M][N] result (N % 4 == 0)
+  const int n4 = N >> 2;
+  if (i >= (long)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+  float4 acc = *(const float4*)(part + (long)m * N + n);
+  for (int s = 1; s < S; ++s) {
+    const float4 v = *(const float4*)(part + s * slab + (long)m * N + n);
+    acc.x += v.x;
+    acc.y += v.y;
+    acc.z += v.z;
+    acc.w += v.w;
+  }
+  float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    r[q] = r[q] * alpha * (scale ? scale[n + q] : 1.f) + (shift ? shift[n + q] : 0.f);
+    if (residual) r[q] += residual[(long)m * ldr + n + q];
+    if (relu) r[q] = fmaxf(r[q], 0.f);
+  }
+  float* o = out + (long)m * ldc + n;
+  if ((ldc & 3) == 0 && (((uintptr_t)out) & 15) == 0) {
+    *(float4*)o = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    o[0] = r[0];
+    o[1] = r[1];
+    o[2] = r[2];
+    o[3] = r[3];
+  }
+}
+
 // [cout][k0 + k1] weight of a two-segment contraction with both frozen-BN scales folded into the rows
 __global__ void pack_cat2_kernel(const float* __restrict__ w0, const float* __restrict__ s0, const float* __restrict__ b0,
                                  int k0, const float* __restrict__ w1, const float* __restrict__ s1,
@@ -567,6 +602,20 @@ int dana_pack_conv_weight(const float* w_oihw, float* out, int cout, int cin, in
     pack_weight_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, out, cin, kh, kw, total);
   }
   DANA_CHECK_LAUNCH("dana_pack_conv_weight");
+  return DANA_OK;
+}
+
+int dana_splitk_reduce(const float* partials, int slices, int m, int n, float* out, long ldc, const float* scale,
+                       const float* shift, const float* residual, long ldr, float alpha, int flags,
+                       dana_stream_t stream) {
+  DANA_CHECK_ARG(slices > 0 && m >= 0 && n > 0 && n % 4 == 0 && ldc >= n, "dana_splitk_reduce: bad shape");
+  if (m == 0) return DANA_OK;
+  DANA_CHECK_ARG(partials && out && (((uintptr_t)partials) & 15) == 0, "dana_splitk_reduce: bad pointer");
+  const long total = (long)m * (n / 4);
+  splitk_reduce_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      partials, slices, (long)m * n, m, n, out, ldc, scale, shift, residual, ldr > 0 ? ldr : ldc, alpha,
+      (flags & DANA_EPI_RELU) ? 1 : 0);
+  DANA_CHECK_LAUNCH("dana_splitk_reduce");
   return DANA_OK;
 }
 

@@ -652,6 +652,23 @@ def get_mfma_mode():
     return lib().query("dana_get_mfma_mode")
 
 
+SPLIT_K = __import__("os").environ.get("DANA_SPLIT_K", "1") != "0"  # split-K for tile-starved GEMMs (few tiles, long K)
+
+
+def _splitk_slices(m, n, k, batch):
+    """how many K slices (1 = no split): only when the 64x64-tile grid leaves most of the 256 CUs' slots empty"""
+    if batch != 1 or n % 4 or n <= 8 or k < 512 or k % 16:
+        return 1
+    tiles = ((m + 63) // 64) * ((n + 63) // 64)
+    if tiles >= 512:
+        return 1
+    s = max(1, min(8, round(768.0 / tiles)))
+    steps = k // 16
+    while s > 1 and (steps % s or k // s < 256):
+        s -= 1
+    return s
+
+
 def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None, residual=None, ldr=0, batch=1,
             batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False, k_true=0):
     """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous."""
@@ -664,8 +681,19 @@ def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None
         ldc = n
         batch_c = m * n
     e0 = _prof_begin()
-    lib().call("dana_gemm_nt", _p(a), _p(b), _p(out), _p(scale), _p(shift), _p(residual), m, n, k, lda, ldb, ldc,
-               ldr, batch, batch_a, batch_b, batch_c, float(alpha), EPI_RELU if relu else 0, _stream())
+    slices = _splitk_slices(m, n, k, batch) if SPLIT_K else 1
+    if slices > 1:
+        # too few output tiles to fill the chip and a long K: the K range is cut into `slices` batched launches-in-one
+        # (blockIdx.z walks K) into fp32 slabs, summed in slice order with the epilogue by a second small kernel
+        kc = k // slices
+        part = torch.empty((slices, m, n), dtype=torch.float32, device=a.device)
+        lib().call("dana_gemm_nt", _p(a), _p(b), _p(part), None, None, None, m, n, kc, lda, ldb, n, 0, slices, kc, kc,
+                   m * n, 1.0, 0, _stream())
+        lib().call("dana_splitk_reduce", _p(part), slices, m, n, _p(out), ldc, _p(scale), _p(shift), _p(residual), ldr,
+                   float(alpha), EPI_RELU if relu else 0, _stream())
+    else:
+        lib().call("dana_gemm_nt", _p(a), _p(b), _p(out), _p(scale), _p(shift), _p(residual), m, n, k, lda, ldb, ldc,
+                   ldr, batch, batch_a, batch_b, batch_c, float(alpha), EPI_RELU if relu else 0, _stream())
     _prof_end(e0, ("gemm M=%d N=%d K=%d b%d", (m, n, k, batch)), 2.0 * batch * m * n * (k_true or k),
               4.0 * batch * (m * k + n * k + m * n * (2 if residual is not None else 1)))
     return out

@@ -440,6 +440,12 @@ int dana_conv1x1_cat2_nhwc(const float* a0, long a0_pix_stride, int k0, const fl
                            int batch, int h1, int w1, int stride1, const float* weight, float* output,
                            const float* scale, const float* shift, const float* residual, long out_pix_stride,
                            long res_pix_stride, int cout, int flags, dana_stream_t stream);
+/* Second half of a split-K contraction: out[m][n] = epi(alpha * sum_s partials[s][m][n]) with the same epilogue as
+ * dana_gemm_nt (scale, shift, residual, DANA_EPI_RELU), summed in slice order (deterministic). The slices themselves
+ * are one batched dana_gemm_nt launch whose batch strides walk K (batch_a = batch_b = K / slices). n % 4 == 0. */
+int dana_splitk_reduce(const float* partials, int slices, int m, int n, float* out, long ldc, const float* scale,
+                       const float* shift, const float* residual, long ldr, float alpha, int flags,
+                       dana_stream_t stream);
 /* w_cat[n][0:k0] = s0[n] * w0[n][:], w_cat[n][k0:] = s1[n] * w1[n][:], shift[n] = b0[n] + b1[n] (w0 / w1 packed [cout][k]) */
 int dana_pack_cat2_weight(const float* w0, const float* s0, const float* b0, int k0, const float* w1, const float* s1,
                           const float* b1, int k1, int cout, float* w_cat, float* shift, dana_stream_t stream);

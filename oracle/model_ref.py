@@ -505,6 +505,8 @@ def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_
         inter["rpn_cls_score"] = cls
         inter["rpn_bbox_pred"] = bbox
     rois = proposal_layer(prob.detach(), bbox.detach(), im_info, "TRAIN" if training else "TEST", nms_inclusive, inter)
+    if inter is not None:
+        inter["rpn_rois"] = rois.clone()
     rpn_loss_cls = rpn_loss_bbox = 0
     rois_label = None
     if training:

@@ -309,3 +309,26 @@ def test_two_segment_contraction_is_expand_plus_downsample(dev, k0, k1, cout, st
     assert (oh2, ow2) == (oh, ow)
     got = out.view(n, oh, ow, cout).permute(0, 3, 1, 2)
     assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("m,n,k", [(512, 1024, 3136), (1176, 256, 1024), (300, 72, 512)])
+def test_split_k_gemm_matches_single_chain_and_fp64(dev, m, n, k):
+    """tile-starved GEMMs run as K slices + a fixed-order reduction (ops._splitk_slices): same epilogue, same numbers up
+    to the fp32 summation order, deterministic run to run"""
+    from dana_amd import ops
+    torch.manual_seed(2)
+    a, b = torch.randn(m, k, device=dev), torch.randn(n, k, device=dev) * 0.05
+    sh, r = torch.randn(n, device=dev), torch.randn(m, n, device=dev)
+    assert ops._splitk_slices(m, n, k, 1) > 1
+    got = ops.gemm_nt(a, b, m, n, k, shift=sh, residual=r, ldr=n, relu=True)
+    again = ops.gemm_nt(a, b, m, n, k, shift=sh, residual=r, ldr=n, relu=True)
+    assert torch.equal(got, again)
+    ops.SPLIT_K = False
+    try:
+        one = ops.gemm_nt(a, b, m, n, k, shift=sh, residual=r, ldr=n, relu=True)
+    finally:
+        ops.SPLIT_K = True
+    ref = torch.relu(a.double() @ b.double().t() + sh.double() + r.double())
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * scale * (k ** 0.5)
+    assert float((got - one).abs().max()) <= 2e-6 * scale * (k ** 0.5)

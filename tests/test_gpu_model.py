@@ -256,18 +256,41 @@ def _train_vs_oracle(dev, B, way, shot, H, W, ba, wseed=11, iseed=1996, nseed=5,
     m.to(dev).train()
     inputs = S.episode_inputs(B, way, shot, H, W, seed=iseed)
     din = [t.to(dev) for t in inputs]
+    m._capture = {}
     np.random.seed(nseed)
     with torch.no_grad():
         out = m(*din)
+    ours_prop = m._capture["rpn_rois"].cpu().numpy()
+    m._capture = None
     np.random.seed(nseed)
     inter = {}
     with torch.no_grad():
         ref = O.forward(sd, *inputs, True, way, shot, ba, nms_inclusive=False, inter=inter)
-    r, rg = out[0].cpu().numpy().reshape(-1, 5), ref[0].numpy().reshape(-1, 5)
-    matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
-    assert matched.mean() >= min_match, "sampled rois diverge from the oracle: %.1f%% match" % (100 * matched.mean())
+    # (a) the proposal layer's output, matched by IoU (not by index: one flipped NMS decision shifts every later slot)
+    ref_prop = inter["rpn_rois"].numpy()
+    flip_free = []
+    for i in range(B):
+        a, b = ours_prop[i, :, 1:], ref_prop[i, :, 1:]
+        hit = np.array([(_iou(np.repeat(a[j:j + 1], len(b), 0), b) >= 1 - 1e-3).any() for j in range(0, len(a), 7)])
+        assert hit.mean() >= 0.99, "image %d: only %.1f%% of the proposals have a counterpart in the oracle's" % (i, 100 * hit.mean())
+        flip_free.append(bool((_iou(a, b) >= 1 - 1e-3).mean() >= 0.999))
+    # (b) the RPN losses depend on the anchor sampling only (exact inputs): always comparable
     assert abs(float(out[3]) - float(ref[3])) <= 1e-4 * max(1.0, abs(float(ref[3])))  # rpn_loss_cls
     assert abs(float(out[4]) - float(ref[4])) <= 1e-4 * max(1.0, abs(float(ref[4])))  # rpn_loss_bbox
+    # (c) this build's own sampling under the same np.random stream: identical picks wherever the candidate list is
+    # identical. (An image whose proposal list differs from the oracle's by ONE discrete decision -- a near-tie in the
+    # score sort or an IoU within an ulp of 0.7 -- has a shifted candidate list, hence a different random subset: that
+    # is not comparable position by position, and everything downstream of the sampling is asserted in (d) instead.)
+    R = out[0].size(1)
+    r, rg = out[0].cpu().numpy(), ref[0].numpy()
+    per_image = [float((_iou(r[i, :, 1:], rg[i, :, 1:]) >= 1 - 1e-3).mean()) for i in range(B)]
+    good = [v >= min_match for v in per_image]
+    for i in range(B):  # an image may only miss the bar if its proposal list really differs from the oracle's
+        assert good[i] or not flip_free[i], "image %d: same proposals, but only %.1f%% of the sampled rois match" % (
+            i, 100 * per_image[i])
+    assert sum(good) * 2 >= B, "sampled rois diverge from the oracle on most images: %s" % per_image
+    matched = np.array(per_image)
+    # (d) stage-wise and unconditional: the oracle's sampled batch goes into the RoI stages
     m._inject_sampled = inter["sampled"]
     np.random.seed(nseed)
     with torch.no_grad():
@@ -275,7 +298,7 @@ def _train_vs_oracle(dev, B, way, shot, H, W, ba, wseed=11, iseed=1996, nseed=5,
     m._inject_sampled = None
     assert np.array_equal(out2[0].cpu().numpy(), ref[0].numpy())
     _assert_train_outputs(out2, [t.numpy() if torch.is_tensor(t) else t for t in ref])
-    return float(matched.mean())
+    return float(matched.mean()), flip_free
 
 
 def test_train_forward_full_size_vs_oracle(dev):

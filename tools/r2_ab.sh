@@ -1,0 +1,14 @@
+#!/bin/bash
+# same-box A/B of the forward bench: bash tools/r2_ab.sh "VAR=0" ["VAR2=0" ...]  (each variant vs the default, interleaved twice)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r2ab
+mkdir -p $O
+cd $R
+run() { env $1 timeout 600 python bench.py --no-cpu-baseline --no-pmc --no-train-step --no-secondary --launch eager --steps 60 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); r=j['roofline']
+print('%-28s %7.1f img/s %6.3f ms  contraction %6.3f ms frac %.4f direct %.3f wino %.3f' % ('$1', j['value'], j['ms_per_step'], r['kernel_ms_per_step'], r['frac'], r['families']['direct']['ms_per_step'], r['families']['winograd']['ms_per_step']))"; }
+for rep in 1 2; do
+  run "DEFAULT=1"
+  for v in "$@"; do run "$v"; done
+done
