@@ -114,8 +114,14 @@ roi_align_fwd_nhwc(const float* __restrict__ in, const float* __restrict__ rois,
                    float* __restrict__ out2, const float* __restrict__ add2,
                    int C, int H, int W, int PH, int PW, float scale, int sr, long in_pix_stride,
                    long out_pix_stride, long out2_pix_stride) {
-  const int n = blockIdx.x;
-  const int bin = blockIdx.y;
+  // XCD-aware order (block b runs on XCD b % 8): each XCD gets a contiguous run of (roi, bin) pairs, so the 49 bins of
+  // a roi -- whose bilinear taps overlap -- and the rois of one image share ONE L2 instead of being dealt over all eight
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin % 8;
+  const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin / 8;
+  const int bins = PH * PW;
+  const int n = v / bins;
+  const int bin = v % bins;
   const int ph = bin / PW, pw = bin % PW;
   RoiGeom g = roi_geom(rois + (long)n * 5, scale, PH, PW, sr);
   const float* img = in + (long)g.batch * H * W * in_pix_stride;

@@ -169,7 +169,7 @@ class DAnARCNN(nn.Module):
         self.winograd_min_cin = int(__import__('os').environ.get('DANA_WINO_MIN_CIN',
                                                                  128 if self.winograd_tile == 4 else 256))
         self.fuse_downsample = __import__('os').environ.get('DANA_FUSE_DS', '1') != '0'  # first block of a layer: expand + downsample 1x1 convs as one contraction
-        self.query_streams = 1
+        self.query_streams = int(__import__('os').environ.get('DANA_QUERY_STREAMS', 1))
         self.query_sequential = False  # chunks of the query batch one after the other on the main stream
         # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
         # True: query + support batches share every trunk launch (dana_conv2d_nhwc_dual)
