@@ -140,3 +140,42 @@ def test_host_target_layers_match_the_oracle_on_cpu():
         assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
     ov = T.bbox_overlaps_batch(rois, gt)
     assert torch.equal(ov, O.bbox_overlaps_batch(rois, gt))
+
+
+def test_torch_ops_registration_of_the_five_C_operators():
+    """the reference's pybind `model._C` (vision.cpp:7-13) as PyTorch custom operators: csrc/torch_ops.cpp
+    registers them with TORCH_LIBRARY over the C ABI; dana_amd._C binds to them when the shim library is built"""
+    assert dana_amd._C.BINDING == "torch.ops.dana", dana_amd._C.BINDING
+    for name in ("nms", "roi_align_forward", "roi_align_backward", "roi_pool_forward", "roi_pool_backward", "roi_align",
+                 "roi_pool"):
+        assert hasattr(torch.ops.dana, name)
+    schema = str(torch.ops.dana.roi_align_forward.default._schema)
+    assert "Tensor input, Tensor rois, float spatial_scale, int pooled_height, int pooled_width, int sampling_ratio" in schema
+    # CPU tensors are refused with the reference's wording; empty input -> empty result without a launch (nms.h:17-18)
+    with pytest.raises(RuntimeError, match="Not compiled with CPU support"):
+        torch.ops.dana.roi_align_forward(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 1.0, 7, 7, 0)
+    with pytest.raises(RuntimeError, match="Not compiled with CPU support"):
+        dana_amd._C.roi_pool_forward(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 1.0, 7, 7)
+    assert dana_amd._C.nms(torch.zeros(0, 4), torch.zeros(0), 0.5).shape == (0,)
+
+
+def test_C_module_installs_as_the_reference_model_C():
+    """`sys.modules['model._C'] = dana_amd._C` is the whole binding a reference caller needs -- the
+    roi_layers wrappers of lib/model/roi_layers/*.py import `from model import _C` and call these five names"""
+    import sys
+    import types
+    stub = types.ModuleType("model")
+    stub._C = dana_amd._C
+    saved = {k: sys.modules.get(k) for k in ("model", "model._C")}
+    sys.modules["model"], sys.modules["model._C"] = stub, dana_amd._C
+    try:
+        ns = {}
+        exec("from model import _C\nnames = [_C.nms, _C.roi_align_forward, _C.roi_align_backward, _C.roi_pool_forward, "
+             "_C.roi_pool_backward]", ns)
+        assert all(callable(f) for f in ns["names"])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

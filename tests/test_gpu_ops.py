@@ -155,6 +155,42 @@ def test_roi_layers_autograd_wrappers(dev):
     assert keep.tolist() == [0, 2] and keep.dtype == torch.int64
 
 
+def test_torch_ops_dana_match_ctypes_binding_and_are_differentiable(dev):
+    """torch.ops.dana.* (csrc/torch_ops.cpp, TORCH_LIBRARY over the C ABI) vs the ctypes binding of the same entry points:
+    identical results; torch.ops.dana.roi_align / roi_pool back-propagate through their registered autograd formulas"""
+    import dana_amd
+    ops, orc = _ops(), _oracle()
+    assert dana_amd._C.BINDING == "torch.ops.dana"
+    rng = np.random.default_rng(17)
+    B, C, H, W, R = 2, 8, 20, 30, 16
+    feat = torch.from_numpy(rng.normal(size=(B, C, H, W)).astype(np.float32)).to(dev)
+    rois = np.zeros((R, 5), np.float32)
+    x1 = rng.uniform(0, 400, R); y1 = rng.uniform(0, 250, R)
+    rois[:, 0] = rng.integers(0, B, R)
+    rois[:, 1], rois[:, 2], rois[:, 3], rois[:, 4] = x1, y1, x1 + rng.uniform(8, 200, R), y1 + rng.uniform(8, 150, R)
+    r = torch.from_numpy(rois).to(dev)
+    a = torch.ops.dana.roi_align_forward(feat, r, 1 / 16., 7, 7, 0)
+    assert torch.equal(a, ops.roi_align_forward(feat, r, 1 / 16., 7, 7, 0))
+    p, arg = torch.ops.dana.roi_pool_forward(feat, r, 1 / 16., 7, 7)
+    p2, arg2 = ops.roi_pool_forward(feat, r, 1 / 16., 7, 7)
+    assert torch.equal(p, p2) and torch.equal(arg, arg2)
+    dets = torch.from_numpy(rng.uniform(0, 300, (400, 2)).astype(np.float32)).to(dev)
+    dets = torch.cat([dets, dets + torch.from_numpy(rng.uniform(20, 120, (400, 2)).astype(np.float32)).to(dev)], 1)
+    sc = torch.from_numpy(rng.permutation(400).astype(np.float32)).to(dev)
+    k1 = torch.ops.dana.nms(dets, sc, 0.5)
+    assert torch.equal(k1.cpu(), ops.nms(dets, sc, 0.5).cpu())
+    assert np.array_equal(k1.cpu().numpy(), orc.nms(dets.cpu().numpy(), sc.cpu().numpy(), 0.5, inclusive=False))
+    x = feat.clone().requires_grad_(True)
+    y = torch.ops.dana.roi_align(x, r, 1 / 16., 7, 7, 0)
+    g = torch.from_numpy(rng.normal(size=tuple(y.shape)).astype(np.float32)).to(dev)
+    y.backward(g)
+    ref = orc.roi_align_backward(g.cpu().numpy(), rois, 1 / 16., 7, 7, B, C, H, W, 0)
+    assert np.abs(x.grad.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+    x2 = feat.clone().requires_grad_(True)
+    torch.ops.dana.roi_pool(x2, r, 1 / 16., 7, 7).backward(g)
+    assert torch.equal(x2.grad, ops.roi_pool_backward(g, feat, r, arg, 1 / 16., 7, 7, B, C, H, W))
+
+
 def test_roi_pool_vs_oracle(dev):
     ops, orc = _ops(), _oracle()
     rng = np.random.default_rng(9)
