@@ -5,12 +5,14 @@
 // RoIAlign / RoIPool also get autograd formulas (what lib/model/roi_layers/roi_align.py:12-43 / roi_pool.py build with
 // torch.autograd.Function), so `torch.ops.dana.roi_align(input, rois, ...)` is differentiable w.r.t. `input`.
 //
+// (PyTorch's ROCm build keeps the device type "cuda": the guard / stream accessors are the *MasqueradingAsCUDA ones.)
+//
 // Errors follow the reference's contract: a failed dana_* call becomes a C++ exception -> Python
 // RuntimeError carrying dana_last_error(); CPU tensors raise ("Not compiled with CPU support": this build has no CPU
 // kernels); empty inputs give empty results without a launch (nms.h:17-18, ROIAlign_cuda.cu:278-281).
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
@@ -28,7 +30,7 @@ const at::Tensor& on_gpu(const at::Tensor& t, const char* name) {
 }
 
 dana_stream_t stream_of(const at::Tensor& t) {
-  return (dana_stream_t)c10::hip::getCurrentHIPStream(t.get_device()).stream();
+  return (dana_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream();
 }
 
 // nms.h:10-28: dets [N,4], scores [N] -> int64 kept ORIGINAL indices, ascending; IoU > threshold suppresses (nms.cu:60)
@@ -36,7 +38,7 @@ at::Tensor nms(const at::Tensor& dets, const at::Tensor& scores, double threshol
   if (dets.numel() == 0) return at::empty({0}, dets.options().dtype(at::kLong).device(at::kCPU));
   on_gpu(dets, "dets");
   on_gpu(scores, "scores");
-  c10::hip::HIPGuard guard(dets.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(dets.device());
   const auto d = dets.contiguous().to(at::kFloat), s = scores.contiguous().to(at::kFloat);
   const int n = (int)d.size(0);
   TORCH_CHECK(d.dim() == 2 && d.size(1) == 4 && s.numel() == n, "nms: dets [N,4], scores [N]");
@@ -61,7 +63,7 @@ at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, do
                              int64_t pooled_width, int64_t sampling_ratio) {
   on_gpu(input, "input");
   on_gpu(rois, "rois");
-  c10::hip::HIPGuard guard(input.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
   const auto in = input.contiguous(), r = rois.contiguous();
   TORCH_CHECK(in.dim() == 4 && r.dim() == 2 && r.size(1) == 5 && in.scalar_type() == at::kFloat, "roi_align_forward: bad args");
   const int B = (int)in.size(0), C = (int)in.size(1), H = (int)in.size(2), W = (int)in.size(3), R = (int)r.size(0);
@@ -78,7 +80,7 @@ at::Tensor roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, do
                               int64_t sampling_ratio) {
   on_gpu(grad, "grad");
   on_gpu(rois, "rois");
-  c10::hip::HIPGuard guard(grad.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(grad.device());
   const auto g = grad.contiguous(), r = rois.contiguous();
   auto gin = at::empty({batch_size, channels, height, width}, g.options());
   check(dana_roi_align_backward(g.data_ptr<float>(), r.data_ptr<float>(), gin.data_ptr<float>(), (int)batch_size,
@@ -92,7 +94,7 @@ std::tuple<at::Tensor, at::Tensor> roi_pool_forward(const at::Tensor& input, con
                                                     int64_t pooled_height, int64_t pooled_width) {
   on_gpu(input, "input");
   on_gpu(rois, "rois");
-  c10::hip::HIPGuard guard(input.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
   const auto in = input.contiguous(), r = rois.contiguous();
   const int B = (int)in.size(0), C = (int)in.size(1), H = (int)in.size(2), W = (int)in.size(3), R = (int)r.size(0);
   auto out = at::empty({R, C, pooled_height, pooled_width}, in.options());
@@ -108,7 +110,7 @@ at::Tensor roi_pool_backward(const at::Tensor& grad, const at::Tensor& input, co
                              const at::Tensor& argmax, double spatial_scale, int64_t pooled_height, int64_t pooled_width,
                              int64_t batch_size, int64_t channels, int64_t height, int64_t width) {
   on_gpu(grad, "grad");
-  c10::hip::HIPGuard guard(grad.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(grad.device());
   const auto g = grad.contiguous(), r = rois.contiguous(), a = argmax.contiguous();
   auto gin = at::empty({batch_size, channels, height, width}, g.options());
   check(dana_roi_pool_backward(g.data_ptr<float>(), a.data_ptr<int>(), r.data_ptr<float>(), gin.data_ptr<float>(),

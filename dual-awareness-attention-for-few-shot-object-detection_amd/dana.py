@@ -373,7 +373,7 @@ class DAnARCNN(nn.Module):
         """save: optional list; receives dict(x, o1, o2, o3, h1, w1, ...) for backward.bottleneck_backward"""
         o1, h1, w1 = self._conv(x, n, h, w, bp["c1"], True, in_stride=in_stride)
         o2, _, _ = self._conv(o1, n, h1, w1, bp["c2"], True)
-        if bp.get("cat") is not None and self.fuse_downsample and ops.get_mfma_mode() != 0:
+        if bp.get("cat") is not None and getattr(self, "fuse_downsample", True) and ops.get_mfma_mode() != 0:
             c3, ds = bp["c3"], bp["ds"]
             o3, _, _ = ops.conv1x1_cat2(o2, c3["cin"], x, ds["cin"], n, h, w, ds["stride"], bp["cat"]["w"],
                                         bp["cat"]["shift"], c3["cout"], relu=True, a1_stride=in_stride, out=out,

@@ -188,7 +188,8 @@ def test_torch_ops_dana_match_ctypes_binding_and_are_differentiable(dev):
     assert np.abs(x.grad.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
     x2 = feat.clone().requires_grad_(True)
     torch.ops.dana.roi_pool(x2, r, 1 / 16., 7, 7).backward(g)
-    assert torch.equal(x2.grad, ops.roi_pool_backward(g, feat, r, arg, 1 / 16., 7, 7, B, C, H, W))
+    ref_p = ops.roi_pool_backward(g, feat, r, arg, 1 / 16., 7, 7, B, C, H, W)  # (atomic scatter: order-dependent rounding)
+    assert float((x2.grad - ref_p).abs().max()) <= 2e-6 * float(ref_p.abs().max())
 
 
 def test_roi_pool_vs_oracle(dev):
