@@ -63,20 +63,56 @@ softmax_rows_kernel(float* __restrict__ x, long G, int L, long ld) {
   for (int l = lane; l < L; l += 64) r[l] = r[l] / s;
 }
 
-// BA block apply: S[g][l][d] += gamma * leaky_relu( sum_l w[g][l] * S[g][l][d] ); grid (D/256, G)
+// BA block apply: S[g][l][d] += gamma * leaky_relu( sum_l w[g][l] * S[g][l][d] )   (dana.py:133-137)
+// grid (D/64, G); 256 threads = 16 row groups x 16 float4 lanes: each row group sums every 16th row of its 64-channel
+// slab, the 16 partials are added in group order through LDS (a fixed order: deterministic), then every thread adds the
+// result back to its own rows. (Round 1 ran one thread per channel down all L rows: 48 workgroups, 84 us at L = 400.)
 __global__ void __launch_bounds__(256)
 ba_apply_kernel(float* __restrict__ S, const float* __restrict__ w, int L, int D, long ld, float gamma, float slope) {
-  extern __shared__ float ws[];
+  extern __shared__ float ws[];      // [L] weights | [16][64] partial sums
+  float* part = ws + ((L + 3) & ~3);
   const int g = blockIdx.y;
   for (int l = threadIdx.x; l < L; l += blockDim.x) ws[l] = w[(long)g * L + l];
   __syncthreads();
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int d = blockIdx.x * 64 + c4 * 4;
+  const bool ok = d + 3 < D;
   float* base = S + (long)g * L * ld + d;
-  float acc = 0.f;
-  for (int l = 0; l < L; ++l) acc += ws[l] * base[(long)l * ld];
-  const float add = gamma * (acc > 0.f ? acc : acc * slope);
-  for (int l = 0; l < L; ++l) base[(long)l * ld] += add;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok)
+    for (int l = rg; l < L; l += 16) {
+      const float4 v = *(const float4*)(base + (long)l * ld);
+      const float wl = ws[l];
+      acc.x += wl * v.x;
+      acc.y += wl * v.y;
+      acc.z += wl * v.z;
+      acc.w += wl * v.w;
+    }
+  *(float4*)(part + rg * 64 + c4 * 4) = acc;
+  __syncthreads();
+  float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float4 p = *(const float4*)(part + r * 64 + c4 * 4);
+    tot.x += p.x;
+    tot.y += p.y;
+    tot.z += p.z;
+    tot.w += p.w;
+  }
+  float4 add;
+  add.x = gamma * (tot.x > 0.f ? tot.x : tot.x * slope);
+  add.y = gamma * (tot.y > 0.f ? tot.y : tot.y * slope);
+  add.z = gamma * (tot.z > 0.f ? tot.z : tot.z * slope);
+  add.w = gamma * (tot.w > 0.f ? tot.w : tot.w * slope);
+  if (ok)
+    for (int l = rg; l < L; l += 16) {
+      float4 v = *(const float4*)(base + (long)l * ld);
+      v.x += add.x;
+      v.y += add.y;
+      v.z += add.z;
+      v.w += add.w;
+      *(float4*)(base + (long)l * ld) = v;
+    }
 }
 
 // scores[r][seg*L + l] <- (softmax_l(scores[r][seg*L .. +L)) + ugamma * unary[b(r)][seg][l]) * out_scale;
@@ -138,9 +174,10 @@ int dana_ba_apply(float* s, const float* w, int groups, int length, int dim, lon
   if (groups == 0) return DANA_OK;
   DANA_CHECK_ARG(s && w, "dana_ba_apply: null pointer");
   if (ld <= 0) ld = dim;
-  dim3 grid(dana_ceil_div(dim, 256), groups);
-  ba_apply_kernel<<<grid, 256, (size_t)length * sizeof(float), (hipStream_t)stream>>>(s, w, length, dim, ld, gamma,
-                                                                                     slope);
+  DANA_CHECK_ARG(dim % 4 == 0 && ld % 4 == 0 && ((uintptr_t)s & 15) == 0, "dana_ba_apply: dim, ld must be multiples of 4 (float4 rows)");
+  dim3 grid(dana_ceil_div(dim, 64), groups);
+  const size_t lds = (size_t)(((length + 3) & ~3) + 16 * 64) * sizeof(float);
+  ba_apply_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(s, w, length, dim, ld, gamma, slope);
   DANA_CHECK_LAUNCH("dana_ba_apply");
   return DANA_OK;
 }

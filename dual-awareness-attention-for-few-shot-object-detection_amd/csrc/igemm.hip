@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   const int li = lane & 31, lh = lane >> 5;
 
   const unsigned long long t_start = p.trace ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long w_start = p.trace ? wall_clock64() : 0ull;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm_idx = tile / p.tiles_n, tn_idx = tile % p.tiles_n;
   const int m0 = tm_idx * BM, n0 = tn_idx * BN;
@@ -759,13 +760,15 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     }
   }
   if (p.trace && tid == 0) {
-    unsigned long long* tr = p.trace + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 6;
+    unsigned long long* tr = p.trace + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 8;
     tr[0] = t_start;
     tr[1] = t_loop;
     tr[2] = t_loop_end;
     tr[3] = __builtin_readcyclecounter();
     tr[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID | XCC_ID
     tr[5] = wall_clock64();
+    tr[6] = w_start;
+    tr[7] = 0;
   }
 }
 

@@ -38,9 +38,9 @@ int dana_abi_version(void);
  * Replaces nothing in the reference: cuDNN picks its own algorithm / math mode there (lib/model/framework/resnet.py). */
 int dana_set_mfma_mode(int mode);
 int dana_get_mfma_mode(void);
-/* debug / profiling aid (tools/igemm_trace.py): while `buffer` is non-null every split-kernel block writes six 64-bit
- * words {shader-clock at start, at the first K-step, after the K loop, at the end, HW_ID, 100 MHz wall clock} at
- * buffer[(z * grid + block) * 6]. The caller sizes the buffer for the launches it traces; null switches it off. */
+/* debug / profiling aid (tools/igemm_trace.py, gemm_power.py): while `buffer` is non-null every split-kernel block writes
+ * eight 64-bit words {shader-clock at start, at the first K-step, after the K loop, at the end, HW_ID, 100 MHz wall clock
+ * at the end, wall clock at the start, 0} at buffer[(z * grid + block) * 8]. The caller sizes the buffer for the launches it traces; null switches it off. */
 int dana_set_igemm_trace(unsigned long long* buffer);
 
 /* ---- native operators: lib/model/csrc/vision.cpp:7-13 (module `model._C`) ------------------- */

@@ -120,17 +120,33 @@ def main():
             smp.stop = True
             smp.join()
             us = e0.elapsed_time(e1) * 1e3 / reps
+            ghz = float("nan")
+            if mode:  # effective shader clock of one more launch from the kernel's own per-block stamps
+                from dana_amd._lib import lib
+                tb = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+                lib().call("dana_set_igemm_trace", tb.data_ptr())
+                ops.gemm_nt(a, b, m, n, k, out=out, ldc=n)
+                torch.cuda.synchronize()
+                lib().call("dana_set_igemm_trace", None)
+                import numpy as np
+                tt = tb.cpu().numpy().astype(np.uint64).reshape(-1, 8)
+                tt = tt[tt[:, 3] > 0].astype(np.float64)
+                ghz = float(np.median((tt[:, 3] - tt[:, 0]) / np.maximum((tt[:, 5] - tt[:, 6]) * 10.0, 1.0)))
             tail = lambda v: sorted(v[len(v) // 3:])[len(v[len(v) // 3:]) // 2] if len(v) >= 3 else (v[-1] if v else float("nan"))  # noqa: E731
-            rows.append((name, "bf16x6 split" if mode else "f32 MFMA", us, 2.0 * m * n * k / us / 1e6, tail(smp.clk), tail(smp.pw),
-                         len(smp.clk), len(smp.pw)))
-            print("%-9s %-12s %8.1f us %6.1f TF/s  sclk %.0f MHz  power %.0f W  (%d / %d samples)" % rows[-1], flush=True)
+            rows.append((name, "bf16x6 split" if mode else "f32 MFMA", us, 2.0 * m * n * k / us / 1e6, ghz, tail(smp.clk),
+                         tail(smp.pw), len(smp.clk), len(smp.pw)))
+            print("%-9s %-12s %8.1f us %6.1f TF/s  in-kernel clock %.2f GHz  smi sclk %.0f MHz  power %.0f W  (%d / %d samples)" % rows[-1], flush=True)
     ops.set_mfma_mode(1)
     L = ["# Operand data vs clock / power / throughput of one large contraction (round 2)", "",
          "`python tools/gemm_power.py` on the GPU box: `dana_gemm_nt` M=16384 N=4096 K=4096, ~1 s of back-to-back launches per row,",
-         "shader clock and socket power sampled every 20 ms while they run (median of the last two thirds of the samples).", "",
-         "| operands | kernel | us / launch | algorithmic TFLOP/s | sclk (MHz) | power (W) | samples |", "|---|---|---|---|---|---|---|"]
+         "SMI shader clock and socket power sampled every 20 ms while they run (median of the last two thirds of the samples;",
+         "the SMI clock is an instantaneous register read and noisy). `in-kernel clock` = shader cycles (s_memtime) each block of one",
+         "more launch counted between its first and last instruction / the 100 MHz wall clock over the same span, median over the",
+         "blocks (dana_set_igemm_trace): the clock the CUs really ran at while the kernel executed (split kernel only).", "",
+         "| operands | kernel | us / launch | algorithmic TFLOP/s | in-kernel clock (GHz) | SMI sclk (MHz) | power (W) | samples |",
+         "|---|---|---|---|---|---|---|---|"]
     for r in rows:
-        L.append("| %s | %s | %.1f | %.1f | %.0f | %.0f | %d / %d |" % r)
+        L.append("| %s | %s | %.1f | %.1f | %.2f | %.0f | %.0f | %d / %d |" % r)
     text = "\n".join(L) + "\n"
     if len(sys.argv) > 1:
         with open(sys.argv[1], "w") as fh:

@@ -20,7 +20,7 @@ run = lambda: ops.conv2d_nhwc(x, n, h, w, ci, wt, co, k, k, st, k // 2, scale=sc
 for _ in range(5):
     run()
 torch.cuda.synchronize()
-buf = torch.zeros(8192 * 6, dtype=torch.int64, device=dev)
+buf = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 lib().call("dana_set_igemm_trace", buf.data_ptr())
 e0.record()
@@ -28,7 +28,7 @@ run()
 e1.record()
 torch.cuda.synchronize()
 lib().call("dana_set_igemm_trace", None)
-t = buf.cpu().numpy().astype(np.uint64).reshape(-1, 6)
+t = buf.cpu().numpy().astype(np.uint64).reshape(-1, 8)
 t = t[t[:, 3] > 0]
 nb = len(t)
 start, loop, loop_end, end, hw, wall = [t[:, i].astype(np.float64) for i in range(6)]
@@ -53,7 +53,10 @@ clk = np.median(tot) and (tot / 1.0)
 print("end wall-clock spread: last block ends %.1f us after the first; p10 %.1f p50 %.1f p90 %.1f us" % (
     wall_us.max(), np.percentile(wall_us, 10), np.median(wall_us), np.percentile(wall_us, 90)))
 # start times in the wall domain, assuming ~2.1 GHz for the conversion of the block's own duration
-for ghz in (2.1,):
+wstart = t[:, 6].astype(np.float64)
+ghz_meas = np.median(tot / np.maximum((wall - wstart) * 10.0, 1.0))  # cycles per ns
+print("effective shader clock during the launch: %.2f GHz (median over blocks: cycles / 100 MHz wall ticks)" % ghz_meas)
+for ghz in (ghz_meas,):
     start_us = wall_us - tot / (ghz * 1e3)
     s0 = start_us.min()
     print("block starts (wall, %.1f GHz assumed): p50 %.1f us p90 %.1f us max %.1f us after the first; kernel span %.1f us" % (
