@@ -525,8 +525,12 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     meta = type(model).__name__ == "MetaRCNN"
     plan, B, R, fh, fw = ctx["plan"], ctx["B"], ctx["R"], ctx["fh"], ctx["fw"]
     n_roi, hw = B * R, fh * fw
-    if isinstance(grad_losses, torch.Tensor):
-        g1, g2, g3, g4 = [float(x) for x in grad_losses.detach().cpu()]
+    g_dev = None
+    if isinstance(grad_losses, torch.Tensor):  # upstream gradients stay on the device: no host sync in the backward
+        g_dev = grad_losses.detach().to(torch.float32).contiguous()
+        g1 = g2 = g3 = g4 = 1.0
+        for seed, k in zip(ctx["loss_seeds"], (2, 2, 3) if meta else (2, 3)):  # (cls seeds..., bbox seed) x (g3, g4)
+            ops.scale_by_device_scalar_(seed, g_dev[k:])
     else:
         g1, g2, g3, g4 = [float(x) for x in grad_losses]
     fc7 = ctx["fc7"]
@@ -560,11 +564,8 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
                                     g_masked=i > 0)
         # 2x2 / 2 max pool (meta.py:247) back onto the support maps: the window's (first) maximum takes the gradient
         (sh_, sw_), (mh, mw) = ctx["sup_hw"], ctx["mp_hw"]
-        x = ctx["sup"].view(Ns, sh_, sw_, 1024).permute(0, 3, 1, 2).detach().requires_grad_(True)
-        with torch.enable_grad():
-            y = torch.nn.functional.max_pool2d(x, 2)
-        gs, = torch.autograd.grad(y, x, g.view(Ns, mh, mw, 1024).permute(0, 3, 1, 2))
-        gs = gs.permute(0, 2, 3, 1).contiguous().view(Ns * sh_ * sw_, 1024)
+        gs = ops.maxpool2x2s2_backward(ctx["sup"].view(Ns * sh_ * sw_, 1024), g.contiguous().view(Ns * mh * mw, 1024), Ns, sh_,
+                                       sw_, 1024)
     else:
         d_cls, d_bbox = ctx["loss_seeds"]  # d(loss_cls + loss_bbox) / d(cls_score, bbox_pred)
         C = d_cls.size(1)
@@ -588,7 +589,7 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     rpn = model.RCNN_rpn
     nh = ctx["nh"]
     d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
-                                    inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0])
+                                    inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0], grad_dev=g_dev)
     dwh, dbh, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512)
     ns = rpn.nc_score_out
     _acc(rpn.RPN_cls_score.weight, dwh[:ns])

@@ -87,6 +87,32 @@ maxpool2x2s2_kernel(const float4* __restrict__ in, float4* __restrict__ out, int
   }
 }
 
+// adjoint of nn.MaxPool2d(2): each window's gradient goes to its maximum -- the FIRST one in row-major window order on
+// ties, like torch's max_pool2d backward; rows / columns the floor-mode pooling never reads get 0. The argmax is
+// recomputed from the forward input.
+__global__ void __launch_bounds__(256)
+maxpool2x2s2_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout, float* __restrict__ gin, int H, int W,
+                        int OH, int OW, int C, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C);
+    const int x = (int)((i / C) % W);
+    const int y = (int)((i / C / W) % H);
+    const long b = i / C / W / H;
+    const int oh = y >> 1, ow = x >> 1;
+    float g = 0.f;
+    if (oh < OH && ow < OW) {
+      const float* p = in + ((b * H + oh * 2) * W + ow * 2) * C + c;
+      const float v[4] = {p[0], p[C], p[(long)W * C], p[(long)W * C + C]};
+      int arg = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k] > v[arg]) arg = k;
+      if (arg == (y & 1) * 2 + (x & 1)) g = gout[((b * OH + oh) * OW + ow) * C + c];
+    }
+    gin[i] = g;
+  }
+}
+
 // y = 1 / (1 + exp(-x)), in place (meta.py:202,250)
 __global__ void __launch_bounds__(256) sigmoid_kernel(float* __restrict__ x, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)blockDim.x * gridDim.x)
@@ -475,6 +501,18 @@ int dana_maxpool2x2s2_nhwc(const float* in, float* out, int batch, int height, i
   maxpool2x2s2_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)in, (float4*)out, height,
                                                                              width, oh, ow, channels / 4, total);
   DANA_CHECK_LAUNCH("dana_maxpool2x2s2_nhwc");
+  return DANA_OK;
+}
+
+int dana_maxpool2x2s2_backward_nhwc(const float* in, const float* grad_out, float* grad_in, int batch, int height,
+                                    int width, int channels, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && height >= 2 && width >= 2 && channels > 0, "dana_maxpool2x2s2_backward_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && grad_out && grad_in, "dana_maxpool2x2s2_backward_nhwc: null pointer");
+  const long total = (long)batch * height * width * channels;
+  maxpool2x2s2_bwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(in, grad_out, grad_in, height, width,
+                                                                                 height / 2, width / 2, channels, total);
+  DANA_CHECK_LAUNCH("dana_maxpool2x2s2_backward_nhwc");
   return DANA_OK;
 }
 

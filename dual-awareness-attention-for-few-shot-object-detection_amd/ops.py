@@ -770,6 +770,14 @@ def maxpool2x2s2(x, B, H, W, C):
     return out, H // 2, W // 2
 
 
+def maxpool2x2s2_backward(x, grad_out, B, H, W, C):
+    """adjoint of maxpool2x2s2 w.r.t. its input x [B*H*W][C]; grad_out [B*(H//2)*(W//2)][C]"""
+    gin = torch.empty((B * H * W, C), dtype=torch.float32, device=x.device)
+    lib().call("dana_maxpool2x2s2_backward_nhwc", _p(_chk(x, "x")), _p(_chk(grad_out, "grad_out")), _p(gin), B, H, W, C,
+               _stream())
+    return gin
+
+
 def sigmoid_(x):
     lib().call("dana_sigmoid", _p(_chk(x, "x")), x.numel(), _stream())
     return x

@@ -243,7 +243,73 @@ class Trainer:
             out["exp_avg_sq"] = {n: v.detach().clone().contiguous() for n, v in sq.items()}
         return out
 
+    def _trainable_names(self):
+        """the order train.py:76-85 builds its one-parameter groups in: named_parameters(), requires_grad only"""
+        return [n for n, p in self.model.named_parameters() if p.requires_grad]
+
+    def torch_optim_state_dict(self):
+        """the same state in torch.optim's format (`checkpoint['optimizer']` of train.py:181-189): index-keyed
+        `state[i]['momentum_buffer']` (SGD) or `exp_avg` / `exp_avg_sq` / `step` (Adam) and one param group per
+        parameter with its lr / weight decay, indices in the reference's parameter order"""
+        names = self._trainable_names()
+        mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
+        sq = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs2)]) if self.optimizer == "adam" else {}
+        mult = {n: (lr_mult, wd) for fb, lr_mult, wd in self.groups for n in fb.names}
+        state, groups = {}, []
+        for i, n in enumerate(names):
+            if self.optimizer == "adam":
+                state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": mom[n].detach().clone().contiguous(),
+                            "exp_avg_sq": sq[n].detach().clone().contiguous()}
+            else:
+                state[i] = {"momentum_buffer": mom[n].detach().clone().contiguous()}
+            g = {"params": [i], "lr": self.lr * mult[n][0], "weight_decay": mult[n][1]}
+            if self.optimizer == "sgd":
+                g["momentum"] = self.momentum
+            groups.append(g)
+        return {"state": state if self.steps else {}, "param_groups": groups}
+
     def load_state_dict(self, state):
+        """accepts this class's own `state_dict()` or a torch.optim SGD / Adam state_dict (the reference's
+        `checkpoint['optimizer']`, train.py:92-101): indices are mapped through the reference's parameter order, the
+        base learning rate is read from a weight's group (biases carry lr * (DOUBLE_BIAS + 1), train.py:79-84)"""
+        if "param_groups" in state:
+            names = self._trainable_names()
+            groups = state["param_groups"]
+            idx_of = {i: n for i, n in enumerate(names)}
+            if sum(len(g["params"]) for g in groups) != len(names):
+                raise ValueError("optimizer state has %d parameters, the model %d trainable ones"
+                                 % (sum(len(g["params"]) for g in groups), len(names)))
+            st = state.get("state", {})
+            is_adam = any("exp_avg" in v for v in st.values())
+            if st and is_adam != (self.optimizer == "adam"):
+                raise ValueError("checkpoint holds %s state, this trainer runs %s" % ("Adam" if is_adam else "SGD", self.optimizer))
+            mult = {n: lr_mult for fb, lr_mult, _ in self.groups for n in fb.names}
+            for g in groups:  # base lr from the first weight (non-bias) group
+                n = idx_of[g["params"][0]]
+                if "bias" not in n:
+                    self.lr = float(g["lr"]) / mult[n]
+                    if "momentum" in g:
+                        self.momentum = float(g["momentum"])
+                    break
+            mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
+            sq = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs2)]) if self.optimizer == "adam" else {}
+            steps = 0
+            for i, n in idx_of.items():
+                e = st.get(i, st.get(str(i)))
+                if e is None:
+                    mom[n].zero_()
+                    continue
+                if self.optimizer == "adam":
+                    mom[n].copy_(e["exp_avg"])
+                    sq[n].copy_(e["exp_avg_sq"])
+                    steps = max(steps, int(float(e.get("step", 0))))
+                elif e.get("momentum_buffer") is not None:
+                    mom[n].copy_(e["momentum_buffer"])
+                    steps = max(steps, 1)
+            self.steps = steps
+            return
+        if state.get("optimizer", self.optimizer) != self.optimizer:
+            raise ValueError("checkpoint holds %s state, this trainer runs %s" % (state.get("optimizer"), self.optimizer))
         self.lr, self.momentum, self.steps = float(state["lr"]), float(state["momentum"]), int(state["steps"])
         mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
         for n, v in mom.items():

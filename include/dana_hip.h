@@ -225,6 +225,9 @@ int dana_depthwise_corr_nhwc(const float* feat, const float* kernels, float* out
  * channel-wise product of the RoI features with their image's class-attentive vector (:136-140) */
 int dana_maxpool2x2s2_nhwc(const float* in, float* out, int batch, int height, int width, int channels,
                            dana_stream_t stream);
+/* adjoint of dana_maxpool2x2s2_nhwc: grad_in[b][y][x][c] = grad_out of the window whose (first) maximum the element is */
+int dana_maxpool2x2s2_backward_nhwc(const float* in, const float* grad_out, float* grad_in, int batch, int height,
+                                    int width, int channels, dana_stream_t stream);
 int dana_sigmoid(float* x, long n, dana_stream_t stream);
 int dana_scale_rows_by_group(const float* x, const float* group_vec, float* out, long rows, long rows_per_group,
                              int channels, dana_stream_t stream);
