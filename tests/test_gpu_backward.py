@@ -306,7 +306,8 @@ def test_trainer_resumes_from_a_torch_optim_checkpoint(dev):
     loss.backward()
     opt.step()
     ck_model = {k: v.detach().clone() for k, v in ma.state_dict().items()}
-    ck_opt = opt.state_dict()
+    import copy
+    ck_opt = copy.deepcopy(opt.state_dict())  # (state_dict() hands out references to the live momentum buffers)
     np.random.seed(2)
     out = ma(*inputs)
     loss = out[3].mean() + out[4].mean() + out[5].mean() + out[6].mean()
