@@ -4,8 +4,9 @@
   computes it (sample position (d + 0.5) * scale - 0.5 in double -> float, floor, clamp to [0, n - 1], horizontal
   pass then vertical pass in float32). cv2 is the reference's third-party dependency (opencv-python, unpinned in
   its requirements) and is NOT installed in this image: **parity unpinned against cv2 itself**; the restatement is
-  cross-checked against an independent implementation of the same sampling rule, torch's
-  F.interpolate(mode="bilinear", align_corners=False) (tests/test_oracle_golden.py).
+  checked against hand-computed known-answer vectors of OpenCV's documented sampling rule (pixel-centre convention,
+  edge clamps, pass order, fx / fy form) and cross-checked against an independent implementation of the same rule,
+  torch's F.interpolate(mode="bilinear", align_corners=False) (tests/test_oracle_golden.py).
 * `prep_im_for_blob`: lib/model/utils/blob.py:35-52 on top of it (RGB->BGR + flip as minibatch.py:76-81).
 * `support_crop`: roi_data_layer/fs_loader.py:118-139.
 * `crop_pad_chw`: fs_loader.py:186-280,318."""

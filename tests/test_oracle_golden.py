@@ -251,3 +251,37 @@ def test_roi_align_backward_oracle_is_the_adjoint_of_the_pinned_forward():
     y.backward(g)
     got = native.roi_align_backward(g.float().numpy(), rois.numpy(), 1 / 16., 7, 7, 2, 3, 20, 30, 0)
     assert np.abs(got - feat.grad.numpy()).max() <= 1e-6 * np.abs(got).max()
+
+
+def test_pipeline_resize_known_answer_vectors_of_cv2_inter_linear():
+    """cv2 is not installed in this image, so the resize restatement cannot be run against it; these are HAND-COMPUTED
+    known answers of cv2.resize(float32, interpolation=cv2.INTER_LINEAR) from OpenCV's documented sampling rule
+    (imgproc/resize.cpp: fx = (dx + 0.5) * scale - 0.5; sx = floor(fx); sx < 0 -> (0, weight 0); sx >= n - 1 ->
+    (n - 1, weight 0); dst = src[sx] * (1 - fx) + src[sx + 1] * fx, horizontal then vertical) on inputs whose results
+    are exactly representable -- they pin the pixel-centre convention, the edge clamps and the pass order, the
+    three things a restatement can get wrong; rounding inside one pass is not exercised."""
+    from oracle import pipeline_ref as P
+
+    def r(a, dsize=None, **kw):
+        a = np.asarray(a, np.float32)
+        return P.cv_resize_linear(a.reshape(a.shape[0], a.shape[1], 1), dsize=dsize, **kw)[:, :, 0]
+
+    # 1 x 2 -> 1 x 4 (scale 0.5): centres at -0.25, 0.25, 0.75, 1.25 -> clamp, 1/4, 3/4, clamp
+    assert np.array_equal(r([[0, 1]], dsize=(4, 1)), [[0, 0.25, 0.75, 1]])
+    # 1 x 4 -> 1 x 2 (scale 2): centres at 0.5, 2.5 -> midpoints of (0,1) and (2,3)
+    assert np.array_equal(r([[0, 1, 2, 3]], dsize=(2, 1)), [[0.5, 2.5]])
+    # 1 x 3 -> 1 x 6 (scale 0.5): -0.25, 0.25, 0.75, 1.25, 1.75, 2.25
+    assert np.array_equal(r([[0, 4, 8]], dsize=(6, 1)), [[0, 1, 3, 5, 7, 8]])
+    # 2 x 2 -> 4 x 4: separable, both axes as the first case
+    got = r([[0, 4], [8, 12]], dsize=(4, 4))
+    col = np.array([0, 0.25, 0.75, 1], np.float32)
+    assert np.array_equal(got, 8 * col[:, None] + 4 * col[None, :])
+    # fx / fy form (blob.py:50: cv2.resize(im, None, None, fx=s, fy=s)): dsize = round(src * f), scale = 1 / f
+    assert np.array_equal(r([[0, 2, 4, 6]], fx=0.5, fy=1.0), [[1, 5]])
+    assert r(np.zeros((3, 5)), fx=1.6, fy=2.0).shape == (6, 8)
+    # identity when the size does not change
+    a = np.arange(12, dtype=np.float32).reshape(3, 4)
+    assert np.array_equal(r(a, dsize=(4, 3)), a)
+    # 1 x 5 -> 1 x 3 (scale 5/3): centres 1/3, 2, 11/3 -> 1/3 between (0,1), exactly 2, 2/3 between (3,4)
+    got = r([[0, 3, 6, 9, 12]], dsize=(3, 1))
+    assert np.allclose(got, [[1.0, 6.0, 11.0]], atol=1e-5)
