@@ -523,7 +523,7 @@ def main():
         # HBM traffic and matrix-core busy cycles of the dominant kernel from PMC counters, measured NOW: nested
         # rocprofv3 --pmc passes over this very command (short, single-stream), one counter group per pass, corrected as
         # MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 64 B per 128-B request of wide reads: doubled).
-        pmc = None if args.no_pmc else pmc_passes(args, traffic_kernel)
+        pmc = None if (args.no_pmc or world > 1) else pmc_passes(args, traffic_kernel)  # (one process per box only)
         if pmc is not None:
             result["roofline"].update(pmc)
         else:
