@@ -11,7 +11,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "dana_hip.h")
-LIB_PATH = os.path.join(_HERE, "libdana_hip.so")
+LIB_PATH = os.environ.get("DANA_LIB_PATH") or os.path.join(_HERE, "libdana_hip.so")  # (override: same-box A/B of two builds)
 
 _CTYPES = {
     "int": ctypes.c_int,

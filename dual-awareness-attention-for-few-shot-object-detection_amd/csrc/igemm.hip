@@ -103,12 +103,18 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // XCD-aware order over the WHOLE grid (batch slices included): the hardware deals linear workgroup ids (x fastest,
+  // then z) round-robin to the 8 XCDs; the remap gives each XCD one contiguous run of (slice, tile) pairs, so that the
+  // tiles of one batch slice -- one Winograd plane, one image's attention matrix -- share an L2 instead of each XCD
+  // fetching its own copy of that slice's operands
+  const int vid = xcd_remap((int)(blockIdx.z * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.z));
+  const int zb = vid / (int)gridDim.x;
+  const int tile = vid - zb * (int)gridDim.x;
   const int tm_idx = tile / p.tiles_n, tn_idx = tile % p.tiles_n;
   const int m0 = tm_idx * BM, n0 = tn_idx * BN;
-  const float* Ab = p.A + (long)blockIdx.z * p.batch_a;
-  const float* Bb = p.Bw + (long)blockIdx.z * p.batch_b;
-  float* Cb = p.C + (long)blockIdx.z * p.batch_c;
+  const float* Ab = p.A + (long)zb * p.batch_a;
+  const float* Bb = p.Bw + (long)zb * p.batch_b;
+  float* Cb = p.C + (long)zb * p.batch_c;
   const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)p.b_bytes, 0x00020000);
 
@@ -392,12 +398,18 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
 
   const unsigned long long t_start = p.trace ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long w_start = p.trace ? wall_clock64() : 0ull;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // XCD-aware order over the WHOLE grid (batch slices included): the hardware deals linear workgroup ids (x fastest,
+  // then z) round-robin to the 8 XCDs; the remap gives each XCD one contiguous run of (slice, tile) pairs, so that the
+  // tiles of one batch slice -- one Winograd plane, one image's attention matrix -- share an L2 instead of each XCD
+  // fetching its own copy of that slice's operands
+  const int vid = xcd_remap((int)(blockIdx.z * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.z));
+  const int zb = vid / (int)gridDim.x;
+  const int tile = vid - zb * (int)gridDim.x;
   const int tm_idx = tile / p.tiles_n, tn_idx = tile % p.tiles_n;
   const int m0 = tm_idx * BM, n0 = tn_idx * BN;
-  const float* Ab = p.A + (long)blockIdx.z * p.batch_a;
-  const float* Bb = p.Bw + (long)blockIdx.z * p.batch_b;
-  float* Cb = p.C + (long)blockIdx.z * p.batch_c;
+  const float* Ab = p.A + (long)zb * p.batch_a;
+  const float* Bb = p.Bw + (long)zb * p.batch_b;
+  float* Cb = p.C + (long)zb * p.batch_c;
   __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)p.b_bytes, 0x00020000);
 
