@@ -193,7 +193,7 @@ def _block_convs(prefix, bp):
 def grad_stages(model):
     """[(stage, [parameter names])] in the order model_backward FINISHES the gradients: the trainer lays its flat
     gradient buffer out in this order so that all-reduce buckets can leave while the rest of the backward runs."""
-    if type(model).__name__ in ("FasterRCNN", "MetaRCNN"):
+    if type(model).__name__ in ("FasterRCNN", "MetaRCNN", "FGN"):
         return frcnn_grad_stages(model)
     plan = model._get_plan()
     lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
@@ -291,7 +291,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     RCNN_loss_cls, RCNN_loss_bbox) of the last `save_for_backward` forward: what train.py:141-143's
     `loss.backward()` computes, accumulated into `.grad` of the trainable parameters (BN, conv1 and layer1 are
     frozen: dana.py:350-385)."""
-    if type(model).__name__ in ("FasterRCNN", "MetaRCNN"):
+    if type(model).__name__ in ("FasterRCNN", "MetaRCNN", "FGN"):
         frcnn_backward(model, grad_losses, ctx=ctx)
         return
     ctx = _take_ctx(model, ctx)
@@ -504,7 +504,10 @@ def frcnn_grad_stages(model):
     plan = model._get_plan()
     lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
     cls = "RCNN_cls_score.0" if type(model).__name__ == "MetaRCNN" else "RCNN_cls_score"  # meta.py:199-201: a Sequential
-    st = [("roi head", lin("RCNN_bbox_pred") + lin(cls)
+    extra = []
+    if type(model).__name__ == "FGN":  # fgn.py:29-41: the relation head's two convs and their (trainable) BatchNorms
+        extra = ["cls_conv2.weight", "cls_conv1.weight"] + lin("bn2") + lin("bn1")
+    st = [("roi head", lin("RCNN_bbox_pred") + lin(cls) + extra
            + [n for bi in (2, 1, 0) for n in _block_convs("RCNN_top.0.%d" % bi, plan["layer4"][bi])])]
     st.append(("rpn", lin("RCNN_rpn.RPN_cls_score") + lin("RCNN_rpn.RPN_bbox_pred") + lin("RCNN_rpn.RPN_Conv")))
     for li in (2, 1):
@@ -523,13 +526,14 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     for the positive and the negative supports, so its support batch is differentiated through layer4 and the trunk too."""
     ctx = _take_ctx(model, ctx)
     meta = type(model).__name__ == "MetaRCNN"
+    fgn = type(model).__name__ == "FGN"
     plan, B, R, fh, fw = ctx["plan"], ctx["B"], ctx["R"], ctx["fh"], ctx["fw"]
     n_roi, hw = B * R, fh * fw
     g_dev = None
     if isinstance(grad_losses, torch.Tensor):  # upstream gradients stay on the device: no host sync in the backward
         g_dev = grad_losses.detach().to(torch.float32).contiguous()
         g1 = g2 = g3 = g4 = 1.0
-        for seed, k in zip(ctx["loss_seeds"], (2, 2, 3) if meta else (2, 3)):  # (cls seeds..., bbox seed) x (g3, g4)
+        for seed, k in zip(ctx["loss_seeds"], (2, 2, 3) if (meta or fgn) else (2, 3)):  # (cls seeds..., bbox seed) x (g3, g4)
             ops.scale_by_device_scalar_(seed, g_dev[k:])
     else:
         g1, g2, g3, g4 = [float(x) for x in grad_losses]
@@ -566,6 +570,58 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         (sh_, sw_), (mh, mw) = ctx["sup_hw"], ctx["mp_hw"]
         gs = ops.maxpool2x2s2_backward(ctx["sup"].view(Ns * sh_ * sw_, 1024), g.contiguous().view(Ns * mh * mw, 1024), Ns, sh_,
                                        sw_, 1024)
+    elif fgn:
+        # -- relation head (fgn.py:145-165): Linear <- ReLU/BN2 <- conv2 <- ReLU/BN1 <- (support half + roi half) of conv1;
+        #    bn1 / bn2 are ORDINARY BatchNorms in train mode: their adjoint goes through the batch statistics --
+        d_pos, d_neg, d_bbox = ctx["loss_seeds"]
+        Ns, shot, way, L = ctx["Ns"], ctx["shot"], ctx["way"], ctx["L"]
+        lin_c, wl = model.RCNN_cls_score, ctx["wl"]
+        d_fc7 = ops.gemm_small(d_bbox, (4, 1), model.RCNN_bbox_pred.weight.detach(), (2048, 1), n_roi, 2048, 4, alpha=g4)
+        for bn_ in (model.bn1, model.bn2):
+            for p_ in (bn_.weight, bn_.bias):
+                if p_.grad is None:
+                    p_.grad = torch.zeros_like(p_)
+        c2 = dict(cin=512, cout=128, k=3, stride=1, pad=0, w=ctx["w2"], scale=None, u=None)
+        d_roi_half = torch.zeros((n_roi * 25, 512), dtype=torch.float32, device=dev)
+        gs = torch.zeros((Ns * L, 1024), dtype=torch.float32, device=dev)  # d(support trunk output)
+        w1g = model.cls_conv1.weight
+
+        def acc_w1_half(packed, lo):  # packed [512][3*3*1024] -> cls_conv1.weight.grad[:, lo:lo+1024] (OIHW)
+            tmp = torch.empty((512, 1024, 3, 3), dtype=torch.float32, device=dev)
+            ops.unpack_conv_weight_grad(packed, tmp, 512, 1024, 3, 3, accumulate=False)
+            if w1g.grad is None:
+                w1g.grad = torch.zeros_like(w1g)
+            w1g.grad[:, lo:lo + 1024].add_(tmp)
+
+        def to_supports(d_map, offset):  # mean over the shots (fgn.py:57-60): every shot gets d_map / shot
+            for b_ in range(B):
+                for s_ in range(shot):
+                    ops.axpy_rows_(gs.view(-1)[(b_ * way * shot + offset + s_) * L * 1024:], d_map[b_], L, 1024,
+                                   alpha=1.0 / shot)
+
+        for hc in ctx["heads"]:
+            ds = d_pos if hc["offset"] == 0 else d_neg
+            dwl = ops.gemm_small(ds, (1, 2), hc["x2"], (1152, 1), 2, 1152, n_roi, alpha=g3)   # [2][(h,w,c)]
+            _acc(lin_c.weight, dwl.view(2, 9, 128).permute(0, 2, 1).reshape(2, 1152))            # -> the NCHW flatten (c,h,w)
+            _acc(lin_c.bias, ops.colsum(ds, n_roi, 2, alpha=g3))
+            d_x2 = ops.gemm_small(ds, (2, 1), wl, (1152, 1), n_roi, 1152, 2, alpha=g3).view(n_roi * 9, 128)
+            ops.relu_mask_(d_x2, hc["x2"], n_roi * 9, 128)
+            x2_pre, m2, v2 = hc["bn2"]
+            d_x2pre = ops.bn_train_backward(d_x2, x2_pre, m2, v2, model.bn2.weight, model.bn2.eps, n_roi * 9, 128,
+                                            model.bn2.weight.grad, model.bn2.bias.grad)
+            grads.add_conv("cls_conv2", d_x2pre, hc["x1"], n_roi, 5, 5, c2)
+            d_x1 = conv_dgrad(d_x2pre, n_roi, 5, 5, c2, mask=hc["x1"])  # (+ the ReLU adjoint of bn1's output)
+            x1_pre, m1, v1 = hc["bn1"]
+            d_x1pre = ops.bn_train_backward(d_x1, x1_pre, m1, v1, model.bn1.weight, model.bn1.eps, n_roi * 25, 512,
+                                            model.bn1.weight.grad, model.bn1.bias.grad)
+            ops.axpy_rows_(d_roi_half, d_x1pre, n_roi * 25, 512)
+            d_s_half = ops.spatial_mean(d_x1pre, B, R, 25 * 512)  # broadcast over the image's R rois: sum = R * mean
+            d_s_half.mul_(float(R))
+            acc_w1_half(ops.conv2d_wgrad(d_s_half, hc["support"], B, 7, 7, 1024, 512, 3, 3, 1, 0), 0)
+            d_support = ops.conv2d_dgrad(d_s_half, ctx["w1_sup"], B, 7, 7, 1024, 512, 3, 3, 1, 0)   # [B*49][1024]
+            to_supports(ops.avgpool_backward(d_support, B, 20, 20, 1024, 14, 1), hc["offset"])          # AvgPool2d(14, 1)
+        acc_w1_half(ops.conv2d_wgrad(d_roi_half, ctx["pooled"], n_roi, 7, 7, 1024, 512, 3, 3, 1, 0), 1024)
+        d_pooled_head = ops.conv2d_dgrad(d_roi_half, ctx["w1_roi"], n_roi, 7, 7, 1024, 512, 3, 3, 1, 0)  # [n*49][1024]
     else:
         d_cls, d_bbox = ctx["loss_seeds"]  # d(loss_cls + loss_bbox) / d(cls_score, bbox_pred)
         C = d_cls.size(1)
@@ -582,6 +638,9 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"], mask_dx=i < len(l4) - 1,
                                 g_masked=i > 0)
     grads.finish_all(model, "RCNN_top")
+    if fgn:
+        grads.finish_all(model, "cls_conv2")
+        ops.axpy_rows_(g, d_pooled_head, n_roi * 49, 1024)  # the pooled features also feed the relation head's roi half
     _ready(model, stages[0][1])
     d_bf = ops.roi_align_backward(g.view(n_roi, 7, 7, 1024), ctx["rois"].view(-1, 5), 1.0 / 16.0, 7, 7, B, 1024, fh, fw,
                                   0, layout=ops.NHWC).view(B * hw, 1024)
@@ -600,7 +659,16 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None, u=plan["rpn_conv_u"])
     grads.add_conv("RCNN_rpn.RPN_Conv", d_x, ctx["rpn_feat"], B, fh, fw, c_rpn)
     _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
-    gq = conv_dgrad(d_x, B, fh, fw, c_rpn, residual=d_bf)  # d base_feat = RPN path + RoIAlign path
+    if fgn:
+        # the RPN ran on base_feat * pos_rpn[image] (fgn.py:75-82): d base = d rfeat * pos_rpn + RoIAlign path, and
+        # d pos_rpn[image] = sum over the pixels of d rfeat * base -> AvgPool2d(20) -> the positive supports' mean map
+        d_rfeat = conv_dgrad(d_x, B, fh, fw, c_rpn)
+        gq = ops.scale_rows_by_group(d_rfeat, ctx["pos_rpn"], B * hw, hw, 1024)
+        ops.axpy_rows_(gq, d_bf, B * hw, 1024)
+        d_pos_rpn = (d_rfeat * ctx["base"]).view(B, hw, 1024).sum(1).contiguous()
+        to_supports(ops.broadcast_rows(d_pos_rpn, B, ctx["L"], 1024, alpha=1.0 / ctx["L"]).view(B, ctx["L"], 1024), 0)
+    else:
+        gq = conv_dgrad(d_x, B, fh, fw, c_rpn, residual=d_bf)  # d base_feat = RPN path + RoIAlign path
     grads.finish_all(model, "RCNN_rpn")
     _ready(model, stages[1][1])
     qs, ss = ctx["q_saved"], ctx.get("s_saved") or []

@@ -341,6 +341,43 @@ transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, i
   }
 }
 
+// Adjoint of a TRAIN-mode BatchNorm (batch statistics; fgn.py:147-153's bn1 / bn2): with xhat = (x - mean) * istd,
+//   dgamma = sum dy * xhat,  dbeta = sum dy,  dx = gamma * istd * (dy - dbeta / R - xhat * dgamma / R).
+// One workgroup per 64 channels; 4 row lanes walk the rows, their partial sums are added in lane order (deterministic).
+__global__ void __launch_bounds__(256)
+bn_train_backward_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                         const float* __restrict__ var, const float* __restrict__ gamma, float eps, long rows, int C,
+                         float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool ok = c < C;
+  const float mu = ok ? mean[c] : 0.f;
+  const float istd = ok ? 1.0f / sqrtf(var[c] + eps) : 0.f;
+  float a1 = 0.f, a2 = 0.f;
+  if (ok)
+    for (long r = rl; r < rows; r += 4) {
+      const float g = dy[r * C + c];
+      a1 += g;
+      a2 += g * ((x[r * C + c] - mu) * istd);
+    }
+  s1[rl][cl] = a1;
+  s2[rl][cl] = a2;
+  __syncthreads();
+  const float t1 = ((s1[0][cl] + s1[1][cl]) + s1[2][cl]) + s1[3][cl];
+  const float t2 = ((s2[0][cl] + s2[1][cl]) + s2[2][cl]) + s2[3][cl];
+  if (!ok) return;
+  if (rl == 0) {
+    dgamma[c] = accumulate ? dgamma[c] + t2 : t2;
+    dbeta[c] = accumulate ? dbeta[c] + t1 : t1;
+  }
+  const float k = gamma[c] * istd, m1 = t1 / (float)rows, m2 = t2 / (float)rows;
+  for (long r = rl; r < rows; r += 4) {
+    const float xh = (x[r * C + c] - mu) * istd;
+    dx[r * C + c] = k * (dy[r * C + c] - m1 - xh * m2);
+  }
+}
+
 // out[m][n] = epi(alpha * sum_s partial[s][m][n]): the fixed-order reduction behind a split-K contraction
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ part, int S, long slab, int M, int N, float* __restrict__ out, long ldc,
@@ -640,6 +677,18 @@ int dana_pack_conv_weight(const float* w_oihw, float* out, int cout, int cin, in
     pack_weight_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, out, cin, kh, kw, total);
   }
   DANA_CHECK_LAUNCH("dana_pack_conv_weight");
+  return DANA_OK;
+}
+
+int dana_bn_train_backward(const float* grad_out, const float* x, const float* mean, const float* var_biased,
+                           const float* gamma, float eps, long rows, int channels, float* grad_x, float* grad_gamma,
+                           float* grad_beta, int accumulate, dana_stream_t stream) {
+  DANA_CHECK_ARG(rows > 0 && channels > 0, "dana_bn_train_backward: bad shape");
+  DANA_CHECK_ARG(grad_out && x && mean && var_biased && gamma && grad_x && grad_gamma && grad_beta,
+                 "dana_bn_train_backward: null pointer");
+  bn_train_backward_kernel<<<dana_ceil_div(channels, 64), 256, 0, (hipStream_t)stream>>>(
+      grad_out, x, mean, var_biased, gamma, eps, rows, channels, grad_x, grad_gamma, grad_beta, accumulate);
+  DANA_CHECK_LAUNCH("dana_bn_train_backward");
   return DANA_OK;
 }
 

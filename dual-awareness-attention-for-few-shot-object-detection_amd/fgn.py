@@ -7,11 +7,14 @@ operators.
   (512->128) -> BatchNorm -> ReLU -> Linear(1152, 2). The concatenation never exists (the support half of the first conv
   is computed once per image and added as a residual). bn1 / bn2 are ORDINARY BatchNorm layers, unlike the trunk's:
   batch statistics and running-statistics updates in train mode (`dana_batch_stats`), running statistics in eval mode.
-Same parameter tree as the reference class. Forward only."""
+Same parameter tree as the reference class. Trainable: backward.frcnn_backward's `fgn` branch (train-mode BatchNorm
+adjoints, the split first conv, the channel re-weighting of the RPN input, the support trunk)."""
 import torch
 import torch.nn as nn
 
 from . import ops
+from .config import cfg
+from .dana import _LossBridge
 from .frcnn import FasterRCNN
 
 
@@ -36,11 +39,14 @@ class FGN(FasterRCNN):
         from .dana import DAnARCNN
         DAnARCNN._init_weights(self)
 
-    def _bn(self, x, rows, bn):
-        """nn.BatchNorm2d on NHWC rows, in place, followed by ReLU: batch statistics + running update when bn.training"""
+    def _bn(self, x, rows, bn, save=None):
+        """nn.BatchNorm2d on NHWC rows, in place, followed by ReLU: batch statistics + running update when bn.training.
+        save: list that receives (pre-BN copy of x, batch mean, batch var) for the backward"""
         C = bn.num_features
         if bn.training:
             mean, var = ops.batch_stats(x, rows, C)
+            if save is not None:
+                save.append((x.clone(), mean, var))
             with torch.no_grad():  # F.batch_norm's running update: momentum 0.1, UNBIASED variance
                 bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
                 bn.running_var.mul_(1 - bn.momentum).add_(var, alpha=bn.momentum * rows / max(rows - 1, 1))
@@ -61,7 +67,14 @@ class FGN(FasterRCNN):
         Ns = sup_ims.size(0)
         if Ns != B * way * shot:
             raise RuntimeError("support_ims must hold batch*way*shot = %d images, got %d" % (B * way * shot, Ns))
-        sup, sh_, sw_ = self._rcnn_base(sup_ims, plan)  # [Ns*400][1024]
+        ctx = None
+        bridge = training and torch.is_grad_enabled()
+        if training and (bridge or getattr(self, "save_for_backward", False)):
+            if cfg.POOLING_MODE != "align":
+                raise NotImplementedError("the HIP backward of fgn covers POOLING_MODE 'align'")
+            ctx = dict(q_saved=[], l4_saved=[], s_saved=[], heads=[])
+        self._ctx = None
+        sup, sh_, sw_ = self._rcnn_base(sup_ims, plan, save=ctx["s_saved"] if ctx is not None else None)  # [Ns*400][1024]
         if (sh_, sw_) != (20, 20):
             raise RuntimeError("support images must be 320x320 (fgn.py:34-35: AvgPool2d(20) / AvgPool2d(14, 1) of a 20x20 map)")
         L = sh_ * sw_
@@ -77,9 +90,11 @@ class FGN(FasterRCNN):
         pos_rcnn = ops.avgpool(pos_map, B, sh_, sw_, 1024, 14, 1)  # AvgPool2d(14, 1): [B][49][1024]
 
         def attention_rpn_input(base, B_, fh, fw, plan_):
+            if ctx is not None:
+                ctx["base"] = base
             return ops.scale_rows_by_group(base, pos_rpn, B_ * fh * fw, fh * fw, 1024), fh, fw
 
-        st = self._stages(im_data, im_info, gt_boxes, rpn_input=attention_rpn_input)
+        st = self._stages(im_data, im_info, gt_boxes, rpn_input=attention_rpn_input, ctx=ctx)
         R, n_roi, pooled, fc7 = st["R"], st["n_roi"], st["pooled"], st["fc7"]
         wb, bb = self._w(self.RCNN_bbox_pred)
         bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
@@ -92,25 +107,38 @@ class FGN(FasterRCNN):
         bl = self.RCNN_cls_score.bias.detach().contiguous()
         roi_half, _, _ = ops.conv2d_nhwc(pooled, n_roi, 7, 7, 1024, w1_roi, 512, 3, 3, 1, 0)  # [n*25][512], shared
 
-        def head(support):  # support [B][49][1024]
+        def head(support, offset):  # support [B][49][1024]
+            saved = [] if ctx is not None else None
             s_half, _, _ = ops.conv2d_nhwc(support, B, 7, 7, 1024, w1_sup, 512, 3, 3, 1, 0)  # [B*25][512]
             x = ops.broadcast_rows(s_half, B, R, 25 * 512)                                      # [n*25][512]
             ops.axpy_rows_(x, roi_half, n_roi * 25, 512)
-            x = self._bn(x, n_roi * 25, self.bn1)
-            x, _, _ = ops.conv2d_nhwc(x, n_roi, 5, 5, 512, w2, 128, 3, 3, 1, 0)                 # [n*9][128]
-            x = self._bn(x, n_roi * 9, self.bn2)
-            score = ops.gemm_nt(x, wl, n_roi, 2, 1152, shift=bl)
+            x1 = self._bn(x, n_roi * 25, self.bn1, save=saved)
+            x, _, _ = ops.conv2d_nhwc(x1, n_roi, 5, 5, 512, w2, 128, 3, 3, 1, 0)                # [n*9][128]
+            x2 = self._bn(x, n_roi * 9, self.bn2, save=saved)
+            score = ops.gemm_nt(x2, wl, n_roi, 2, 1152, shift=bl)
+            if ctx is not None:
+                ctx["heads"].append(dict(offset=offset, support=support, x1=x1, x2=x2, bn1=saved[0], bn2=saved[1]))
             return ops.softmax_rows_(score.clone(), n_roi, 2), score
 
-        cls_prob, cls_score = head(pos_rcnn)
+        cls_prob, cls_score = head(pos_rcnn, 0)
         RCNN_loss_cls = RCNN_loss_bbox = 0
         rois_label = st["rois_label"]
         if training:
-            neg_prob, neg_score = head(ops.avgpool(mean_map(shot), B, sh_, sw_, 1024, 14, 1))
+            neg_prob, neg_score = head(ops.avgpool(mean_map(shot), B, sh_, sw_, 1024, 14, 1), shot)
             cls_prob = torch.cat([cls_prob, neg_prob], 0)
             rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
-            rl, _ = ops.rcnn_losses(cls_score, neg_score, st["labels_f"], bbox_pred, st["rois_target"].contiguous(),
-                                    st["rois_inside_ws"].contiguous(), st["rois_outside_ws"].contiguous())
+            rl, seeds = ops.rcnn_losses(cls_score, neg_score, st["labels_f"], bbox_pred, st["rois_target"].contiguous(),
+                                        st["rois_inside_ws"].contiguous(), st["rois_outside_ws"].contiguous(),
+                                        with_grad=ctx is not None)
             RCNN_loss_cls, RCNN_loss_bbox = rl[0], rl[1]
-        return (st["rois"], cls_prob, bbox_pred, st["rpn_loss_cls"], st["rpn_loss_bbox"], RCNN_loss_cls, RCNN_loss_bbox,
-                rois_label)
+        rpn_loss_cls, rpn_loss_bbox = st["rpn_loss_cls"], st["rpn_loss_bbox"]
+        if ctx is not None:
+            ctx.update(loss_seeds=seeds, sup=sup, Ns=Ns, shot=shot, way=way, L=L, pos_rpn=pos_rpn, pooled=pooled,
+                       w1_sup=w1_sup, w1_roi=w1_roi, w2=w2, wl=wl)
+            self._ctx = ctx
+            if bridge:  # loss.backward() (train.py:141-143) runs backward.frcnn_backward (fgn branch) on the HIP kernels
+                if self._grad_anchor is None or self._grad_anchor.device != dev:
+                    self._grad_anchor = torch.zeros(1, device=dev, requires_grad=True)
+                rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox = _LossBridge.apply(
+                    self._grad_anchor, self, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox)
+        return (st["rois"], cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, RCNN_loss_bbox, rois_label)

@@ -757,6 +757,15 @@ def batch_stats(x, rows, channels, ld=0):
     return mean, var
 
 
+def bn_train_backward(grad_out, x, mean, var, gamma, eps, rows, channels, grad_gamma, grad_beta):
+    """adjoint of a train-mode BatchNorm on NHWC rows; dgamma / dbeta are ACCUMULATED into grad_gamma / grad_beta -> grad_x"""
+    gx = torch.empty((rows, channels), dtype=torch.float32, device=x.device)
+    lib().call("dana_bn_train_backward", _p(_chk(grad_out, "grad_out")), _p(_chk(x, "x")), _p(mean), _p(var),
+               _p(_chk(gamma.detach().contiguous(), "gamma")), float(eps), rows, channels, _p(gx), _p(grad_gamma),
+               _p(grad_beta), 1, _stream())
+    return gx
+
+
 def scale_shift_relu_(x, scale, shift, rows, channels, relu=True):
     lib().call("dana_scale_shift_relu", _p(_chk(x, "x")), _p(_chk(scale, "scale")), _p(_chk(shift, "shift")), rows,
                channels, int(bool(relu)), _stream())

@@ -215,6 +215,12 @@ int dana_batch_stats(const float* x, float* mean, float* var_biased, long rows, 
                      size_t workspace_bytes, dana_stream_t stream);
 int dana_scale_shift_relu(float* x, const float* scale, const float* shift, long rows, int channels, int relu,
                           dana_stream_t stream);
+/* adjoint of a TRAIN-mode nn.BatchNorm2d over NHWC rows (batch statistics mean / var_biased of x, as dana_batch_stats
+ * returns them): grad_x = gamma / sqrt(var + eps) * (g - mean(g) - xhat * mean(g * xhat)), grad_gamma (+)= sum g * xhat,
+ * grad_beta (+)= sum g (fgn.py:147-153: the head's bn1 / bn2 are ordinary, trainable BatchNorm layers) */
+int dana_bn_train_backward(const float* grad_out, const float* x, const float* mean, const float* var_biased,
+                           const float* gamma, float eps, long rows, int channels, float* grad_x, float* grad_gamma,
+                           float* grad_beta, int accumulate, dana_stream_t stream);
 /* sibling model `fsod` (framework/fsod.py:109-116, 207-214): depth-wise "valid" cross-correlation
  * F.conv2d(feat, kernel.view(C, 1, kh, kw), groups=C): out[n][oh][ow][c] = sum feat[n][oh+i][ow+j][c] *
  * kernels[n / maps_per_kernel][i][j][c]; feat [n_maps][height][width][feat_pix_stride], out [n_maps][oh][ow][channels] */

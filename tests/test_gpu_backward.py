@@ -127,6 +127,8 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba, mfma_mode):
     weights = (1.0, 0.5, 2.0, 1.5)
 
     def trainable(k):
+        if k in ("bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias"):
+            return True  # fgn's head BatchNorms are ordinary, trainable layers (fgn.py:31-36)
         if "bn" in k or "downsample.1" in k or "running_" in k or "num_batches" in k:
             return False
         return not (k.startswith("RCNN_base.0") or k.startswith("RCNN_base.1") or k.startswith("RCNN_base.4"))
@@ -385,10 +387,10 @@ def test_trainer_adam_matches_torch_adam(dev):
         assert frac <= 2e-3 and diff.mean().item() <= 2e-3 * lr, (k, frac, diff.max().item(), diff.mean().item())
 
 
-@pytest.mark.parametrize("name", ["frcnn", "meta"])
+@pytest.mark.parametrize("name", ["frcnn", "meta", "fgn"])
 def test_sibling_backward_vs_oracle_autograd_and_trainer_step(dev, mfma_mode, name):
-    """row N4 widened: the plain Faster R-CNN (utils.py:109-110) and the Meta R-CNN (utils.py:113-114) siblings train on
-    the HIP kernels too. Every trainable parameter's gradient vs autograd through the oracle's forward of that model
+    """row N4 widened: the plain Faster R-CNN (utils.py:109-110), the Meta R-CNN (utils.py:113-114) and the FGN
+    (utils.py:115-116: train-mode BatchNorm head) siblings train on the HIP kernels too. Every trainable parameter's gradient vs autograd through the oracle's forward of that model
     (same sampled rois), then one Trainer.step through the reference's `loss.backward()` contract."""
     import dana_amd
     from dana_amd import synthetic as S, backward as BW
@@ -403,17 +405,23 @@ def test_sibling_backward_vs_oracle_autograd_and_trainer_step(dev, mfma_mode, na
     weights = (1.0, 0.5, 2.0, 1.5)
 
     def trainable(k):
+        if k in ("bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias"):
+            return True  # fgn's head BatchNorms are ordinary, trainable layers (fgn.py:31-36)
         if "bn" in k or "downsample.1" in k or "running_" in k or "num_batches" in k:
             return False
         return not (k.startswith("RCNN_base.0") or k.startswith("RCNN_base.1") or k.startswith("RCNN_base.4"))
 
     def episode(seed):
         e = S.episode_inputs(B, way, shot, H, W, seed=seed)
+        if name == "fgn":
+            return list(e)
         return e[:4] if name == "frcnn" else list(e) + [e[2].clone()]  # meta.py:39,48: all_cls_gt_boxes
 
     def oracle(state, inputs, **kw):
         if name == "frcnn":
             return O.frcnn_forward(state, *inputs, training=True, nms_inclusive=True, **kw)
+        if name == "fgn":
+            return O.fgn_forward(state, *inputs, training=True, n_way=way, n_shot=shot, nms_inclusive=True, **kw)
         return O.meta_forward(state, *inputs, training=True, n_way=way, n_shot=shot, nms_inclusive=True, **kw)
 
     m.save_for_backward = True
