@@ -193,7 +193,7 @@ def _block_convs(prefix, bp):
 def grad_stages(model):
     """[(stage, [parameter names])] in the order model_backward FINISHES the gradients: the trainer lays its flat
     gradient buffer out in this order so that all-reduce buckets can leave while the rest of the backward runs."""
-    if type(model).__name__ in ("FasterRCNN", "MetaRCNN", "FGN"):
+    if type(model).__name__ in ("FasterRCNN", "MetaRCNN", "FGN", "FSOD"):
         return frcnn_grad_stages(model)
     plan = model._get_plan()
     lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
@@ -291,7 +291,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     RCNN_loss_cls, RCNN_loss_bbox) of the last `save_for_backward` forward: what train.py:141-143's
     `loss.backward()` computes, accumulated into `.grad` of the trainable parameters (BN, conv1 and layer1 are
     frozen: dana.py:350-385)."""
-    if type(model).__name__ in ("FasterRCNN", "MetaRCNN", "FGN"):
+    if type(model).__name__ in ("FasterRCNN", "MetaRCNN", "FGN", "FSOD"):
         frcnn_backward(model, grad_losses, ctx=ctx)
         return
     ctx = _take_ctx(model, ctx)
@@ -505,6 +505,18 @@ def frcnn_grad_stages(model):
     lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
     cls = "RCNN_cls_score.0" if type(model).__name__ == "MetaRCNN" else "RCNN_cls_score"  # meta.py:199-201: a Sequential
     extra = []
+    if type(model).__name__ == "FSOD":  # fsod.py:29-75: the three relation heads replace RCNN_cls_score
+        st = [("roi head", lin("RCNN_bbox_pred") + lin("global_fc_1") + lin("global_fc_2") + lin("global_cls_score")
+               + ["corr_conv.weight"] + lin("corr_cls_score") + ["patch_conv_1.weight", "patch_conv_2.weight",
+                                                                 "patch_conv_3.weight"] + lin("patch_cls_score")
+               + [n for bi in (2, 1, 0) for n in _block_convs("RCNN_top.0.%d" % bi, plan["layer4"][bi])])]
+        st.append(("rpn", lin("RCNN_rpn.RPN_cls_score") + lin("RCNN_rpn.RPN_bbox_pred") + lin("RCNN_rpn.RPN_Conv")))
+        for li in (2, 1):
+            layer = plan["layers"][li]
+            for bi in reversed(range(len(layer))):
+                key = "RCNN_base.%d.%d" % (4 + li, bi)
+                st.append((key, _block_convs(key, layer[bi])))
+        return st
     if type(model).__name__ == "FGN":  # fgn.py:29-41: the relation head's two convs and their (trainable) BatchNorms
         extra = ["cls_conv2.weight", "cls_conv1.weight"] + lin("bn2") + lin("bn1")
     st = [("roi head", lin("RCNN_bbox_pred") + lin(cls) + extra
@@ -527,13 +539,14 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     ctx = _take_ctx(model, ctx)
     meta = type(model).__name__ == "MetaRCNN"
     fgn = type(model).__name__ == "FGN"
+    fsod = type(model).__name__ == "FSOD"
     plan, B, R, fh, fw = ctx["plan"], ctx["B"], ctx["R"], ctx["fh"], ctx["fw"]
     n_roi, hw = B * R, fh * fw
     g_dev = None
     if isinstance(grad_losses, torch.Tensor):  # upstream gradients stay on the device: no host sync in the backward
         g_dev = grad_losses.detach().to(torch.float32).contiguous()
         g1 = g2 = g3 = g4 = 1.0
-        for seed, k in zip(ctx["loss_seeds"], (2, 2, 3) if (meta or fgn) else (2, 3)):  # (cls seeds..., bbox seed) x (g3, g4)
+        for seed, k in zip(ctx["loss_seeds"], (2, 2, 3) if (meta or fgn or fsod) else (2, 3)):  # (cls seeds..., bbox seed) x (g3, g4)
             ops.scale_by_device_scalar_(seed, g_dev[k:])
     else:
         g1, g2, g3, g4 = [float(x) for x in grad_losses]
@@ -570,6 +583,102 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         (sh_, sw_), (mh, mw) = ctx["sup_hw"], ctx["mp_hw"]
         gs = ops.maxpool2x2s2_backward(ctx["sup"].view(Ns * sh_ * sw_, 1024), g.contiguous().view(Ns * mh * mw, 1024), Ns, sh_,
                                        sw_, 1024)
+    elif fsod:
+        # -- multi-relation head (fsod.py:181-249): score = (global + local-correlation + patch) / 10 for the positive
+        #    and the negative support; every [roi | support] concatenation is a split layer (roi half + support half) --
+        d_pos, d_neg, d_bbox = ctx["loss_seeds"]
+        Ns, shot, way, L = ctx["Ns"], ctx["shot"], ctx["way"], ctx["L"]
+        P2, d, dq_ = 49, 1024, 256
+        pooled, g_roi, corr_roi = ctx["pooled"], ctx["g_roi"], ctx["corr_roi"]
+        d_fc7 = ops.gemm_small(d_bbox, (4, 1), model.RCNN_bbox_pred.weight.detach(), (2048, 1), n_roi, 2048, 4, alpha=g4)
+        w1 = model.global_fc_1.weight.detach()
+        w2 = model.global_fc_2.weight.detach()
+        wg = model.global_cls_score.weight.detach()
+        wcc = model.corr_conv.weight.detach().view(d, d).contiguous()
+        wcs = model.corr_cls_score.weight.detach()
+        wp1 = model.patch_conv_1.weight.detach().view(dq_, 2 * d).contiguous()
+        wp3 = model.patch_conv_3.weight.detach().view(d, dq_).contiguous()
+        wps = model.patch_cls_score.weight.detach()
+        c_p2 = dict(cin=dq_, cout=dq_, k=3, stride=1, pad=0, w=ctx["wp2"], scale=None, u=None)
+        d_pooled_head = torch.zeros((n_roi * P2, d), dtype=torch.float32, device=dev)
+        d_g_roi = torch.zeros((n_roi, d), dtype=torch.float32, device=dev)
+        d_corr_roi = torch.zeros((n_roi * P2, d), dtype=torch.float32, device=dev)
+        gs = torch.zeros((Ns * L, 1024), dtype=torch.float32, device=dev)  # d(support trunk output)
+        d_w1 = torch.zeros((d, 2 * d), dtype=torch.float32, device=dev)
+        d_wp1 = torch.zeros((dq_, 2 * d), dtype=torch.float32, device=dev)
+        d_wcc = torch.zeros((d, d), dtype=torch.float32, device=dev)
+        d_pos_kernel = None  # d(pooled positive support) from the attention RPN, added below
+
+        def to_supports(d_map, offset):  # mean over the shots (fsod.py:98-101): every shot gets d_map / shot
+            for b_ in range(B):
+                for s_ in range(shot):
+                    ops.axpy_rows_(gs.view(-1)[(b_ * way * shot + offset + s_) * L * 1024:], d_map[b_], L, 1024,
+                                   alpha=1.0 / shot)
+
+        d_supports = {}
+        for hc in ctx["heads"]:
+            ds = (d_pos if hc["offset"] == 0 else d_neg)
+            a3 = g3 / 10.0  # fsod.py:237: the three scores are summed and divided by 10
+            support = hc["support"]
+            d_support = torch.zeros((B * P2, d), dtype=torch.float32, device=dev)
+            # .. global relation: Linear(2) <- relu fc2 <- relu fc1([mean(roi) | mean(support)])
+            _acc(model.global_cls_score.weight, ops.gemm_small(ds, (1, 2), hc["h2"], (d, 1), 2, d, n_roi, alpha=a3))
+            _acc(model.global_cls_score.bias, ops.colsum(ds, n_roi, 2, alpha=a3))
+            d_h2 = ops.gemm_small(ds, (2, 1), wg, (d, 1), n_roi, d, 2, alpha=a3)
+            ops.relu_mask_(d_h2, hc["h2"], n_roi, d)
+            dw2, db2, d_h1 = ops.linear_backward(d_h2, hc["h1"], w2, n_roi, d, d)
+            _acc(model.global_fc_2.weight, dw2)
+            _acc(model.global_fc_2.bias, db2)
+            ops.relu_mask_(d_h1, hc["h1"], n_roi, d)
+            dw1r, db1, _ = ops.linear_backward(d_h1, g_roi, w1, n_roi, d, d, ldw=2 * d, dx_out=d_g_roi, dx_ld=d)
+            ops.axpy_rows_(d_w1, dw1r, d, d, ld_y=2 * d)
+            _acc(model.global_fc_1.bias, db1)
+            d_gs = ops.spatial_mean(d_h1, B, R, d)  # the support half was broadcast over the image's R rois
+            d_gs.mul_(float(R))
+            dw1s = ops.gemm_small(d_gs, (1, d), hc["m_sup"], (d, 1), d, d, B)            # [d][d] = d_gs^T . mean(support)
+            ops.axpy_rows_(d_w1.view(-1)[d:], dw1s, d, d, ld_y=2 * d)
+            d_m_sup = ops.gemm_small(d_gs, (d, 1), w1.view(-1)[d:], (2 * d, 1), B, d, d)  # [B][d] = d_gs . w1[:, d:]
+            ops.broadcast_rows(d_m_sup, B, P2, d, alpha=1.0 / P2, out=d_support)
+            # .. local correlation: Linear(2) <- sum over the 49 positions of corr_conv(roi) * corr_conv(support)
+            _acc(model.corr_cls_score.weight, ops.gemm_small(ds, (1, 2), hc["oc"], (d, 1), 2, d, n_roi, alpha=a3))
+            _acc(model.corr_cls_score.bias, ops.colsum(ds, n_roi, 2, alpha=a3))
+            d_oc = ops.gemm_small(ds, (2, 1), wcs, (d, 1), n_roi, d, 2, alpha=a3)        # [n][1024] = a 1x1 output map
+            g_feat, g_kern = ops.depthwise_corr_backward(d_oc, corr_roi, hc["corr_sup"], n_roi, 7, 7, d, 7, 7,
+                                                         maps_per_kernel=R)
+            ops.axpy_rows_(d_corr_roi, g_feat, n_roi * P2, d)
+            dwc_s, _, _ = ops.linear_backward(g_kern.view(B * P2, d), support.view(B * P2, d), wcc, B * P2, d, d,
+                                              dx_out=d_support, dx_ld=d)
+            ops.axpy_rows_(d_wcc, dwc_s, d, d)
+            # .. patch relation: Linear(2) <- avgpool3 <- relu 1x1 <- relu 3x3 <- avgpool 3/1 <- relu 1x1([roi | support])
+            _acc(model.patch_cls_score.weight, ops.gemm_small(ds, (1, 2), hc["x4"], (d, 1), 2, d, n_roi, alpha=a3))
+            _acc(model.patch_cls_score.bias, ops.colsum(ds, n_roi, 2, alpha=a3))
+            d_x4 = ops.gemm_small(ds, (2, 1), wps, (d, 1), n_roi, d, 2, alpha=a3)
+            d_x3 = ops.avgpool_backward(d_x4, n_roi, 3, 3, d, 3, 1).view(n_roi * 9, d)
+            ops.relu_mask_(d_x3, hc["x3"], n_roi * 9, d)
+            dwp3, _, d_x2 = ops.linear_backward(d_x3, hc["x2"], wp3, n_roi * 9, d, dq_)
+            _acc(model.patch_conv_3.weight, dwp3.view(d, dq_, 1, 1))
+            ops.relu_mask_(d_x2, hc["x2"], n_roi * 9, dq_)
+            grads.add_conv("patch_conv_2", d_x2, hc["x1"].view(n_roi * 25, dq_), n_roi, 5, 5, c_p2)
+            d_x1 = conv_dgrad(d_x2, n_roi, 5, 5, c_p2)
+            d_x0 = ops.avgpool_backward(d_x1, n_roi, 7, 7, dq_, 3, 1).view(n_roi * P2, dq_)
+            ops.relu_mask_(d_x0, hc["x0"], n_roi * P2, dq_)
+            dwp1r, _, _ = ops.linear_backward(d_x0, pooled.view(n_roi * P2, d), wp1, n_roi * P2, dq_, d, ldw=2 * d,
+                                              dx_out=d_pooled_head, dx_ld=d)
+            ops.axpy_rows_(d_wp1, dwp1r, dq_, d, ld_y=2 * d)
+            d_p_sup = ops.spatial_mean(d_x0, B, R, P2 * dq_)  # the support half was broadcast over the image's rois
+            d_p_sup.mul_(float(R))
+            dwp1s, _, _ = ops.linear_backward(d_p_sup.view(B * P2, dq_), support.view(B * P2, d), wp1.view(-1)[d:],
+                                              B * P2, dq_, d, ldw=2 * d, dx_out=d_support, dx_ld=d)
+            ops.axpy_rows_(d_wp1.view(-1)[d:], dwp1s, dq_, d, ld_y=2 * d)
+            d_supports[hc["offset"]] = d_support
+        # the roi halves shared by both heads: mean over the 49 positions, corr_conv(rois)
+        ops.broadcast_rows(d_g_roi, n_roi, P2, d, alpha=1.0 / P2, out=d_pooled_head)
+        dwc_r, _, _ = ops.linear_backward(d_corr_roi, pooled.view(n_roi * P2, d), wcc, n_roi * P2, d, d,
+                                          dx_out=d_pooled_head, dx_ld=d)
+        ops.axpy_rows_(d_wcc, dwc_r, d, d)
+        _acc(model.global_fc_1.weight, d_w1)
+        _acc(model.patch_conv_1.weight, d_wp1.view(dq_, 2 * d, 1, 1))
+        _acc(model.corr_conv.weight, d_wcc.view(d, d, 1, 1))
     elif fgn:
         # -- relation head (fgn.py:145-165): Linear <- ReLU/BN2 <- conv2 <- ReLU/BN1 <- (support half + roi half) of conv1;
         #    bn1 / bn2 are ORDINARY BatchNorms in train mode: their adjoint goes through the batch statistics --
@@ -638,6 +747,9 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         g = bottleneck_backward(g, sv, sv["n"], sv["h"], sv["w"], sv["bp"], grads, sv["key"], mask_dx=i < len(l4) - 1,
                                 g_masked=i > 0)
     grads.finish_all(model, "RCNN_top")
+    if fsod:
+        grads.finish_all(model, "patch_conv_2")
+        ops.axpy_rows_(g, d_pooled_head, n_roi * 49, 1024)  # the pooled features also feed the relation heads' roi halves
     if fgn:
         grads.finish_all(model, "cls_conv2")
         ops.axpy_rows_(g, d_pooled_head, n_roi * 49, 1024)  # the pooled features also feed the relation head's roi half
@@ -649,17 +761,28 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     nh = ctx["nh"]
     d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
                                     inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0], grad_dev=g_dev)
-    dwh, dbh, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512)
+    rfh, rfw = ctx.get("rfh", fh), ctx.get("rfw", fw)  # the RPN input's own geometry (fsod: the correlation map is smaller)
+    rhw = rfh * rfw
+    dwh, dbh, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * rhw, nh, 512)
     ns = rpn.nc_score_out
     _acc(rpn.RPN_cls_score.weight, dwh[:ns])
     _acc(rpn.RPN_cls_score.bias, dbh[:ns])
     _acc(rpn.RPN_bbox_pred.weight, dwh[ns:])
     _acc(rpn.RPN_bbox_pred.bias, dbh[ns:])
-    ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
+    ops.relu_mask_(d_x, ctx["rpn_x"], B * rhw, 512)
     c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None, u=plan["rpn_conv_u"])
-    grads.add_conv("RCNN_rpn.RPN_Conv", d_x, ctx["rpn_feat"], B, fh, fw, c_rpn)
-    _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
-    if fgn:
+    grads.add_conv("RCNN_rpn.RPN_Conv", d_x, ctx["rpn_feat"], B, rfh, rfw, c_rpn)
+    _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * rhw, 512))
+    if fsod:
+        # attention RPN (fsod.py:109-116): the RPN ran on the depth-wise correlation of base_feat with the pooled positive
+        # support -> d base = full correlation of d rfeat with that kernel + RoIAlign path; d kernel -> positive supports
+        d_rfeat = conv_dgrad(d_x, B, rfh, rfw, c_rpn)
+        gq, d_pos_kernel = ops.depthwise_corr_backward(d_rfeat, ctx["base"], ctx["pos"], B, fh, fw, 1024, 7, 7)
+        ops.axpy_rows_(gq, d_bf, B * hw, 1024)
+        ops.axpy_rows_(d_supports[0], d_pos_kernel.view(B * 49, 1024), B * 49, 1024)
+        for off_, d_sup_ in d_supports.items():  # AvgPool2d(14, 1) of the shots' mean map (fsod.py:98-101)
+            to_supports(ops.avgpool_backward(d_sup_, B, 20, 20, 1024, 14, 1), off_)
+    elif fgn:
         # the RPN ran on base_feat * pos_rpn[image] (fgn.py:75-82): d base = d rfeat * pos_rpn + RoIAlign path, and
         # d pos_rpn[image] = sum over the pixels of d rfeat * base -> AvgPool2d(20) -> the positive supports' mean map
         d_rfeat = conv_dgrad(d_x, B, fh, fw, c_rpn)

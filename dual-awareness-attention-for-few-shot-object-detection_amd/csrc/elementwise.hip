@@ -156,6 +156,65 @@ depthwise_corr_kernel(const float4* __restrict__ feat, const float4* __restrict_
   }
 }
 
+// adjoints of the depth-wise "valid" cross-correlation above (the fsod sibling's backward):
+//   d feat[n][y][x][c]  = sum_{i,j : 0 <= y-i < OH, 0 <= x-j < OW} d out[n][y-i][x-j][c] * kern[n / per_kernel][i][j][c]
+//   d kern[k][i][j][c]  = sum_{n in kernel k's maps} sum_{oh,ow} d out[n][oh][ow][c] * feat[n][oh+i][ow+j][c]
+__global__ void __launch_bounds__(256)
+depthwise_corr_bwd_feat_kernel(const float4* __restrict__ gout, const float4* __restrict__ kern, float4* __restrict__ gfeat,
+                               int H, int W, int KH, int KW, int OH, int OW, int C4, long per_kernel, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const int x = (int)((i / C4) % W);
+    const int y = (int)((i / C4 / W) % H);
+    const long n = i / C4 / W / H;
+    const float4* kp = kern + (n / per_kernel) * KH * KW * C4 + c;
+    const float4* gp = gout + n * OH * OW * C4 + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < KH; ++a) {
+      const int oh = y - a;
+      if (oh < 0 || oh >= OH) continue;
+      for (int b = 0; b < KW; ++b) {
+        const int ow = x - b;
+        if (ow < 0 || ow >= OW) continue;
+        const float4 g = gp[((long)oh * OW + ow) * C4], k = kp[(a * KW + b) * C4];
+        acc.x += g.x * k.x;
+        acc.y += g.y * k.y;
+        acc.z += g.z * k.z;
+        acc.w += g.w * k.w;
+      }
+    }
+    gfeat[i] = acc;
+  }
+}
+
+// one thread per (kernel, tap, float4 of channels); maps and output positions are walked in order (deterministic)
+__global__ void __launch_bounds__(256)
+depthwise_corr_bwd_kern_kernel(const float4* __restrict__ gout, const float4* __restrict__ feat, float4* __restrict__ gkern,
+                               int H, int W, int KH, int KW, int OH, int OW, int C4, long lda4, long per_kernel,
+                               long n_maps, long total, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const int b = (int)((i / C4) % KW);
+    const int a = (int)((i / C4 / KW) % KH);
+    const long k = i / C4 / KW / KH;
+    float4 acc = accumulate ? gkern[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long n1 = (k + 1) * per_kernel < n_maps ? (k + 1) * per_kernel : n_maps;
+    for (long n = k * per_kernel; n < n1; ++n) {
+      const float4* gp = gout + n * OH * OW * C4 + c;
+      const float4* fp = feat + ((n * H + a) * W + b) * lda4 + c;
+      for (int oh = 0; oh < OH; ++oh)
+        for (int ow = 0; ow < OW; ++ow) {
+          const float4 g = gp[((long)oh * OW + ow) * C4], f = fp[((long)oh * W + ow) * lda4];
+          acc.x += g.x * f.x;
+          acc.y += g.y * f.y;
+          acc.z += g.z * f.z;
+          acc.w += g.w * f.w;
+        }
+    }
+    gkern[i] = acc;
+  }
+}
+
 // k x k average pool, given stride, no padding (dana.py:42: AvgPool2d(14, stride=1))
 __global__ void __launch_bounds__(256)
 avgpool_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, int W, int OH, int OW, int C4, int k,
@@ -524,6 +583,37 @@ int dana_depthwise_corr_nhwc(const float* feat, const float* kernels, float* out
       (const float4*)feat, (const float4*)kernels, (float4*)out, height, width, kh, kw, oh, ow, channels / 4,
       feat_pix_stride / 4, maps_per_kernel, total);
   DANA_CHECK_LAUNCH("dana_depthwise_corr_nhwc");
+  return DANA_OK;
+}
+
+int dana_depthwise_corr_backward_nhwc(const float* grad_out, const float* feat, const float* kernels, float* grad_feat,
+                                      float* grad_kernels, long n_maps, int height, int width, int channels, int kh,
+                                      int kw, long maps_per_kernel, long feat_pix_stride, int accumulate_kernels,
+                                      dana_stream_t stream) {
+  DANA_CHECK_ARG(n_maps >= 0 && height >= kh && width >= kw && kh > 0 && kw > 0 && channels > 0 && channels % 4 == 0 &&
+                     maps_per_kernel > 0,
+                 "dana_depthwise_corr_backward_nhwc: bad shape");
+  if (n_maps == 0) return DANA_OK;
+  DANA_CHECK_ARG(grad_out && (!grad_feat || kernels) && (!grad_kernels || feat),
+                 "dana_depthwise_corr_backward_nhwc: null pointer");
+  if (feat_pix_stride <= 0) feat_pix_stride = channels;
+  DANA_CHECK_ARG(feat_pix_stride % 4 == 0, "dana_depthwise_corr_backward_nhwc: stride %% 4 != 0");
+  const int oh = height - kh + 1, ow = width - kw + 1, c4 = channels / 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (grad_feat) {
+    const long total = n_maps * height * width * c4;
+    depthwise_corr_bwd_feat_kernel<<<grid_for(total, 256), 256, 0, s>>>((const float4*)grad_out, (const float4*)kernels,
+                                                                        (float4*)grad_feat, height, width, kh, kw, oh, ow,
+                                                                        c4, maps_per_kernel, total);
+  }
+  if (grad_kernels) {
+    const long nk = (n_maps + maps_per_kernel - 1) / maps_per_kernel;
+    const long total = nk * kh * kw * c4;
+    depthwise_corr_bwd_kern_kernel<<<grid_for(total, 256), 256, 0, s>>>(
+        (const float4*)grad_out, (const float4*)feat, (float4*)grad_kernels, height, width, kh, kw, oh, ow, c4,
+        feat_pix_stride / 4, maps_per_kernel, n_maps, total, accumulate_kernels);
+  }
+  DANA_CHECK_LAUNCH("dana_depthwise_corr_backward_nhwc");
   return DANA_OK;
 }
 

@@ -747,6 +747,21 @@ def depthwise_corr(feat, kernels, n_maps, H, W, C, kh, kw, maps_per_kernel=1, fe
     return out, oh, ow
 
 
+def depthwise_corr_backward(grad_out, feat, kernels, n_maps, H, W, C, kh, kw, maps_per_kernel=1, feat_stride=0,
+                            need_feat=True, grad_kernels=None):
+    """adjoints of depthwise_corr: -> (grad_feat [n_maps*H*W][C] or None, grad_kernels [kernels][kh*kw][C], accumulated
+    into `grad_kernels` when that is given)"""
+    gf = torch.empty((n_maps * H * W, C), dtype=torch.float32, device=grad_out.device) if need_feat else None
+    acc = grad_kernels is not None
+    if grad_kernels is None:
+        nk = (n_maps + maps_per_kernel - 1) // maps_per_kernel
+        grad_kernels = torch.empty((nk, kh * kw, C), dtype=torch.float32, device=grad_out.device)
+    lib().call("dana_depthwise_corr_backward_nhwc", _p(_chk(grad_out, "grad_out")), _p(_chk(feat, "feat")),
+               _p(_chk(kernels, "kernels")), _p(gf), _p(grad_kernels), n_maps, H, W, C, kh, kw, maps_per_kernel, feat_stride,
+               int(acc), _stream())
+    return gf, grad_kernels
+
+
 def batch_stats(x, rows, channels, ld=0):
     """per-channel (mean, biased variance) over the rows: what nn.BatchNorm2d normalises with in train mode"""
     _chk(x, "x")

@@ -227,6 +227,12 @@ int dana_bn_train_backward(const float* grad_out, const float* x, const float* m
 int dana_depthwise_corr_nhwc(const float* feat, const float* kernels, float* out, long n_maps, int height, int width,
                              int channels, int kh, int kw, long maps_per_kernel, long feat_pix_stride,
                              dana_stream_t stream);
+/* adjoints of dana_depthwise_corr_nhwc: grad_feat [n_maps][height][width][channels] (dense; null to skip) and
+ * grad_kernels [ceil(n_maps / maps_per_kernel)][kh][kw][channels] (null to skip; accumulated when accumulate_kernels) */
+int dana_depthwise_corr_backward_nhwc(const float* grad_out, const float* feat, const float* kernels, float* grad_feat,
+                                      float* grad_kernels, long n_maps, int height, int width, int channels, int kh,
+                                      int kw, long maps_per_kernel, long feat_pix_stride, int accumulate_kernels,
+                                      dana_stream_t stream);
 /* sibling model `meta` (framework/meta.py): nn.MaxPool2d(2) of the PRN (:203,246), nn.Sigmoid (:202,250), and the
  * channel-wise product of the RoI features with their image's class-attentive vector (:136-140) */
 int dana_maxpool2x2s2_nhwc(const float* in, float* out, int batch, int height, int width, int channels,

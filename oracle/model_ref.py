@@ -632,7 +632,9 @@ def meta_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, all_cls
 # ------------------------------------------------------------------------------------------------
 # sibling model `fsod` (attention-RPN + multi-relation head): lib/model/framework/fsod.py:79-249
 # ------------------------------------------------------------------------------------------------
-def fsod_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_way=2, n_shot=3, nms_inclusive=True):
+def fsod_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_way=2, n_shot=3, nms_inclusive=True,
+                 differentiable=False):
+    """differentiable: RoIAlign as torch ops (roi_align_torch) so that autograd reaches the trunk (gradient tests)"""
     B = im_data.shape[0]
     base_feat = rcnn_base(im_data, sd)
     sup = rcnn_base(support_ims.reshape(-1, *support_ims.shape[2:]), sd)
@@ -658,8 +660,11 @@ def fsod_forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, trainin
         rois, rois_label, rois_target, rw_in, rw_out = proposal_target_layer(rois, gt_boxes)
         rois_label = rois_label.view(-1).long()
         rois_target, rw_in, rw_out = rois_target.view(-1, 4), rw_in.view(-1, 4), rw_out.view(-1, 4)
-    pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
-                                                       1.0 / 16.0, 7, 7, 0))
+    if differentiable:
+        pooled = roi_align_torch(base_feat, rois.view(-1, 5), 1.0 / 16.0, 7)
+    else:
+        pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
+                                                           1.0 / 16.0, 7, 7, 0))
     R = rois.size(1)
     n = B * R
     bbox_pred = _lin(rcnn_top(pooled, sd), sd, "RCNN_bbox_pred")
