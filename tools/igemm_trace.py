@@ -63,6 +63,11 @@ for ghz in (ghz_meas,):
         ghz, np.median(start_us - s0), np.percentile(start_us - s0, 90), (start_us - s0).max(), wall_us.max() - s0))
     late = start_us - s0 > 0.3 * (wall_us.max() - s0)
     print("blocks starting in a later round: %d of %d" % (int(late.sum()), nb))
+    first = start_us - s0 < 2.0  # dispatched with the launch: cold instruction cache, cold TLB, every block in the same phase
+    for nm, sel in (("first round", first), ("later rounds", ~first)):
+        if sel.sum():
+            print("  %-12s (%4d blocks)  prologue p50 %6.0f  K loop p50 %6.0f  epilogue p50 %6.0f  total p50 %6.0f cycles" % (
+                nm, int(sel.sum()), np.median(pro[sel]), np.median(lp[sel]), np.median(epi[sel]), np.median(tot[sel])))
 ids = xcc * 1000 + se * 16 + cu
 u, c = np.unique(ids, return_counts=True)
 print("distinct (xcc, se, cu) ids seen: %d; blocks per id min %d max %d" % (len(u), c.min(), c.max()))
