@@ -198,8 +198,8 @@ def main():
     from dana_amd import ops, synthetic as S
     training = args.mode in ("train", "step")
     way = args.way if training else 1
-    if args.model != "DAnA" and args.mode not in ("train", "eval") and not (args.model in ("frcnn", "meta") and args.mode == "step"):
-        raise SystemExit("--model %s supports --mode train / eval only (frcnn, meta: also step)" % args.model)
+    if args.model != "DAnA" and args.mode not in ("train", "eval", "step"):
+        raise SystemExit("--model %s supports --mode train / eval / step" % args.model)
     model = dana_amd.get_model(args.model, pretrained=False, use_BA_block=args.ba, way=args.way, shot=args.shot,
                                classes=["fg", "bg"])
     sd = S.fill_state_dict(model.state_dict(), seed=11, profile="test")  # random init, O(1) activations
@@ -227,8 +227,10 @@ def main():
         inputs = inputs[:4]  # faster_rcnn.py:35: (im_data, im_info, gt_boxes, num_boxes)
     elif args.model == "meta":
         inputs = inputs + [inputs[2].clone()]  # meta.py:39,48: all_cls_gt_boxes (one class in the synthetic episodes)
-    if args.model not in ("DAnA", "frcnn", "meta"):
-        args.no_train_step = True  # the HIP backward covers DAnA and the frcnn / meta siblings
+    if args.model == "fsod":  # same test-profile taming as the goldens: its correlations sum 49 products per channel
+        model.load_state_dict(S.tame_fsod_weights(sd))
+    elif args.model == "fgn":
+        model.load_state_dict(S.tame_fgn_weights(sd))
 
     def fwd_step():
         with torch.no_grad():

@@ -489,7 +489,11 @@ WgradShape wgrad_shape(int N, int K, int M, int planes = 1) {
     const int tn = (N + tile - 1) / tile, tk = (K + tile - 1) / tile;
     const long tiles = (long)tn * tk * planes;
     const int slots = tile == 128 ? 512 : 1024;
-    const double cu_flops = 157.3e12 / 256.0 * (tile == 128 ? 0.75 : 0.5);
+    // the 128 x 128 tile runs on the bf16x6 split kernel (419.4 TFLOP/s ceiling, ~0.5 of it sustained) unless
+    // dana_set_mfma_mode(0); the 64 x 64 tile is always the f32-MFMA kernel (157.3)
+    static const int old_model = getenv("DANA_WGRAD_MODEL_R1") ? 1 : 0;
+    const bool split = tile == 128 && dana_get_mfma_mode() != 0 && !old_model;
+    const double cu_flops = split ? 419.4e12 / 256.0 * 0.5 : 157.3e12 / 256.0 * (tile == 128 ? 0.75 : 0.5);
     const double wg_flops = cu_flops / (tile == 128 ? 2 : 4);
     const int maxS = (M + 255) / 256 < 64 ? (M + 255) / 256 : 64;
     for (int S = 1; S <= (maxS < 1 ? 1 : maxS); ++S) {
