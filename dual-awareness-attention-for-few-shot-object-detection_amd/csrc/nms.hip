@@ -6,13 +6,24 @@
 //                            grid enumerates (column group, row block) so every workgroup has the
 //                            same amount of work (the reference's row-major sweep is triangular).
 //   host scan (:100-123)  -> nms_scan_kernel : one 1024-thread workgroup per problem walks the
-//                            64-box blocks in order. Wave 0 (the resolver) settles block b with
-//                            scalar bit tricks (s_ff1 + v_readlane) and ORs the kept rows' words
-//                            for block b+1 from registers it prefetched one iteration earlier;
-//                            waves 1..15 (the workers) OR the kept rows of block b-1 into the
-//                            LDS-resident `remv` for every later block, one iteration behind, with
-//                            unconditional coalesced loads. One barrier per block; nothing on the
-//                            resolver's critical path waits for HBM.
+//                            64-box blocks in order. Wave 0 (the resolver) settles block b as a FIXED POINT
+//                            instead of the reference's box-by-box chain: lane j holds the bits of the earlier
+//                            boxes of its block that suppress box j (the transposed diagonal tile, written by
+//                            the mask kernel), so "kept = alive and no kept earlier box suppresses me" is one
+//                            ballot per round, K <- ballot(alive_j && (col_j & K) == 0). Suppression only points
+//                            from earlier to later boxes, so the rounds settle the boxes in order of their
+//                            dependency depth and the fixed point IS the greedy result (typically 3-8 rounds of
+//                            ~40 cycles, where the scalar chain cost ~165 cycles per kept box). The previous
+//                            block's kept boxes enter the same way through the transposed super-diagonal tile.
+//                            Waves 1..15 (the workers) OR the kept rows of block b-1 into the LDS-resident `remv`
+//                            for every later block, one iteration behind, with unconditional coalesced loads.
+//                            One barrier per block; nothing on the resolver's critical path waits for HBM.
+// Column bands when the caller keeps at most `max_keep` boxes (the RPN's post_nms_topN): greedy NMS stops after max_keep
+// keeps, which on score-sorted proposals happens long before the last box, and the scan only ever reads mask words
+// of rows it has visited. Band 0 fills and scans the triangle of the first ~2.5 * max_keep boxes; every later band
+// (its column band of the mask, then its stretch of the scan) leaves at once if an earlier one reached max_keep. A
+// band's tiles fold the rows kept so far into a per-column "already suppressed" word on the way (one wave OR + one
+// atomic per tile), so its scan starts from the exact state a single full scan would have at that block.
 // IoU uses the legacy "+1" widths (nms.cu:13-21). `inclusive`==0 suppresses on IoU > thr
 // (reference CUDA, nms.cu:60); ==1 on IoU >= thr (reference CPU, cpu/nms_cpu.cpp:60).
 // Compiled with -ffp-contract=off. The division-free fast path below only decides cases that are
@@ -20,6 +31,7 @@
 // so every decision equals the reference's `inter / (Sa + Sb - inter) > thr` bit for bit.
 #include "common.h"
 #include "../../include/dana_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -40,16 +52,34 @@ __device__ __forceinline__ bool iou_suppress(float4 a, float sa, float4 b, float
 
 __device__ __forceinline__ float box_area(float4 a) { return (a.z - a.x + 1.f) * (a.w - a.y + 1.f); }
 
-// grid = (ceil(col_blocks/4), row_blocks, problems); wave w of the workgroup owns tile (rb, cg*4 + w)
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+  return v;
+}
+
+// per-problem hand-off between the passes (workspace): state[0] = keeps so far, state[1] = finished
+struct NmsPass {
+  int cb_lo, cb_hi;                      // column blocks of this launch
+  const int* state;                      // pass 2: leave if state[2 * problem + 1]
+  const unsigned long long* keptmask;    // pass 2: bit r of keptmask[problem][rb] = row rb*64+r was kept in pass 1
+  unsigned long long* remv_g;            // pass 2: OR of the kept rows' words, per column block
+  int kept_rows_hi;                      // row blocks < this were scanned in pass 1
+  unsigned long long* diag_t;            // [problem][n]: bits of the EARLIER boxes of box j's block that suppress j
+  unsigned long long* prev_t;            // [problem][n]: bits of the boxes of the PREVIOUS block that suppress j
+};
+
+// grid = (ceil((cb_hi - cb_lo)/4), cb_hi, problems); wave w of the workgroup owns tile (rb, cb_lo + cg*4 + w)
 __global__ void __launch_bounds__(256)
 nms_mask_kernel(const float4* __restrict__ boxes, unsigned long long* __restrict__ mask, int n, int col_blocks,
-                float thr, int inclusive) {
+                float thr, int inclusive, NmsPass ps) {
   __shared__ float4 colbox[4][64];
   __shared__ float colarea[4][64];
+  if (ps.state && ps.state[2 * blockIdx.z + 1]) return;  // pass 1 already kept max_keep boxes
   const int rb = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cb = blockIdx.x * 4 + wave;
-  if (cb < rb || cb >= col_blocks) return;  // wave-uniform: whole waves leave, no barrier below
+  const int cb = ps.cb_lo + blockIdx.x * 4 + wave;
+  if (cb < rb || cb >= ps.cb_hi) return;  // wave-uniform: whole waves leave, no barrier below
   const float4* pb = boxes + (long)blockIdx.z * n;
   unsigned long long* pm = mask + (long)blockIdx.z * n * col_blocks;
   const int row = rb * 64 + lane;
@@ -61,11 +91,39 @@ nms_mask_kernel(const float4* __restrict__ boxes, unsigned long long* __restrict
   colarea[wave][lane] = box_area(cbx);
   __builtin_amdgcn_wave_barrier();
   const int csize = min(64, n - cb * 64);
-  const int start = (cb == rb) ? lane + 1 : 0;
   unsigned long long t = 0;
-  for (int i = 0; i < csize; ++i)
-    if (i >= start && iou_suppress(me, sme, colbox[wave][i], colarea[wave][i], thr, inclusive)) t |= 1ULL << i;
+  if (cb != rb) {
+    for (int i = 0; i < csize; ++i)
+      if (iou_suppress(me, sme, colbox[wave][i], colarea[wave][i], thr, inclusive)) t |= 1ULL << i;
+  } else {
+    // Diagonal tile: the test is symmetric bit for bit (max / min / the commutative sa + sb), so the same sweep over
+    // ALL boxes of the block gives the row word (later boxes this one suppresses) and its transpose (earlier boxes
+    // that suppress this one); a second sweep over the previous block gives the transposed super-diagonal tile.
+    for (int i = 0; i < csize; ++i)
+      if (i != lane && iou_suppress(me, sme, colbox[wave][i], colarea[wave][i], thr, inclusive)) t |= 1ULL << i;
+    const unsigned long long below = (1ULL << lane) - 1;
+    unsigned long long pv = 0;
+    if (rb > 0) {
+      __builtin_amdgcn_wave_barrier();
+      const float4 pbx = pb[(rb - 1) * 64 + lane];  // the previous block is always full
+      colbox[wave][lane] = pbx;
+      colarea[wave][lane] = box_area(pbx);
+      __builtin_amdgcn_wave_barrier();
+      for (int i = 0; i < 64; ++i)
+        if (iou_suppress(me, sme, colbox[wave][i], colarea[wave][i], thr, inclusive)) pv |= 1ULL << i;
+    }
+    if (row < n) {
+      ps.diag_t[(long)blockIdx.z * n + row] = t & below;
+      ps.prev_t[(long)blockIdx.z * n + row] = pv;
+    }
+    t &= ~below;
+  }
   if (row < n) pm[(long)row * col_blocks + cb] = t;
+  if (ps.keptmask && rb < ps.kept_rows_hi) {
+    const unsigned long long kept = ps.keptmask[(long)blockIdx.z * col_blocks + rb];
+    const unsigned long long v = wave_or64(((kept >> lane) & 1ULL) && row < n ? t : 0ULL);
+    if (lane == 0 && v) atomicOr(&ps.remv_g[(long)blockIdx.z * col_blocks + cb], v);
+  }
 }
 
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
@@ -77,16 +135,16 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
   return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
 }
-__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
-  return v;
-}
 
 // LDS: remv[col_blocks] | list[2][64] ints | cnt[2] | count | done
+// Scans the blocks [b_lo, b_hi) of every problem. b_lo == 0: fresh start (and the hand-off words are reset);
+// b_lo > 0: continues from the state pass 1 left (count, per-column words folded by the band's mask tiles).
 __global__ void __launch_bounds__(1024)
 nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int col_blocks, int max_keep,
-                int* __restrict__ keep, int* __restrict__ num_keep, int keep_stride) {
+                int* __restrict__ keep, int* __restrict__ num_keep, int keep_stride, int b_lo, int b_hi,
+                int* __restrict__ state, unsigned long long* __restrict__ keptmask,
+                unsigned long long* __restrict__ remv_g, const unsigned long long* __restrict__ diag_t,
+                const unsigned long long* __restrict__ prev_t) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];
   int* list = (int*)(remv + col_blocks);  // [2][64] kept rows (local index) of the last two blocks
   int* cnt = list + 128;                  // [2]
@@ -94,57 +152,73 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int col_bloc
   int* s_done = cnt + 3;
   const unsigned long long* pm = mask + (long)blockIdx.x * n * col_blocks;
   int* pk = keep + (long)blockIdx.x * keep_stride;
-  for (int j = threadIdx.x; j < col_blocks; j += blockDim.x) remv[j] = 0;
+  int* st = state ? state + 2 * blockIdx.x : nullptr;
+  unsigned long long* km = keptmask ? keptmask + (long)blockIdx.x * col_blocks : nullptr;
+  unsigned long long* rg = remv_g ? remv_g + (long)blockIdx.x * col_blocks : nullptr;
+  if (b_lo > 0 && st[1]) return;  // pass 1 finished the problem (num_keep is already written)
+  for (int j = threadIdx.x; j < col_blocks; j += blockDim.x) {
+    remv[j] = b_lo > 0 ? rg[j] : 0ULL;
+    if (b_lo == 0 && rg) rg[j] = 0ULL;  // the band's mask tiles OR into it before pass 2 reads it
+  }
   if (threadIdx.x < 4) cnt[threadIdx.x] = 0;  // cnt[0..1], count, done
   __syncthreads();
+  if (threadIdx.x == 0 && b_lo > 0) *s_count = st[0];
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // resolver prefetch registers: diagonal word and the word for the next block, rows of block b
-  unsigned long long diag = 0, nxt = 0;
+  // resolver prefetch registers: the transposed diagonal / super-diagonal words of the boxes of block b
+  const unsigned long long* dt = diag_t + (long)blockIdx.x * n;
+  const unsigned long long* pt = prev_t + (long)blockIdx.x * n;
+  unsigned long long colw = 0, prvw = 0;
+  unsigned long long kprev = 0;  // kept boxes of block b-1 (uniform); at the start of a band they are already in remv
   if (wave == 0) {
-    if (lane < n) {
-      diag = pm[(long)lane * col_blocks];
-      if (col_blocks > 1) nxt = pm[(long)lane * col_blocks + 1];
+    const int row0 = b_lo * 64 + lane;
+    if (row0 < n) {
+      colw = dt[row0];
+      prvw = pt[row0];
     }
   }
-  for (int b = 0; b < col_blocks; ++b) {
+  for (int b = b_lo; b < b_hi; ++b) {
     if (wave == 0) {
       // ---- resolver: prefetch block b+1's words first so their latency hides under the resolve ----
-      unsigned long long diag_n = 0, nxt_n = 0;
+      unsigned long long colw_n = 0, prvw_n = 0;
       const int rown = (b + 1) * 64 + lane;
-      if (b + 1 < col_blocks && rown < n) {
-        diag_n = pm[(long)rown * col_blocks + b + 1];
-        if (b + 2 < col_blocks) nxt_n = pm[(long)rown * col_blocks + b + 2];
+      if (b + 1 < b_hi && rown < n) {
+        colw_n = dt[rown];
+        prvw_n = pt[rown];
       }
       const int bsize = min(64, n - b * 64);
-      const unsigned long long valid = bsize == 64 ? ~0ULL : ((1ULL << bsize) - 1);
-      unsigned long long alive = uniform64(~remv[b] & valid);
-      unsigned long long kept = 0, fast = 0;  // fast: the kept rows' words for block b+1, gathered as they are kept
-      const int base = *s_count;
-      int count = base;
-      while (alive) {
-        const int k = __builtin_ctzll(alive);
-        kept |= 1ULL << k;
-        alive &= ~(1ULL << k);
-        alive &= ~readlane64(diag, k);
-        fast |= readlane64(nxt, k);
-        if (++count == max_keep) break;
+      const unsigned long long rm = uniform64(remv[b]);
+      const bool al = lane < bsize && !((rm >> lane) & 1ULL) && (prvw & kprev) == 0ULL;
+      unsigned long long K = __ballot(al);
+      for (;;) {  // fixed point of K = alive & ~suppressed_by(K): the greedy result (see the header)
+        const unsigned long long Kn = __ballot(al && (colw & K) == 0ULL);
+        if (Kn == K) break;
+        K = Kn;
       }
-      const bool mine = (kept >> lane) & 1ULL;
-      const int pos = __builtin_popcountll(kept & ((1ULL << lane) - 1));
+      const int base = __builtin_amdgcn_readfirstlane(*s_count);
+      const unsigned long long below = (1ULL << lane) - 1;
+      int c = __builtin_popcountll(K);
+      if (base + c > max_keep) {  // the block that reaches max_keep: its first max_keep - base kept boxes
+        c = max_keep - base;
+        K = __ballot(((K >> lane) & 1ULL) && __builtin_popcountll(K & below) < c);
+      }
+      const bool mine = (K >> lane) & 1ULL;
+      const int pos = __builtin_popcountll(K & below);
       if (mine) {
         pk[base + pos] = b * 64 + lane;
         list[(b & 1) * 64 + pos] = lane;
       }
       if (lane == 0) {
-        if (b + 1 < col_blocks && fast) atomicOr(&remv[b + 1], fast);
-        cnt[b & 1] = count - base;
-        *s_count = count;
-        if (count == max_keep) *s_done = 1;
+        cnt[b & 1] = c;
+        *s_count = base + c;
+        if (base + c == max_keep) *s_done = 1;
+        if (km) km[b] = K;
       }
-      diag = diag_n;
-      nxt = nxt_n;
-    } else if (b > 0) {
-      // ---- workers: rows kept in block b-1 -> remv[j], j >= b+1 (one iteration behind the resolver) ----
+      kprev = K;
+      colw = colw_n;
+      prvw = prvw_n;
+    } else if (b > b_lo) {
+      // ---- workers: rows kept in block b-1 -> remv[j], b+1 <= j < b_hi (one iteration behind the resolver) ----
       // The (kept row, group of 64 column words) items are dealt round-robin to the 15 worker waves and each wave issues
       // ALL its loads before it uses any (up to 6 in flight): one L2 round trip per block instead of one per column
       // group (round 1: 3.2 us per block; now 2.5, the resolver wave's chain being what is left).
@@ -152,7 +226,7 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int col_bloc
       const int* rows = list + ((b - 1) & 1) * 64;
       const unsigned long long* base = pm + (long)(b - 1) * 64 * col_blocks;
       const int first = b + 1;
-      const int ngroups = (col_blocks - first + 63) / 64;
+      const int ngroups = (b_hi - first + 63) / 64;
       const int items = c * ngroups;
       constexpr int U = 6;
       for (int it0 = wave - 1; it0 < items; it0 += 15 * U) {
@@ -166,7 +240,7 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int col_bloc
           if (it < items) {
             const int i = it / ngroups, g = it - i * ngroups;
             const int j = first + g * 64 + lane;
-            if (j < col_blocks) {
+            if (j < b_hi) {
               jj[u] = j;
               v[u] = base[(long)rows[i] * col_blocks + j];
             }
@@ -180,7 +254,13 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int col_bloc
     __syncthreads();
     if (*s_done) break;
   }
-  if (threadIdx.x == 0) num_keep[blockIdx.x] = *s_count;
+  if (threadIdx.x == 0) {
+    num_keep[blockIdx.x] = *s_count;
+    if (st) {
+      st[0] = *s_count;
+      st[1] = (*s_done || b_hi >= col_blocks) ? 1 : 0;
+    }
+  }
 }
 
 }  // namespace
@@ -190,7 +270,10 @@ extern "C" {
 size_t dana_nms_workspace_bytes(int n, int problems) {
   if (n <= 0 || problems <= 0) return 0;
   size_t cb = (size_t)(n + 63) / 64;
-  return (size_t)problems * n * cb * sizeof(unsigned long long);
+  // mask words | kept-row words [problems][cb] | folded column words [problems][cb] | state [problems][2]
+  // ... | transposed diagonal / super-diagonal words [2][problems][n]
+  return (size_t)problems * n * cb * sizeof(unsigned long long) + (size_t)problems * (2 * cb * 8 + 16) +
+         (size_t)2 * problems * n * sizeof(unsigned long long);
 }
 
 int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, int max_keep, int* keep,
@@ -218,12 +301,46 @@ int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, 
   const int cb = (n + 63) / 64;
   const size_t lds = (size_t)cb * 8 + 128 * 4 + 16;
   DANA_CHECK_ARG(lds <= 64 * 1024 && cb <= 65535, "dana_nms: n=%d too large for the LDS-resident scan", n);
-  dim3 grid((cb + 3) / 4, cb, problems);
-  nms_mask_kernel<<<grid, 256, 0, s>>>((const float4*)boxes, (unsigned long long*)workspace, n, cb, thr, inclusive);
-  DANA_CHECK_LAUNCH("dana_nms(mask)");
-  nms_scan_kernel<<<problems, 1024, lds, s>>>((const unsigned long long*)workspace, n, cb, max_keep, keep, num_keep,
-                                              keep_stride);
-  DANA_CHECK_LAUNCH("dana_nms(scan)");
+  unsigned long long* maskw = (unsigned long long*)workspace;
+  unsigned long long* keptmask = maskw + (size_t)problems * n * cb;
+  unsigned long long* remv_g = keptmask + (size_t)problems * cb;
+  int* state = (int*)(remv_g + (size_t)problems * cb);
+  unsigned long long* diag_t = (unsigned long long*)(state + 2 * (size_t)problems + 2 * ((size_t)problems & 1));
+  unsigned long long* prev_t = diag_t + (size_t)problems * n;
+  // Band edges in units of max_keep boxes x 100 (DANA_NMS_BANDS="250,500": the first pass covers 2.5 x max_keep boxes,
+  // the second up to 5 x, the last the rest; "0": a single pass). An edge that would leave less than a quarter of the
+  // problem for the later bands is dropped.
+  static int edges_pct[8], n_edges = -1;
+  if (n_edges < 0) {
+    const char* e = getenv("DANA_NMS_BANDS");
+    if (!e) e = "250,500";
+    n_edges = 0;
+    while (*e && n_edges < 8) {
+      const int v = atoi(e);
+      if (v > 0) edges_pct[n_edges++] = v;
+      while (*e && *e != ',') ++e;
+      if (*e == ',') ++e;
+    }
+  }
+  int edge[10], nb = 0;  // band i = column blocks [edge[i], edge[i+1])
+  edge[nb++] = 0;
+  if (max_keep < n)
+    for (int i = 0; i < n_edges; ++i) {
+      long blocks = ((long)max_keep * edges_pct[i] / 100 + 63) / 64;
+      if (blocks < 8) blocks = 8;
+      if (blocks > edge[nb - 1] && blocks * 4 <= (long)cb * 3) edge[nb++] = (int)blocks;
+    }
+  edge[nb] = cb;
+  for (int i = 0; i < nb; ++i) {
+    const int lo = edge[i], hi = edge[i + 1];
+    const NmsPass ps = {lo, hi, i ? state : nullptr, i ? keptmask : nullptr, i ? remv_g : nullptr, lo, diag_t, prev_t};
+    nms_mask_kernel<<<dim3((hi - lo + 3) / 4, hi, problems), 256, 0, s>>>((const float4*)boxes, maskw, n, cb, thr, inclusive,
+                                                                          ps);
+    DANA_CHECK_LAUNCH("dana_nms(mask)");
+    nms_scan_kernel<<<problems, 1024, lds, s>>>(maskw, n, cb, max_keep, keep, num_keep, keep_stride, lo, hi, state, keptmask,
+                                                remv_g, diag_t, prev_t);
+    DANA_CHECK_LAUNCH("dana_nms(scan)");
+  }
   return DANA_OK;
 }
 

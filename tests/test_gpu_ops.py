@@ -264,6 +264,31 @@ def test_nms_max_keep_truncates_in_order(dev):
     assert int(num[0]) == 300 and np.array_equal(keep[0].cpu().numpy(), keep_all[:300])
 
 
+@pytest.mark.parametrize("clusters,max_keep", [(40, 300), (400, 300), (3000, 300), (150, 1000)])
+def test_nms_two_pass_hand_off_vs_oracle(dev, clusters, max_keep):
+    """dana_nms scans the first ~3*max_keep boxes first and only then the rest: problems that finish in pass 1, problems
+    that need pass 2 and problems that never reach max_keep, side by side in one call (nms.cu:70-131 semantics)"""
+    ops, orc = _ops(), _oracle()
+    n, P = 6000, 3
+    boxes = np.zeros((P, n, 4), np.float32)
+    for q in range(P):
+        rng = np.random.default_rng(100 * clusters + q)
+        k = max(clusters // (1 + 3 * q), 4)  # fewer clusters -> fewer survivors -> the scan runs further
+        c = rng.uniform([0, 0], [1000, 600], size=(k, 2))
+        ctr = c[rng.integers(0, k, n)] + rng.normal(0, 4, size=(n, 2))
+        wh = rng.uniform(40, 60, size=(n, 2))
+        boxes[q] = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1)
+    keep, num = ops.nms_sorted(torch.from_numpy(boxes).to(dev), 0.7, False, max_keep=max_keep)
+    seen = set()
+    for q in range(P):
+        ref = orc.nms(boxes[q], -np.arange(n, dtype=np.float32), 0.7, inclusive=False)[:max_keep]
+        assert int(num[q]) == len(ref)
+        assert np.array_equal(keep[q, :len(ref)].cpu().numpy(), ref)
+        seen.add("full" if len(ref) == max_keep else "short")
+    if clusters == 40:
+        assert seen == {"full", "short"}  # the case list really covers both outcomes in one launch
+
+
 def test_sort_desc_stable(dev):
     ops = _ops()
     rng = np.random.default_rng(0)
