@@ -205,21 +205,16 @@ __device__ __forceinline__ float gt_iou(float4 a, float a_area, const float* __r
   return inter / (a_area + sg[4] - inter);
 }
 
-// grid = B, block = 1024; dynamic LDS: sgt[n_gt][6] | gt_max bits[n_gt]
-__global__ void __launch_bounds__(1024)
-anchor_target_prepare_kernel(const float* __restrict__ gt, const float* __restrict__ im_info,
-                             const float* __restrict__ base, AnchorGeom g, float neg_ov, float pos_ov,
-                             float* __restrict__ labels, float* __restrict__ max_ov_out, int* __restrict__ assign,
-                             int* __restrict__ fg_list, int* __restrict__ bg_list, int* __restrict__ counts) {
-  extern __shared__ float sm[];
-  float* sgt = sm;
-  int* gmax = (int*)(sm + g.n_gt * 6);
-  __shared__ int wsum_fg[16], wsum_bg[16];
-  __shared__ int run_fg, run_bg;
-  const int b = blockIdx.x;
-  const int total = g.H * g.W * g.A;
-  for (int k = threadIdx.x; k < g.n_gt; k += blockDim.x) {
-    const float* q = gt + ((long)b * g.n_gt + k) * 5;
+// The assignment runs as three launches over (anchor chunk, image) so that it is not one workgroup per image (round 1:
+// 290-350 us on 4 CUs, the slowest launch of the step):
+//   anchor_target_iou_kernel    per-anchor max / first argmax over gt, per-gt max over the inside anchors (LDS atomicMax
+//                               on the float bits, IoU >= 0, then one global atomicMax per gt and block)
+//   anchor_target_label_kernel  labels before subsampling (:109-124)
+//   anchor_target_lists_kernel  ascending fg / bg index lists + counts (one workgroup per image: an ordered compaction)
+// The per-gt maxima live in the first n_gt ints of the image's fg_list row until the third launch overwrites them.
+__device__ __forceinline__ void load_gt(const float* __restrict__ gt, int b, int n_gt, float* sgt) {
+  for (int k = threadIdx.x; k < n_gt; k += blockDim.x) {
+    const float* q = gt + ((long)b * n_gt + k) * 5;
     const float gw = q[2] - q[0] + 1.f, gh = q[3] - q[1] + 1.f;
     sgt[k * 6 + 0] = q[0];
     sgt[k * 6 + 1] = q[1];
@@ -227,13 +222,25 @@ anchor_target_prepare_kernel(const float* __restrict__ gt, const float* __restri
     sgt[k * 6 + 3] = q[3];
     sgt[k * 6 + 4] = gw * gh;
     sgt[k * 6 + 5] = (gw == 1.f && gh == 1.f) ? 1.f : 0.f;
-    gmax[k] = 0;  // bits of +0.0f: overlaps are >= 0 for real anchors
   }
-  if (threadIdx.x == 0) run_fg = run_bg = 0;
+}
+
+// grid = (chunks, B), block = 256; dynamic LDS: sgt[n_gt][6] | gt_max bits[n_gt]
+__global__ void __launch_bounds__(256)
+anchor_target_iou_kernel(const float* __restrict__ gt, const float* __restrict__ im_info,
+                         const float* __restrict__ base, AnchorGeom g, float* __restrict__ max_ov_out,
+                         int* __restrict__ assign, int* __restrict__ gmax_g) {
+  extern __shared__ float sm[];
+  float* sgt = sm;
+  int* gmax = (int*)(sm + g.n_gt * 6);
+  const int b = blockIdx.y;
+  const int total = g.H * g.W * g.A;
+  load_gt(gt, b, g.n_gt, sgt);
+  for (int k = threadIdx.x; k < g.n_gt; k += blockDim.x) gmax[k] = 0;  // bits of +0.0f: overlaps are >= 0
   __syncthreads();
   const float im_h = (float)(long)im_info[0], im_w = (float)(long)im_info[1];  // long(im_info[0][..]) of IMAGE 0
-  // pass 1a: per-anchor max / first argmax over gt (zero-area gt rows are a wave-uniform shortcut)
-  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) {
     const float4 a = anchor_box(base, g, i);
     const bool inside = a.x >= 0.f && a.y >= 0.f && a.z < im_w && a.w < im_h;
     float best = -3.4e38f;
@@ -246,50 +253,65 @@ anchor_target_prepare_kernel(const float* __restrict__ gt, const float* __restri
           best = ov;
           arg = k;
         }
+        // per-gt max over the inside anchors (zero-area gt rows stay at 0, like the reference's masked column)
+        if (__float_as_int(ov) > gmax[k]) atomicMax(&gmax[k], __float_as_int(ov));
       }
     }
     max_ov_out[(long)b * total + i] = inside ? best : -2.f;  // -2 marks "outside the image"
     assign[(long)b * total + i] = arg;
   }
-  // pass 1b: per-gt max over the inside anchors: gt outer (uniform), anchors inner, one LDS atomic per wave
-  for (int k = 0; k < g.n_gt; ++k) {
-    if (sgt[k * 6 + 5] != 0.f) continue;  // padding row: its column is all zeros
-    float mx = 0.f;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      const float4 a = anchor_box(base, g, i);
-      if (a.x >= 0.f && a.y >= 0.f && a.z < im_w && a.w < im_h)
-        mx = fmaxf(mx, gt_iou(a, (a.z - a.x + 1.f) * (a.w - a.y + 1.f), sgt + k * 6));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(&gmax[k], __float_as_int(mx));
-  }
   __syncthreads();
   for (int k = threadIdx.x; k < g.n_gt; k += blockDim.x)
-    if (__int_as_float(gmax[k]) == 0.f) gmax[k] = __float_as_int(1e-5f);  // :116
+    if (gmax[k] > 0) atomicMax(&gmax_g[(long)b * total + k], gmax[k]);
+}
+
+// grid = (chunks, B), block = 256; dynamic LDS: sgt[n_gt][6] | gt_max[n_gt]
+__global__ void __launch_bounds__(256)
+anchor_target_label_kernel(const float* __restrict__ gt, const float* __restrict__ base, AnchorGeom g, float neg_ov,
+                           float pos_ov, const float* __restrict__ max_ov, const int* __restrict__ gmax_g,
+                           float* __restrict__ labels) {
+  extern __shared__ float sm[];
+  float* sgt = sm;
+  float* gmax = sm + g.n_gt * 6;
+  const int b = blockIdx.y;
+  const int total = g.H * g.W * g.A;
+  load_gt(gt, b, g.n_gt, sgt);
+  for (int k = threadIdx.x; k < g.n_gt; k += blockDim.x) {
+    const float m = __int_as_float(gmax_g[(long)b * total + k]);
+    gmax[k] = m == 0.f ? 1e-5f : m;  // :116
+  }
   __syncthreads();
-  // pass 2: labels + ordered fg / bg lists
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float best = max_ov[(long)b * total + i];
+  float label = -1.f;
+  if (best > -1.5f) {  // inside
+    const float4 a = anchor_box(base, g, i);
+    const float area = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+    if (best < neg_ov) label = 0.f;
+    bool is_best = false;
+    for (int k = 0; k < g.n_gt; ++k)
+      if (sgt[k * 6 + 5] == 0.f) is_best |= (gt_iou(a, area, sgt + k * 6) == gmax[k]);
+    if (is_best) label = 1.f;
+    if (best >= pos_ov) label = 1.f;
+  }
+  labels[(long)b * total + i] = label;
+}
+
+// grid = B, block = 1024
+__global__ void __launch_bounds__(1024)
+anchor_target_lists_kernel(const float* __restrict__ labels, int total, int* __restrict__ fg_list,
+                           int* __restrict__ bg_list, int* __restrict__ counts) {
+  __shared__ int wsum_fg[16], wsum_bg[16];
+  __shared__ int run_fg, run_bg;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) run_fg = run_bg = 0;
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i0 = 0; i0 < total; i0 += blockDim.x) {
     const int i = i0 + threadIdx.x;
-    bool fg = false, bg = false;
-    if (i < total) {
-      const float best = max_ov_out[(long)b * total + i];
-      float label = -1.f;
-      if (best > -1.5f) {  // inside
-        const float4 a = anchor_box(base, g, i);
-        const float area = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
-        if (best < neg_ov) label = 0.f;
-        bool is_best = false;
-        for (int k = 0; k < g.n_gt; ++k)
-          if (sgt[k * 6 + 5] == 0.f) is_best |= (gt_iou(a, area, sgt + k * 6) == __int_as_float(gmax[k]));
-        if (is_best) label = 1.f;
-        if (best >= pos_ov) label = 1.f;
-      }
-      labels[(long)b * total + i] = label;
-      fg = label == 1.f;
-      bg = label == 0.f;
-    }
+    const float label = i < total ? labels[(long)b * total + i] : -1.f;
+    const bool fg = label == 1.f, bg = label == 0.f;
     const unsigned long long mf = __ballot(fg), mb = __ballot(bg);
     if (lane == 0) {
       wsum_fg[wave] = __builtin_popcountll(mf);
@@ -707,9 +729,20 @@ int dana_anchor_target_prepare(const float* gt_boxes, const float* im_info, cons
                  "dana_anchor_target_prepare: null pointer");
   DANA_CHECK_ARG((size_t)n_gt * 28 <= 48 * 1024, "dana_anchor_target_prepare: too many gt boxes");
   AnchorGeom g = {A, H, W, feat_stride, n_gt};
-  anchor_target_prepare_kernel<<<B, 1024, (size_t)n_gt * 7 * sizeof(float), (hipStream_t)stream>>>(
-      gt_boxes, im_info, base_anchors, g, negative_overlap, positive_overlap, labels, max_overlaps, argmax, fg_list,
-      bg_list, counts);
+  const int total = A * H * W;
+  DANA_CHECK_ARG(n_gt <= total, "dana_anchor_target_prepare: more gt boxes than anchors");
+  hipStream_t s = (hipStream_t)stream;
+  // per-gt maxima: the first n_gt ints of every image's fg_list row, zeroed here (bits of +0.0f)
+  if (hipMemset2DAsync(fg_list, (size_t)total * sizeof(int), 0, (size_t)n_gt * sizeof(int), (size_t)B, s) != hipSuccess) {
+    dana_set_error("dana_anchor_target_prepare: memset failed");
+    return DANA_ERR_HIP;
+  }
+  const dim3 grid(dana_ceil_div(total, 256), B);
+  const size_t lds = (size_t)n_gt * 7 * sizeof(float);
+  anchor_target_iou_kernel<<<grid, 256, lds, s>>>(gt_boxes, im_info, base_anchors, g, max_overlaps, argmax, fg_list);
+  anchor_target_label_kernel<<<grid, 256, lds, s>>>(gt_boxes, base_anchors, g, negative_overlap, positive_overlap,
+                                                    max_overlaps, fg_list, labels);
+  anchor_target_lists_kernel<<<B, 1024, 0, s>>>(labels, total, fg_list, bg_list, counts);
   DANA_CHECK_LAUNCH("dana_anchor_target_prepare");
   return DANA_OK;
 }
