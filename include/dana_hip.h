@@ -75,7 +75,10 @@ int dana_roi_pool_backward(const float* grad_out, const int* argmax, const float
  * boxes[problems][n][4] must already be in descending-score order (the reference sorts inside
  * nms_cuda, nms.cu:73-75; here the sort is dana_sort_desc). keep[p][0..num_keep[p]) receives
  * the kept POSITIONS, ascending; at most max_keep (<=0: all). inclusive=0: suppress IoU > thr
- * (nms.cu:60); inclusive=1: IoU >= thr (nms_cpu.cpp:60). */
+ * (nms.cu:60); inclusive=1: IoU >= thr (nms_cpu.cpp:60).
+ * With max_keep < n the mask is filled and scanned in column bands (the first covers ~2.5 x max_keep boxes; the later
+ * ones leave at once when max_keep is reached): the result is the same greedy NMS truncated at max_keep, only the
+ * work differs. DANA_NMS_BANDS="a,b" sets the band edges (percent of max_keep), "0" a single pass. */
 size_t dana_nms_workspace_bytes(int n, int problems);
 int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, int max_keep, int* keep,
              int keep_stride, int* num_keep, void* workspace, size_t workspace_bytes, dana_stream_t stream);
