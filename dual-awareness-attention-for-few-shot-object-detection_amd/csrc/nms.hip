@@ -324,11 +324,12 @@ int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, 
   }
   int edge[10], nb = 0;  // band i = column blocks [edge[i], edge[i+1])
   edge[nb++] = 0;
-  if (max_keep < n)
+  // (worth it only when the full triangle is a real cost: a band that turns out to be needed adds ~25 us of restart)
+  if (max_keep < n && (long)problems * cb * cb / 2 >= 20000)
     for (int i = 0; i < n_edges; ++i) {
       long blocks = ((long)max_keep * edges_pct[i] / 100 + 63) / 64;
-      if (blocks < 8) blocks = 8;
-      if (blocks > edge[nb - 1] && blocks * 4 <= (long)cb * 3) edge[nb++] = (int)blocks;
+      if (blocks < 32 * (i + 1)) blocks = 32 * (i + 1);  // a band's mask costs little below ~2000 boxes, a launch does
+      if (blocks > edge[nb - 1] && blocks * 4 <= (long)cb * 3 && nb <= cb / 64) edge[nb++] = (int)blocks;  // <= 1 + cb/64 bands
     }
   edge[nb] = cb;
   for (int i = 0; i < nb; ++i) {

@@ -269,7 +269,7 @@ def test_nms_two_pass_hand_off_vs_oracle(dev, clusters, max_keep):
     """dana_nms scans the first ~3*max_keep boxes first and only then the rest: problems that finish in pass 1, problems
     that need pass 2 and problems that never reach max_keep, side by side in one call (nms.cu:70-131 semantics)"""
     ops, orc = _ops(), _oracle()
-    n, P = 6000, 3
+    n, P = 8000, 4  # large enough for dana_nms to band the mask (problems * blocks^2 / 2 >= 20000 tiles)
     boxes = np.zeros((P, n, 4), np.float32)
     for q in range(P):
         rng = np.random.default_rng(100 * clusters + q)
