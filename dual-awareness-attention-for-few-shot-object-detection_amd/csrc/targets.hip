@@ -632,9 +632,9 @@ rcnn_loss_c_kernel(int n, int blocks, RcnnLossWs ws, float* __restrict__ losses,
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r < 2 * n) {
     float* g = r < n ? (gsp ? gsp + (long)r * 2 : nullptr) : (gsn ? gsn + (long)(r - n) * 2 : nullptr);
-    if (g) {
-      g[0] /= cnt;
-      g[1] /= cnt;
+    if (g) {  // no kept row: the loss is 0/0 = NaN like F.cross_entropy of an empty selection, its gradient is zero
+      g[0] = cnt > 0.f ? g[0] / cnt : 0.f;
+      g[1] = cnt > 0.f ? g[1] / cnt : 0.f;
     }
   }
 }
