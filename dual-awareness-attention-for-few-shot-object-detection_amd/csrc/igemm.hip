@@ -429,12 +429,21 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   unsigned a_mask[RA];  // bit t: tap t reads inside the image (and the row exists); <= 32 taps on this kernel
   int a_dseg[RA];       // bytes added per filter row on top of segment 0's row pitch (second geometry segment)
   unsigned a_off2[RA];  // second K segment (A2): byte offset of this lane's float4 of the row's pixel, or OOB
+  // 1x1 / stride 1 / no padding (every GEMM, most convs of the path): output row m IS input pixel m -- no divisions
+  const bool lin = !STEM && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int m = m0 + r0 + 64 * j;
     const bool ok = m < p.M;
     const bool s1 = ok && m >= p.M0;
     const int mm = ok ? (s1 ? m - p.M0 : m) : 0;
+    if (lin && !p.A2) {
+      a_off[j] = (unsigned)(((s1 ? p.pix1 : 0) + mm) * lda4 + c4 * 16);
+      a_mask[j] = ok ? 1u : 0u;
+      a_dseg[j] = 0;
+      a_off2[j] = OOB;
+      continue;
+    }
     const int IH = s1 ? p.IH1 : p.IH, IW = s1 ? p.IW1 : p.IW, OW = s1 ? p.OW1 : p.OW;
     const int ohw = (s1 ? p.OH1 : p.OH) * OW;
     const int img = mm / ohw, rem = mm - img * ohw;
@@ -442,13 +451,20 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
     const int pix = (s1 ? p.pix1 : 0) + (img * IH + ih0) * IW;
     unsigned mask = 0;
-    if (ok)
+    if (STEM) {
+      // tap t = 2 * kh + half is inside the image iff row ih0 + kh is and this lane's pixel iw0 + 4 * half + c4 is (and is
+      // one of the 7 filter columns): the row range as a run of bit pairs, the two halves as a 2-bit pattern
+      const int lo = ih0 < 0 ? -ih0 : 0, hi = IH - ih0 < 7 ? IH - ih0 : 7;
+      const int iwa = iw0 + c4, iwb = iw0 + 4 + c4;
+      const unsigned cv = ((iwa >= 0 && iwa < IW) ? 0x1555u : 0u) | ((iwb >= 0 && iwb < IW && c4 < 3) ? 0x2aaau : 0u);
+      if (ok && hi > lo) mask = ((1u << (2 * hi)) - (1u << (2 * lo))) & cv;
+    } else if (ok) {
+      unsigned colbits = 0;
+      for (int kw = 0; kw < kw_t; ++kw)
+        if (iw0 + kw >= 0 && iw0 + kw < IW) colbits |= 1u << kw;
       for (int kh = 0; kh < kh_t; ++kh)
-        for (int kw = 0; kw < kw_t; ++kw) {
-          const int iw = iw0 + (STEM ? 4 * kw + c4 : kw);
-          if (ih0 + kh >= 0 && ih0 + kh < IH && iw >= 0 && iw < IW && (!STEM || 4 * kw + c4 < 7))
-            mask |= 1u << (kh * kw_t + kw);
-        }
+        if (ih0 + kh >= 0 && ih0 + kh < IH) mask |= colbits << (kh * kw_t);
+    }
     a_off[j] = STEM ? (unsigned)((pix + iw0 + c4) * lda4) : (unsigned)((pix + iw0) * lda4 + c4 * 16);
     a_mask[j] = mask;
     a_dseg[j] = s1 ? (p.IW1 - p.IW) * lda4 : 0;
@@ -694,15 +710,30 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   const int er = tid / TPR;
   const int n = n0 + ec;
   const bool full4 = p.vec_io && (n + 3) < p.N;
+  // A tile lies in ONE geometry segment except for the single tile row that straddles M0: there the output / residual
+  // rows are a base pointer plus a constant step per pass (the general form costs two 64-bit multiply-adds and a select
+  // per pass and operand -- a few thousand cycles of a short-K tile's life with one wave per SIMD).
+  const bool one_seg = m0 + BM <= p.M0 || m0 >= p.M0;  // (uniform)
+  const bool seg1 = m0 >= p.M0;
+  const long ld_c = seg1 ? p.ldc1 : p.ldc, ld_r = seg1 ? p.ldr1 : p.ldr;
+  const int mrel = (seg1 ? m0 - p.M0 : m0) + er;
+  float* const c_base = (seg1 ? p.C1 : Cb) + (long)mrel * ld_c + n;
+  const float* const r_base = (seg1 ? p.residual1 : p.residual) + (long)mrel * ld_r + n;
   float4 rres[NP];
   if (p.residual && full4) {
+    if (one_seg) {
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const int m = m0 + er + q * RPP;
-      rres[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < p.M) {
-        const bool s1 = m >= p.M0;
-        rres[q] = *(const float4*)(s1 ? p.residual1 + (long)(m - p.M0) * p.ldr1 + n : p.residual + (long)m * p.ldr + n);
+      for (int q = 0; q < NP; ++q)
+        rres[q] = (m0 + er + q * RPP < p.M) ? *(const float4*)(r_base + (long)(q * RPP) * ld_r) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int m = m0 + er + q * RPP;
+        rres[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < p.M) {
+          const bool s1 = m >= p.M0;
+          rres[q] = *(const float4*)(s1 ? p.residual1 + (long)(m - p.M0) * p.ldr1 + n : p.residual + (long)m * p.ldr + n);
+        }
       }
     }
   }
@@ -731,8 +762,11 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
       if (m < p.M) {
         const float4 a4 = *(const float4*)(Cs + rr * CLD + ec);
         float v[4] = {a4.x * sc[0] + sh[0], a4.y * sc[1] + sh[1], a4.z * sc[2] + sh[2], a4.w * sc[3] + sh[3]};
-        const bool s1 = m >= p.M0;
-        float* cp = s1 ? p.C1 + (long)(m - p.M0) * p.ldc1 + n : Cb + (long)m * p.ldc + n;
+        float* cp = c_base + (long)(q * RPP) * ld_c;
+        if (!one_seg) {
+          const bool s1 = m >= p.M0;
+          cp = s1 ? p.C1 + (long)(m - p.M0) * p.ldc1 + n : Cb + (long)m * p.ldc + n;
+        }
         if (p.residual) {
           v[0] += rres[q].x;
           v[1] += rres[q].y;
