@@ -737,6 +737,13 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
       }
     }
   }
+  float sc[4], sh[4];  // (requested with the residual rows: in flight while the accumulators go through LDS)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool nok = (n + q) < p.N;
+    sc[q] = (nok && p.scale) ? p.scale[n + q] : 1.f;
+    sh[q] = (nok && p.shift) ? p.shift[n + q] : 0.f;
+  }
   float* Cs = smem;  // [BM][CLD]
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -746,14 +753,9 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
 #pragma unroll
       for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * CLD] = acc[i][j][r];
     }
-  __syncthreads();
-  float sc[4], sh[4];
+  __syncthreads();  // (waits for the LDS writes only: the residual / scale / shift loads stay in flight)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const bool nok = (n + q) < p.N;
-    sc[q] = (nok && p.scale) ? p.alpha * p.scale[n + q] : p.alpha;
-    sh[q] = (nok && p.shift) ? p.shift[n + q] : 0.f;
-  }
+  for (int q = 0; q < 4; ++q) sc[q] *= p.alpha;
   if (full4) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
