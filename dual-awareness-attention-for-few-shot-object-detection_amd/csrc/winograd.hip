@@ -208,13 +208,15 @@ wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int cout
 __global__ void __launch_bounds__(256)
 wino4_input_kernel(const float* __restrict__ in, float* __restrict__ V, int H, int W, int C4, int th, int tw,
                    long tiles, int lda, unsigned in_bytes) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= tiles * C4) return;
-  const int c4 = (int)(idx % C4);
-  const long t = idx / C4;
-  const int j = (int)(t % tw);
-  const int i = (int)((t / tw) % th);
-  const int img = (int)(t / ((long)tw * th));
+  // 32-bit index math (tiles * C4 < 2^31 is checked by the host): the 64-bit divides cost more than the transform
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (unsigned)(tiles * C4)) return;
+  const unsigned t = idx / (unsigned)C4;
+  const int c4 = (int)(idx - t * (unsigned)C4);
+  const unsigned tr = t / (unsigned)tw;
+  const int j = (int)(t - tr * (unsigned)tw);
+  const int img = (int)(tr / (unsigned)th);
+  const int i = (int)(tr - (unsigned)img * (unsigned)th);
   const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
   float4 tm[6][6];  // B^T d, built column by column (6 loads in flight per column)
 #pragma unroll
@@ -258,15 +260,16 @@ __global__ void __launch_bounds__(256)
 wino4_output_kernel(const float* __restrict__ M, float* __restrict__ out, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ mask, long ldm, int H, int W, int N4,
                     int th, int tw, long tiles, long ldc, int relu) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= tiles * N4) return;
-  const int n4 = (int)(idx % N4);
-  const long t = idx / N4;
-  const int j = (int)(t % tw);
-  const int i = (int)((t / tw) % th);
-  const long img = t / ((long)tw * th);
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;  // (32-bit index math, see wino4_input_kernel)
+  if (idx >= (unsigned)(tiles * N4)) return;
+  const unsigned t = idx / (unsigned)N4;
+  const int n4 = (int)(idx - t * (unsigned)N4);
+  const unsigned tr = t / (unsigned)tw;
+  const int j = (int)(t - tr * (unsigned)tw);
+  const long img = (long)(tr / (unsigned)th);
+  const int i = (int)(tr - (unsigned)img * (unsigned)th);
   const long plane = tiles * (long)N4;
-  const float4* mp = (const float4*)M + t * N4 + n4;
+  const float4* mp = (const float4*)M + (long)idx;
   float4 s[4][6];  // A^T m, column by column
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
@@ -497,6 +500,7 @@ int dana_conv3x3_wgrad_winograd4(const float* grad_out, const float* input, floa
   const size_t du = dana_align_up((size_t)36 * cout * cin * 4, 256);
   void* gws = (char*)workspace + p.total + du;
   const int C4 = cin / 4, N4 = cout / 4;
+  DANA_CHECK_ARG(p.tiles * (long)(C4 > N4 ? C4 : N4) < (1L << 31), "dana_conv3x3_wgrad_winograd4: too many tiles x channels");
   wino4_input_kernel<<<dana_ceil_div(p.tiles * C4, 256), 256, 0, s>>>(input, V, h, w, C4, p.th, p.tw, p.tiles, (int)lda,
                                                                      (unsigned)in_bytes);
   DANA_CHECK_LAUNCH("dana_conv3x3_wgrad_winograd4(input transform)");
@@ -550,6 +554,7 @@ int dana_conv3x3_winograd4_nhwc_masked(const float* input, const float* u, float
   float* V = (float*)workspace;
   float* M = (float*)((char*)workspace + p.v_bytes);
   const int C4 = cin / 4, N4 = cout / 4;
+  DANA_CHECK_ARG(p.tiles * (long)(C4 > N4 ? C4 : N4) < (1L << 31), "dana_conv3x3_winograd4_nhwc: too many tiles x channels");
   wino4_input_kernel<<<dana_ceil_div(p.tiles * C4, 256), 256, 0, s>>>(input, V, h, w, C4, p.th, p.tw, p.tiles, (int)lda,
                                                                      (unsigned)in_bytes);
   DANA_CHECK_LAUNCH("dana_conv3x3_winograd4_nhwc(input transform)");
