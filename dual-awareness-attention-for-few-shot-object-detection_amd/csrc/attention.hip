@@ -125,6 +125,36 @@ attn_softmax_unary_kernel(float* __restrict__ scores, const float* __restrict__ 
   if (row >= rows) return;
   float* r = scores + row * ld;
   const float* u = unary + (row / rows_per_batch) * unary_batch_stride;
+  constexpr int RV = 8;  // a segment of up to 512 scores stays in registers: one read and one write instead of 3 + 2
+  if (L <= 64 * RV) {
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+      float* x = r + sgm * L;
+      float v[RV];
+      float m = -FLT_MAX;
+#pragma unroll
+      for (int i = 0; i < RV; ++i) {
+        const int l = lane + 64 * i;
+        v[i] = l < L ? x[l] : -FLT_MAX;
+        m = fmaxf(m, v[i]);
+      }
+      m = wave_max(m);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < RV; ++i)
+        if (lane + 64 * i < L) {  // (same per-lane summation order as the loop below)
+          v[i] = expf(v[i] - m);
+          s += v[i];
+        }
+      s = wave_sum(s);
+#pragma unroll
+      for (int i = 0; i < RV; ++i) {
+        const int l = lane + 64 * i;
+        if (l < L) x[l] = (v[i] / s + ugamma * u[sgm * L + l]) * out_scale;
+      }
+    }
+    for (int l = nseg * L + lane; l < kpad; l += 64) r[l] = 0.f;
+    return;
+  }
   for (int sgm = 0; sgm < nseg; ++sgm) {
     float* x = r + sgm * L;
     float m = -FLT_MAX;
