@@ -563,13 +563,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     }
   };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc[TM][TN];  // (zeroed below, under the first tiles' memory round trip)
 
   // ---- main loop: three stages in flight -------------------------------------------------------------------------
   //   registers R[.]  : fp32 rows of tile t+2 / t+3 (global loads, issued one iteration before they are split)
@@ -605,6 +599,18 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
 
   load_tile(ra0, rb0);       // tile 0
   load_tile(ra1, rb1);       // tile 1
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+a"(acc[i][j]));  // (64 accumulator writes: here, not in front of the loop)
+  __builtin_amdgcn_sched_barrier(0);
   store_tile(0, ra0, rb0);
   __syncthreads();
   load_tile(ra0, rb0);       // tile 2
