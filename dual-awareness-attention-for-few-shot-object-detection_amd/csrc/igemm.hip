@@ -63,6 +63,7 @@ struct IgemmParams {
   float alpha;
   int relu;
   int vec_io;  // C / residual rows are 16-byte aligned -> float4 epilogue
+  int vec_ss;  // scale / shift are 16-byte aligned (or null) -> one float4 load each
   int tiles_m, tiles_n;
   // optional SECOND K segment (split kernel only): after K0 = Cin channels of A, the K walk continues through K1 channels
   // of A2, a [batch][IH2][IW2] NHWC map sampled at (oh * stride2, ow * stride2) -- a bottleneck's 1x1 expand conv and
@@ -743,12 +744,24 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
       }
     }
   }
+  // The common tile -- all BM rows and BN columns inside the problem, one geometry segment, vector I/O, no ReLU-adjoint
+  // mask -- takes a straight-line epilogue (uniform choice): two float4 loads for scale / shift, every pass's LDS read
+  // issued before the first is used, no per-pass bounds / flag branches. (The general form below loads the eight scale /
+  // shift values one by one, each behind its own wait, and serialises the passes behind their LDS reads.)
+  const bool fast_epi = p.vec_io && p.vec_ss && one_seg && !p.mask && m0 + BM <= p.M && n0 + BN <= p.N;
   float sc[4], sh[4];  // (requested with the residual rows: in flight while the accumulators go through LDS)
+  if (fast_epi) {
+    const float4 s4 = p.scale ? *(const float4*)(p.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 h4 = p.shift ? *(const float4*)(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+    sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+  } else {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const bool nok = (n + q) < p.N;
-    sc[q] = (nok && p.scale) ? p.scale[n + q] : 1.f;
-    sh[q] = (nok && p.shift) ? p.shift[n + q] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const bool nok = (n + q) < p.N;
+      sc[q] = (nok && p.scale) ? p.scale[n + q] : 1.f;
+      sh[q] = (nok && p.shift) ? p.shift[n + q] : 0.f;
+    }
   }
   float* Cs = smem;  // [BM][CLD]
 #pragma unroll
@@ -762,7 +775,36 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   __syncthreads();  // (waits for the LDS writes only: the residual / scale / shift loads stay in flight)
 #pragma unroll
   for (int q = 0; q < 4; ++q) sc[q] *= p.alpha;
-  if (full4) {
+  if (fast_epi) {
+    float4 a4[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) a4[q] = *(const float4*)(Cs + (er + q * RPP) * CLD + ec);
+    auto emit = [&](auto res_c, auto relu_c) {
+      constexpr bool RES = decltype(res_c)::value != 0, RELU = decltype(relu_c)::value != 0;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        float v[4] = {a4[q].x * sc[0] + sh[0], a4[q].y * sc[1] + sh[1], a4[q].z * sc[2] + sh[2], a4[q].w * sc[3] + sh[3]};
+        if (RES) {
+          v[0] += rres[q].x;
+          v[1] += rres[q].y;
+          v[2] += rres[q].z;
+          v[3] += rres[q].w;
+        }
+        if (RELU) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        *(float4*)(c_base + (long)(q * RPP) * ld_c) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    };
+    if (p.residual) {
+      if (p.relu) emit(IC<1>{}, IC<1>{});
+      else emit(IC<1>{}, IC<0>{});
+    } else {
+      if (p.relu) emit(IC<0>{}, IC<1>{});
+      else emit(IC<0>{}, IC<0>{});
+    }
+  } else if (full4) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const int rr = er + q * RPP;
@@ -948,6 +990,7 @@ int run(IgemmParams& p, int batch, int stem, hipStream_t s) {
              (!p.residual || ((p.ldr % 4 == 0) && (((uintptr_t)p.residual & 15) == 0))) &&
              (p.ldc1 % 4 == 0) && (((uintptr_t)p.C1 & 15) == 0) &&
              (!p.residual1 || ((p.ldr1 % 4 == 0) && (((uintptr_t)p.residual1 & 15) == 0)));
+  p.vec_ss = (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0;
   return dispatch(p, batch, stem, s);
 }
 
