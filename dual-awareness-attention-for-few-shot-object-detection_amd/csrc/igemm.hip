@@ -967,6 +967,8 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
     if (mode == 4) return launch_split<128, 128>(p, batch, s);
     if (mode == 5) return launch_split<64, 128>(p, batch, s);
     if (p.N <= 64) return launch_split<128, 64>(p, batch, s);
+    // a narrow last column tile (N = 147: 128 + 19) wastes most of a 128-wide tile: 64-wide ones pad less
+    if (mode == 1 && p.N <= 256 && p.N % 128 != 0 && p.N % 128 <= 32) return launch_split<64, 64>(p, batch, s);
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     if (mode == 1 && t128 < 160) return launch_split<64, 64>(p, batch, s);
     return launch_split<128, 128>(p, batch, s);
