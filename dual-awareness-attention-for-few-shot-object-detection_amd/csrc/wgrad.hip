@@ -261,13 +261,21 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_128_kernel(WgradParams p) 
   for (int i = 0; i < 4; ++i) {
     const int m = m_begin + mg * 4 + i;
     m_row[i] = m;
-    const int mm = m < p.M ? m : 0;
-    img[i] = mm / ohw;
-    const int rem = mm - img[i] * ohw;
-    oh[i] = rem / p.OW;
-    ow[i] = rem - oh[i] * p.OW;
+    img[i] = oh[i] = ow[i] = 0;
+    if (!plain) {  // (wave-uniform: the dY half and every 1x1 / stride-1 X half address row m directly, no divisions)
+      const int mm = m < p.M ? m : 0;
+      img[i] = mm / ohw;
+      const int rem = mm - img[i] * ohw;
+      oh[i] = rem / p.OW;
+      ow[i] = rem - oh[i] * p.OW;
+    }
   }
-  const int d_ow = WSK % p.OW, d_oh = (WSK / p.OW) % p.OH, d_img = WSK / ohw;
+  int d_ow = 0, d_oh = 0, d_img = 0;
+  if (!plain) {
+    d_ow = WSK % p.OW;
+    d_oh = (WSK / p.OW) % p.OH;
+    d_img = WSK / ohw;
+  }
 
   float4 r[4];
   auto load_slab = [&]() {  // the thread's 4 x 4 block of the next 16 pixels, then advance
