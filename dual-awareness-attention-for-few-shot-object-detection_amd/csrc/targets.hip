@@ -225,6 +225,11 @@ __device__ __forceinline__ void load_gt(const float* __restrict__ gt, int b, int
   }
 }
 
+__global__ void __launch_bounds__(256) anchor_target_zero_kernel(int* __restrict__ gmax_g, int n_gt, int total) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_gt) gmax_g[(long)blockIdx.y * total + k] = 0;
+}
+
 // grid = (chunks, B), block = 256; dynamic LDS: sgt[n_gt][6] | gt_max bits[n_gt]
 __global__ void __launch_bounds__(256)
 anchor_target_iou_kernel(const float* __restrict__ gt, const float* __restrict__ im_info,
@@ -732,11 +737,9 @@ int dana_anchor_target_prepare(const float* gt_boxes, const float* im_info, cons
   const int total = A * H * W;
   DANA_CHECK_ARG(n_gt <= total, "dana_anchor_target_prepare: more gt boxes than anchors");
   hipStream_t s = (hipStream_t)stream;
-  // per-gt maxima: the first n_gt ints of every image's fg_list row, zeroed here (bits of +0.0f)
-  if (hipMemset2DAsync(fg_list, (size_t)total * sizeof(int), 0, (size_t)n_gt * sizeof(int), (size_t)B, s) != hipSuccess) {
-    dana_set_error("dana_anchor_target_prepare: memset failed");
-    return DANA_ERR_HIP;
-  }
+  // per-gt maxima: the first n_gt ints of every image's fg_list row, zeroed here (bits of +0.0f) by a kernel -- a
+  // strided (2-D) memset node did not replay reliably inside a captured hipGraph on ROCm 7.2
+  anchor_target_zero_kernel<<<dim3(dana_ceil_div(n_gt, 256), B), 256, 0, s>>>(fg_list, n_gt, total);
   const dim3 grid(dana_ceil_div(total, 256), B);
   const size_t lds = (size_t)n_gt * 7 * sizeof(float);
   anchor_target_iou_kernel<<<grid, 256, lds, s>>>(gt_boxes, im_info, base_anchors, g, max_overlaps, argmax, fg_list);

@@ -49,6 +49,37 @@ def test_graphed_train_forward_equals_eager_with_the_reference_rng_stream(dev):
         assert out[0].shape == (2, 128, 5) and bool(torch.isfinite(out[3]))
 
 
+def test_graphed_forward_does_not_depend_on_what_recycled_memory_holds(dev):
+    """replays between allocations that leave garbage in the caching allocator's blocks: every scratch word a captured
+    kernel reads must have been written by the graph itself (regression: a strided memset node that did not replay)"""
+    from dana_amd import synthetic as S
+    from dana_amd.graphs import GraphedDAnA
+    m = _model(dev)
+    inputs = [t.to(dev) for t in S.episode_inputs(2, 2, 2, 192, 256, seed=9)]
+
+    def garbage(seed):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        ts = [torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), dtype=torch.int32, device=dev, generator=g)
+              for n in (1 << 24, 1 << 22, 1 << 20, 1 << 18, 3 << 16, 5 << 14, 1 << 12)]
+        del ts
+
+    np.random.seed(3)
+    with torch.no_grad():
+        ref = [t.clone() if torch.is_tensor(t) else t for t in m(*inputs)]
+    run = GraphedDAnA(m, *inputs)
+    for it in range(12):
+        garbage(it)
+        np.random.seed(3)
+        with torch.no_grad():
+            _same(m(*inputs), ref)  # the eager path too
+        garbage(100 + it)
+        np.random.seed(3)
+        out = run(*inputs)
+        torch.cuda.synchronize()
+        _same(out, ref)
+
+
 def test_graphed_eval_forward_equals_eager(dev):
     from dana_amd import synthetic as S
     from dana_amd.graphs import GraphedDAnA
