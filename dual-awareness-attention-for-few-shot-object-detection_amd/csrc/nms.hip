@@ -126,11 +126,6 @@ nms_mask_kernel(const float4* __restrict__ boxes, unsigned long long* __restrict
   }
 }
 
-__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
-  unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
-  unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
-  return ((unsigned long long)hi << 32) | lo;
-}
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
   return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);

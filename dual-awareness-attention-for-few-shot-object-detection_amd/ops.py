@@ -322,7 +322,8 @@ def proposal_target_layer(rois, gt_boxes, rois_per_image, fg_rois_per_image, fg_
 
 def anchor_target_prepare(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_stride, negative_overlap,
                           positive_overlap, counts=None):
-    """_AnchorTargetLayer up to the un-subsampled labels (anchor_target_layer.py:48-136): one HIP launch -> handle with
+    """_AnchorTargetLayer up to the un-subsampled labels (anchor_target_layer.py:48-136): one C call (IoU / labels /
+    ordered lists: three multi-workgroup launches) -> handle with
     labels, max overlaps, argmax, ordered fg / bg lists and their counts [B,2] on the device"""
     gt_boxes = _chk(gt_boxes.contiguous(), "gt_boxes")
     im_info = _chk(im_info.contiguous(), "im_info")
@@ -461,7 +462,7 @@ def anchor_target_apply_draws(h, drawn, lay):
 
 def anchor_target_assign(gt_boxes, im_info, base_anchors, feat_h, feat_w, feat_stride, negative_overlap,
                          positive_overlap, rpn_batchsize, fg_fraction, device_rng=None):
-    """_AnchorTargetLayer (anchor_target_layer.py:48-193) up to the sampled labels: one HIP launch, one D2H
+    """_AnchorTargetLayer (anchor_target_layer.py:48-193) up to the sampled labels: one C call, one D2H
     read of the fg/bg counts, the reference's np.random.permutation draws (:137-156), one scatter launch.
     Returns a dict consumed by rpn_losses() / anchor_target_outputs()."""
     import numpy as np
