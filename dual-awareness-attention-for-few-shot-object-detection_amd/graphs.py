@@ -270,4 +270,9 @@ class GraphedTrainer:
             for fb, i in buckets:
                 works.append(fb.reduce_bucket(i))
         tr.steps += 1
+        # the fused SGD wrote the weights through raw pointers (no tensor._version bump) and the graph re-derived its OWN
+        # packed / Winograd / two-segment copies at the start of the replay, i.e. before this step's update: an eager
+        # forward that follows (per-epoch eval, Trainer.step) must re-derive them from the live weights
+        self.model._epoch += 1
+        self.model._plan = None
         return self.outputs

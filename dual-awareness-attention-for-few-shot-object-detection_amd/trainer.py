@@ -262,9 +262,14 @@ class Trainer:
                             "exp_avg_sq": sq[n].detach().clone().contiguous()}
             else:
                 state[i] = {"momentum_buffer": mom[n].detach().clone().contiguous()}
-            g = {"params": [i], "lr": self.lr * mult[n][0], "weight_decay": mult[n][1]}
+            # full torch.optim groups (every key SGD / Adam's step() reads), so that the reference's resume path
+            # (train.py:92-101: optimizer.load_state_dict(checkpoint['optimizer'])) can step on the exported dict
+            g = {"params": [i], "lr": self.lr * mult[n][0], "weight_decay": mult[n][1], "maximize": False, "foreach": None,
+                 "differentiable": False, "fused": None}
             if self.optimizer == "sgd":
-                g["momentum"] = self.momentum
+                g.update(momentum=self.momentum, dampening=0, nesterov=False)
+            else:
+                g.update(betas=(0.9, 0.999), eps=1e-8, amsgrad=False, capturable=False, decoupled_weight_decay=False)
             groups.append(g)
         return {"state": state if self.steps else {}, "param_groups": groups}
 

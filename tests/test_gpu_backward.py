@@ -326,6 +326,15 @@ def test_trainer_resumes_from_a_torch_optim_checkpoint(dev):
     for i, g in enumerate(ck_opt["param_groups"]):
         assert abs(exported["param_groups"][i]["lr"] - g["lr"]) < 1e-12
         assert float((exported["state"][i]["momentum_buffer"] - ck_opt["state"][i]["momentum_buffer"]).abs().max()) == 0.0
+    # the export must be something torch.optim can load AND step on (train.py:92-101 resume path): full param groups
+    for kind, ex in (("sgd", exported), ("adam", Trainer(build(), 0.1, optimizer="adam").torch_optim_state_dict())):
+        ps = [torch.nn.Parameter(torch.zeros_like(p_)) for p_ in mb.parameters() if p_.requires_grad]
+        groups = [{"params": [p_]} for p_ in ps]
+        o2 = torch.optim.SGD(groups, lr=0.1, momentum=0.9) if kind == "sgd" else torch.optim.Adam(groups, lr=0.1)
+        o2.load_state_dict(ex)
+        for p_ in ps:
+            p_.grad = torch.ones_like(p_)
+        o2.step()
     np.random.seed(2)
     tb.step(*inputs)
     torch.cuda.synchronize()

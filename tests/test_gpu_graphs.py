@@ -161,6 +161,19 @@ def test_graphed_training_iteration_equals_trainer_step(dev, rccl):
         for a, b in zip([float(x) for x in out[3:7]], ref_losses):
             assert abs(a - b) <= 1e-4 * max(1.0, abs(b))
         assert t1.steps == 5
+        # an EAGER forward after graphed training must see the updated weights (the graphs own their derived copies, the
+        # eager path's packed / Winograd / two-segment caches have to be re-derived): eval forward of both twins
+        m0.eval(), m1.eval()
+        ev = [t.to(dev) for t in S.episode_inputs(1, 1, 2, 160, 224, seed=6)]
+        with torch.no_grad():
+            e0, e1 = m0(*ev), m1(*ev)
+        torch.cuda.synchronize()
+        assert float((e0[1] - e1[1]).abs().max()) <= 1e-4 and float((e0[2] - e1[2]).abs().max()) <= 1e-4
+        from dana_amd import ops
+        live = ops.pack_conv_weight(m1.RCNN_rpn.RPN_Conv.weight)  # (the eager plan's copy is the LIVE weight's, bit for bit)
+        assert torch.equal(m1._get_plan()["rpn_conv_w"], live)
+        blk = m1.RCNN_base[6][1]
+        assert torch.equal(m1._get_plan()["layers"][2][1]["c1"]["w"], ops.pack_conv_weight(blk.conv1.weight))
     finally:
         if rccl:
             dist.destroy_process_group()
