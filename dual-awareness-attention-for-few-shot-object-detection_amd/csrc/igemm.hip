@@ -383,6 +383,56 @@ __device__ __forceinline__ void split3(const float4& v, uint2& h, uint2& m, uint
   l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
 }
 
+// Issue schedule of one K-step of the split kernel. Everything that is not an MFMA is cut into micro-items of one or two
+// INDEPENDENT instructions and dealt out over the NM gaps between the step's MFMAs so that every gap carries the same
+// number of issue slots (the 8-pass MFMA hides about five; a wave alone on its SIMD -- a launch's last round, a
+// tile-starved layer -- has nothing else to cover a gap that carries more):
+//   kind 0  one half of a global load: [compare + select] / [load + offset step]            2 x NF items, weight 2
+//   kind 1  one fragment read (ds_read_b128) of the NEXT step's operands                    NR items, weight 1
+//   kind 2  one thirteenth of a float4's three-way split: H01 H23 R01 R23 M01 M23 L01 L23 (two elements each, so
+//           that consecutive instructions never depend on each other), PA PB PC (the packs), W1 W2 (staging writes)
+// The loads go into the first third of the step (their data is split one step later, filters first), the reads are
+// spread evenly, the split fills the rest; an item's gap is its cumulative issue weight scaled to NM.
+template <int NM, int NF, int NR>
+struct StepSched {
+  static constexpr int NCV = 13 * NF, NLH = 2 * NF, NIT = NCV + NR + NLH;
+  // The step's ONE barrier sits behind MFMA number SB, not at the step boundary: it orders the LDS traffic of step t
+  // (staging writes of tile t+2, fragment reads of tile t+1) against the LDS traffic of step t+1, and the MFMAs of
+  // step t+1 read registers only. So the first SB MFMAs of a step run while the previous step's last staging writes
+  // drain, every wave reaches the barrier with lgkmcnt already at zero, and the matrix pipe does not idle through an
+  // LDS round trip per step (with one wave per SIMD that was a third of the step: tools/ubench/split_loop.hip).
+  // All LDS items of a step are placed in gaps >= SB.
+  static constexpr int SB = NM >= 24 ? 4 : (NM >= 12 ? 3 : 1);
+  int kind[NIT], idx[NIT], gap[NIT];
+};
+template <int NM, int NF, int NR>
+constexpr StepSched<NM, NF, NR> make_step_sched() {
+  using S = StepSched<NM, NF, NR>;
+  S s{};
+  int w[S::NIT] = {};
+  int n = 0, r = 0, l = 0;
+  for (int i = 0; i < S::NCV; ++i) {
+    while (l < S::NLH && l * S::NCV <= 3 * i * S::NLH) { s.kind[n] = 0; s.idx[n] = l++; w[n++] = 2; }
+    while (r < NR && i >= 11 && r * (S::NCV - 11) <= (i - 11) * NR) { s.kind[n] = 1; s.idx[n] = r++; w[n++] = 1; }
+    s.kind[n] = 2; s.idx[n] = i; w[n++] = (i % 13 == 12) ? 1 : 2;
+  }
+  while (l < S::NLH) { s.kind[n] = 0; s.idx[n] = l++; w[n++] = 2; }
+  while (r < NR) { s.kind[n] = 1; s.idx[n] = r++; w[n++] = 1; }
+  int total = 0;
+  for (int i = 0; i < S::NIT; ++i) total += w[i];
+  int cum = 0;
+  for (int i = 0; i < S::NIT; ++i) {
+    const int g = (int)((long)cum * NM / total);
+    s.gap[i] = g < NM ? g : NM - 1;
+    const bool lds = s.kind[i] == 1 || (s.kind[i] == 2 && s.idx[i] % 13 >= 11);
+    if (lds && s.gap[i] < S::SB) s.gap[i] = S::SB;
+    cum += w[i];
+  }
+  return s;
+}
+template <int NM, int NF, int NR>
+inline constexpr StepSched<NM, NF, NR> kStepSched = make_step_sched<NM, NF, NR>();
+
 template <int BM, int BN, int STEM>
 __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_split_kernel(IgemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
@@ -579,10 +629,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   constexpr int NM = 6 * TM * TN;  // MFMAs per K-step
   constexpr int NF = RA + RB;      // float4s loaded / split per thread per K-step
   constexpr int NR = 3 * (TM + TN);  // fragment reads per K-step
-  constexpr int I_LD = 1;                  // items [0, I_LD): step scalars; then NF loads
-  constexpr int I_RD = I_LD + NF;          // then NR fragment reads (one item each)
-  constexpr int I_CV = I_RD + NR;          // then 7 per float4: e0 e1 P01 e2 e3 P23 W
-  constexpr int NI = I_CV + 7 * NF;
+  using SCH = StepSched<NM, NF, NR>;        // the step's issue schedule (make_step_sched)
   const int nk = (p.K + SBK - 1) / SBK;
 
   u32x4 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];  // fragments as raw dwords (8 bf16 each)
@@ -620,7 +667,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   __syncthreads();
 
   // iteration t: MFMAs on F_cur (tile t); reads tile t+1 from LDS[(t+1)&1] into F_nxt; splits R_cv (tile t+2) into
-  // LDS[t&1]; loads tile t+3 into R_ld
+  // LDS[t&1]; loads tile t+3 into R_ld (t enters as its parity)
   auto k_step = [&](int t, const u32x4(&fa)[3][TM], const u32x4(&fb)[3][TN], u32x4(&na)[3][TM], u32x4(&nb)[3][TN],
                     const float4(&cv_a)[RA], const float4(&cv_b)[RB], float4(&ld_a)[RA], float4(&ld_b)[RB]) {
     const int bw_ = t & 1, br_ = bw_ ^ 1;
@@ -631,7 +678,9 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
     constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
     unsigned hb[NF][4], mb[NF][4], lb[NF][4];
+    float r1[NF][4];
     uint2 hp[NF], mp[NF], lp[NF];
+    unsigned ld_off[NF];
     next_tap();  // (scalar branch, before the fenced stream)
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, NM>([&](auto qc) {
@@ -639,71 +688,100 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
       constexpr int pq = q / (TM * TN), ti = (q / TN) % TM, tj = q % TN;
       acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[pq]][ti]),
                                                             __builtin_bit_cast(bf16x8, fb[PB[pq]][tj]), acc[ti][tj], 0, 0, 0);
-      static_for<0, NI>([&](auto ic) {
+      asm volatile("" : "+a"(acc[ti][tj]));  // (the MFMA opens its gap: the items below are issued in its shadow)
+      if constexpr (q == SCH::SB) __syncthreads();  // (see StepSched::SB)
+      static_for<0, SCH::NIT>([&](auto ic) {
         constexpr int it = decltype(ic)::value;
-        if constexpr (it * NM / NI != q) {
-        } else if constexpr (it < I_LD) {
-        } else if constexpr (it < I_RD) {
+        constexpr int kind = kStepSched<NM, NF, NR>.kind[it], ix = kStepSched<NM, NF, NR>.idx[it];
+        if constexpr (kStepSched<NM, NF, NR>.gap[it] != q) {
+        } else if constexpr (kind == 0) {
           // filters first: they are L2 hits and in front of the in-order load counter, the activation rows (possible
           // HBM misses) behind them -- and the split below takes the filters first, so an activation row has until the
-          // last third of the NEXT step to land
-          constexpr int f = it - I_LD;
-          if constexpr (f < RB) load_b(f < RB ? f : 0, ld_b[f < RB ? f : 0]);
-          else load_a(f < RB ? 0 : f - RB, ld_a[f < RB ? 0 : f - RB]);
-          if constexpr (f == NF - 1) {
-            lt_k0 += SBK;
-            lt_cin += SBK;
+          // middle of the NEXT step to land
+          constexpr int f = ix / 2, half = ix % 2;
+          constexpr bool isb = f < RB;
+          constexpr int j = isb ? f : f - RB;
+          if constexpr (half == 0) {
+            unsigned off = isb ? (lt_k0 < b_lim[isb ? j : 0] ? b_cur[isb ? j : 0] : OOB)
+                               : (lt_k0 < a_lim[isb ? 0 : j] ? a_cur[isb ? 0 : j] : OOB);
+            asm volatile("" : "+v"(off));
+            ld_off[f] = off;
+          } else {
+            if constexpr (isb) {
+              ld_b[isb ? j : 0] = ldg_b128(rb_src, ld_off[f]);
+              b_cur[isb ? j : 0] += SBK * 4;
+            } else {
+              ld_a[isb ? 0 : j] = ldg_b128(ra_src, ld_off[f]);
+              a_cur[isb ? 0 : j] += SBK * 4;
+            }
+            if constexpr (f == NF - 1) {
+              lt_k0 += SBK;
+              lt_cin += SBK;
+            }
           }
-        } else if constexpr (it < I_CV) {
-          constexpr int r = it - I_RD;  // planes in order h, m, l; within a plane A fragments then B fragments
+        } else if constexpr (kind == 1) {
+          constexpr int r = ix;  // planes in order h, m, l; within a plane A fragments then B fragments
           constexpr int pc = r / (TM + TN), x = r % (TM + TN);
           if constexpr (x < TM) na[pc][x < TM ? x : 0] = *(const u32x4*)(as + (pc * BM + x * 32) * SLD);
           else nb[pc][x < TM ? 0 : x - TM] = *(const u32x4*)(bs + (pc * BN + (x - TM) * 32) * SLD);
         } else {
-          constexpr int fo = (it - I_CV) / 7, r = (it - I_CV) % 7;
+          constexpr int fo = ix / 13, r = ix % 13;
           constexpr int f = fo < RB ? RA + fo : fo - RB;  // order of work: B floats, then A floats (f indexes A then B)
           const float4 v = f < RA ? cv_a[f < RA ? f : 0] : cv_b[f < RA ? 0 : f - RA];
-          if constexpr (r == 0 || r == 1 || r == 3 || r == 4) {
-            constexpr int e = r < 2 ? r : r - 1;
-            float x = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
-            asm volatile("" : "+v"(x));
-            hb[f][e] = __float_as_uint(x) & 0xffff0000u;
-            const float r1 = x - __uint_as_float(hb[f][e]);  // exact
-            mb[f][e] = __float_as_uint(r1) & 0xffff0000u;
-            lb[f][e] = __float_as_uint(r1 - __uint_as_float(mb[f][e]));  // exact; <= 8 significant bits
-            asm volatile("" : "+v"(hb[f][e]), "+v"(mb[f][e]), "+v"(lb[f][e]));
-          } else if constexpr (r == 2) {  // pack the upper halves of two dwords: bytes {S1.2, S1.3, S0.2, S0.3}
-            asm volatile("" : "+v"(hb[f][0]), "+v"(hb[f][1]));
+          constexpr int e0 = (r & 1) * 2, e1 = e0 + 1;  // the two elements of items 0..7
+          if constexpr (r < 2) {  // H: top 16 bits
+            const float x0 = e0 == 0 ? v.x : v.z, x1 = e0 == 0 ? v.y : v.w;
+            hb[f][e0] = __float_as_uint(x0) & 0xffff0000u;
+            hb[f][e1] = __float_as_uint(x1) & 0xffff0000u;
+            asm volatile("" : "+v"(hb[f][e0]), "+v"(hb[f][e1]));
+          } else if constexpr (r < 4) {  // R: x - h, exact
+            const float x0 = e0 == 0 ? v.x : v.z, x1 = e0 == 0 ? v.y : v.w;
+            r1[f][e0] = x0 - __uint_as_float(hb[f][e0]);
+            r1[f][e1] = x1 - __uint_as_float(hb[f][e1]);
+            asm volatile("" : "+v"(r1[f][e0]), "+v"(r1[f][e1]));
+          } else if constexpr (r < 6) {  // M: top 16 bits of the remainder
+            mb[f][e0] = __float_as_uint(r1[f][e0]) & 0xffff0000u;
+            mb[f][e1] = __float_as_uint(r1[f][e1]) & 0xffff0000u;
+            asm volatile("" : "+v"(mb[f][e0]), "+v"(mb[f][e1]));
+          } else if constexpr (r < 8) {  // L: exact; <= 8 significant bits
+            lb[f][e0] = __float_as_uint(r1[f][e0] - __uint_as_float(mb[f][e0]));
+            lb[f][e1] = __float_as_uint(r1[f][e1] - __uint_as_float(mb[f][e1]));
+            asm volatile("" : "+v"(lb[f][e0]), "+v"(lb[f][e1]));
+          } else if constexpr (r == 8) {  // pack the upper halves of two dwords: bytes {S1.2, S1.3, S0.2, S0.3}
             hp[f].x = __builtin_amdgcn_perm(hb[f][1], hb[f][0], 0x07060302u);
-            mp[f].x = __builtin_amdgcn_perm(mb[f][1], mb[f][0], 0x07060302u);
-            lp[f].x = __builtin_amdgcn_perm(lb[f][1], lb[f][0], 0x07060302u);
-            asm volatile("" : "+v"(hp[f].x), "+v"(mp[f].x), "+v"(lp[f].x));
-          } else if constexpr (r == 5) {
-            asm volatile("" : "+v"(hb[f][2]), "+v"(hb[f][3]));
             hp[f].y = __builtin_amdgcn_perm(hb[f][3], hb[f][2], 0x07060302u);
+            asm volatile("" : "+v"(hp[f].x), "+v"(hp[f].y));
+          } else if constexpr (r == 9) {
+            mp[f].x = __builtin_amdgcn_perm(mb[f][1], mb[f][0], 0x07060302u);
             mp[f].y = __builtin_amdgcn_perm(mb[f][3], mb[f][2], 0x07060302u);
+            asm volatile("" : "+v"(mp[f].x), "+v"(mp[f].y));
+          } else if constexpr (r == 10) {
+            lp[f].x = __builtin_amdgcn_perm(lb[f][1], lb[f][0], 0x07060302u);
             lp[f].y = __builtin_amdgcn_perm(lb[f][3], lb[f][2], 0x07060302u);
-            asm volatile("" : "+v"(hp[f].y), "+v"(mp[f].y), "+v"(lp[f].y));
+            asm volatile("" : "+v"(lp[f].x), "+v"(lp[f].y));
           } else {
             unsigned* w = f < RA ? aw + 64 * f * SLD : bw + 64 * (f - RA) * SLD;
             constexpr int rows = f < RA ? BM : BN;
-            *(uint2*)(w + 0 * rows * SLD) = hp[f];
-            *(uint2*)(w + 1 * rows * SLD) = mp[f];
-            *(uint2*)(w + 2 * rows * SLD) = lp[f];
+            if constexpr (r == 11) {
+              *(uint2*)(w + 0 * rows * SLD) = hp[f];
+              *(uint2*)(w + 1 * rows * SLD) = mp[f];
+            } else {
+              *(uint2*)(w + 2 * rows * SLD) = lp[f];
+            }
           }
         }
       });
       __builtin_amdgcn_sched_barrier(0);
     });
-    __syncthreads();
   };
   // always whole pairs of K-steps (an odd count runs one extra all-zero step): no conditional between the two halves,
   // so the register sets swap roles without copies
   const unsigned long long t_loop = p.trace ? __builtin_readcyclecounter() : 0ull;
   for (int t = 0; t < nk; t += 2) {
-    k_step(t, fa0, fb0, fa1, fb1, ra0, rb0, ra1, rb1);
-    k_step(t + 1, fa1, fb1, fa0, fb0, ra1, rb1, ra0, rb0);
+    k_step(0, fa0, fb0, fa1, fb1, ra0, rb0, ra1, rb1);
+    k_step(1, fa1, fb1, fa0, fb0, ra1, rb1, ra0, rb0);
   }
+  __syncthreads();  // (the last steps' staging writes / fragment reads vs the epilogue's use of the same LDS)
   const unsigned long long t_loop_end = p.trace ? __builtin_readcyclecounter() : 0ull;
 
   // ---- epilogue through LDS (same C/D map as the f32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
