@@ -70,6 +70,7 @@ struct IgemmParams {
   // its (strided) 1x1 downsample conv as ONE contraction over the concatenated channels (resnet.py:84-100)
   const float* A2;
   int lda2, IH2, IW2, stride2, K1;
+  int IH21, IW21, pix21;  // A2's geometry for rows of the second geometry segment (image size, first pixel)
   unsigned a2_bytes;
   unsigned long long* trace;  // debug (dana_set_igemm_trace): per block {start, first MFMA, loop end, end} in 100 MHz ticks + HW id
 };
@@ -519,8 +520,10 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     a_off[j] = STEM ? (unsigned)((pix + iw0 + c4) * lda4) : (unsigned)((pix + iw0) * lda4 + c4 * 16);
     a_mask[j] = mask;
     a_dseg[j] = s1 ? (p.IW1 - p.IW) * lda4 : 0;
-    a_off2[j] = (!STEM && p.A2 && ok) ? (unsigned)((((long)img * p.IH2 + oh * p.stride2) * p.IW2 + ow * p.stride2) * p.lda2 * 4 + c4 * 16)
-                                     : OOB;
+    a_off2[j] = (!STEM && p.A2 && ok)
+                    ? (unsigned)(((s1 ? p.pix21 : 0) + ((long)img * (s1 ? p.IH21 : p.IH2) + oh * p.stride2) * (s1 ? p.IW21 : p.IW2) +
+                                  ow * p.stride2) * p.lda2 * 4 + c4 * 16)
+                    : OOB;
   }
   unsigned b_cur[RB];  // byte offset of this lane's float4 of the current K-step in its filter row
   int b_lim[RB];
@@ -1210,20 +1213,26 @@ int dana_conv2d_nhwc_dual(const float* input, const float* weight, float* out0, 
                      res0_stride, res1_stride, flags, stream);
 }
 
-int dana_conv1x1_cat2_nhwc(const float* a0, long a0_pix_stride, int k0, const float* a1, long a1_pix_stride, int k1,
-                           int batch, int h1, int w1, int stride1, const float* weight, float* output,
-                           const float* scale, const float* shift, const float* residual, long out_pix_stride,
-                           long res_pix_stride, int cout, int flags, dana_stream_t stream) {
-  const char* who = "dana_conv1x1_cat2_nhwc";
-  DANA_CHECK_ARG(batch >= 0 && h1 > 0 && w1 > 0 && stride1 > 0 && k0 > 0 && k1 > 0 && cout > 0, "%s: bad shape", who);
-  if (batch == 0) return DANA_OK;
-  DANA_CHECK_ARG(a0 && a1 && weight && output, "%s: null pointer", who);
+static int cat2_impl(const char* who, const float* a0, long a0_pix_stride, int k0, const float* a1, long a1_pix_stride,
+                     int k1, int n0, int h0, int w0, int n1, int h1, int w1, int stride1, const float* weight, float* out0,
+                     float* out1, const float* scale, const float* shift, const float* residual, long out0_pix_stride,
+                     long out1_pix_stride, long res_pix_stride, int cout, int flags, dana_stream_t stream) {
+  DANA_CHECK_ARG(n0 >= 0 && n1 >= 0 && stride1 > 0 && k0 > 0 && k1 > 0 && cout > 0, "%s: bad shape", who);
+  DANA_CHECK_ARG((n0 == 0 || (h0 > 0 && w0 > 0)) && (n1 == 0 || (h1 > 0 && w1 > 0)), "%s: bad image size", who);
+  if (n0 + n1 == 0) return DANA_OK;
+  if (n0 == 0)  // only the second group is populated: make it the first
+    return cat2_impl(who, a0, a0_pix_stride, k0, a1, a1_pix_stride, k1, n1, h1, w1, 0, 0, 0, stride1, weight, out1, nullptr,
+                     scale, shift, residual, out1_pix_stride, 0, res_pix_stride, cout, flags, stream);
+  DANA_CHECK_ARG(a0 && a1 && weight && out0 && (n1 == 0 || out1), "%s: null pointer", who);
+  DANA_CHECK_ARG(!(residual && n1), "%s: residual only with one image group", who);
   DANA_CHECK_ARG(k0 % SBK == 0 && k1 % SBK == 0, "%s: k0 and k1 must be multiples of %d", who, SBK);
   DANA_CHECK_ARG(dana_get_mfma_mode() != 0, "%s: needs the split kernel (dana_set_mfma_mode != 0)", who);
-  const int oh = (h1 - 1) / stride1 + 1, ow = (w1 - 1) / stride1 + 1;
+  const int oh0 = (h0 - 1) / stride1 + 1, ow0 = (w0 - 1) / stride1 + 1;
+  const int oh1 = n1 ? (h1 - 1) / stride1 + 1 : 0, ow1 = n1 ? (w1 - 1) / stride1 + 1 : 0;
   const long lda0 = a0_pix_stride > 0 ? a0_pix_stride : k0, lda1 = a1_pix_stride > 0 ? a1_pix_stride : k1;
   DANA_CHECK_ARG(lda0 % 4 == 0 && lda0 >= k0 && lda1 % 4 == 0 && lda1 >= k1, "%s: bad pixel stride", who);
-  const long a0_bytes = (long)batch * oh * ow * lda0 * 4, a1_bytes = (long)batch * h1 * w1 * lda1 * 4;
+  const long m0 = (long)n0 * oh0 * ow0, m1 = (long)n1 * oh1 * ow1;
+  const long a0_bytes = (m0 + m1) * lda0 * 4, a1_bytes = ((long)n0 * h0 * w0 + (long)n1 * h1 * w1) * lda1 * 4;
   const long b_bytes = (long)cout * (k0 + k1) * 4;
   DANA_CHECK_ARG(a0_bytes < (long)OOB && a1_bytes < (long)OOB && b_bytes < (long)OOB, "%s: operand spans >= 2 GiB", who);
   DANA_CHECK_ARG(((uintptr_t)a0 & 15) == 0 && ((uintptr_t)a1 & 15) == 0 && ((uintptr_t)weight & 15) == 0,
@@ -1232,13 +1241,23 @@ int dana_conv1x1_cat2_nhwc(const float* a0, long a0_pix_stride, int k0, const fl
   memset(&p, 0, sizeof(p));
   p.A = a0;
   p.Bw = weight;
-  p.C = output;
+  p.C = out0;
   p.scale = scale;
   p.shift = shift;
   p.residual = residual;
-  p.IH = p.OH = oh;
-  p.IW = p.OW = ow;
-  p.M = p.M0 = batch * oh * ow;
+  p.IH = p.OH = oh0;
+  p.IW = p.OW = ow0;
+  p.M0 = (int)m0;
+  p.M = (int)(m0 + m1);
+  if (n1) {  // second image group: a0's rows continue at m0, a1's pixels behind group 0's
+    p.IH1 = p.OH1 = oh1;
+    p.IW1 = p.OW1 = ow1;
+    p.pix1 = (int)m0;
+    p.C1 = out1;
+    p.IH21 = h1;
+    p.IW21 = w1;
+    p.pix21 = n0 * h0 * w0;
+  }
   p.N = cout;
   p.KH = p.KW = 1;
   p.stride = 1;
@@ -1251,14 +1270,14 @@ int dana_conv1x1_cat2_nhwc(const float* a0, long a0_pix_stride, int k0, const fl
   p.b_bytes = (unsigned)b_bytes;
   p.A2 = a1;
   p.lda2 = (int)lda1;
-  p.IH2 = h1;
-  p.IW2 = w1;
+  p.IH2 = h0;
+  p.IW2 = w0;
   p.stride2 = stride1;
   p.K1 = k1;
   p.a2_bytes = (unsigned)a1_bytes;
-  p.ldc = out_pix_stride > 0 ? out_pix_stride : cout;
+  p.ldc = out0_pix_stride > 0 ? out0_pix_stride : cout;
   p.ldr = res_pix_stride > 0 ? res_pix_stride : cout;
-  p.ldc1 = p.ldc;
+  p.ldc1 = n1 ? (out1_pix_stride > 0 ? out1_pix_stride : cout) : p.ldc;
   p.ldr1 = p.ldr;
   p.alpha = 1.f;
   p.relu = (flags & DANA_EPI_RELU) ? 1 : 0;
@@ -1266,6 +1285,22 @@ int dana_conv1x1_cat2_nhwc(const float* a0, long a0_pix_stride, int k0, const fl
   run(p, 1, 0, (hipStream_t)stream);
   DANA_CHECK_LAUNCH(who);
   return DANA_OK;
+}
+
+int dana_conv1x1_cat2_nhwc(const float* a0, long a0_pix_stride, int k0, const float* a1, long a1_pix_stride, int k1,
+                           int batch, int h1, int w1, int stride1, const float* weight, float* output,
+                           const float* scale, const float* shift, const float* residual, long out_pix_stride,
+                           long res_pix_stride, int cout, int flags, dana_stream_t stream) {
+  return cat2_impl("dana_conv1x1_cat2_nhwc", a0, a0_pix_stride, k0, a1, a1_pix_stride, k1, batch, h1, w1, 0, 0, 0, stride1,
+                   weight, output, nullptr, scale, shift, residual, out_pix_stride, 0, res_pix_stride, cout, flags, stream);
+}
+
+int dana_conv1x1_cat2_nhwc_dual(const float* a0, long a0_pix_stride, int k0, const float* a1, long a1_pix_stride, int k1,
+                                int n0, int h0, int w0, int n1, int h1, int w1, int stride1, const float* weight,
+                                float* out0, float* out1, const float* scale, const float* shift, long out0_pix_stride,
+                                long out1_pix_stride, int cout, int flags, dana_stream_t stream) {
+  return cat2_impl("dana_conv1x1_cat2_nhwc_dual", a0, a0_pix_stride, k0, a1, a1_pix_stride, k1, n0, h0, w0, n1, h1, w1,
+                   stride1, weight, out0, out1, scale, shift, nullptr, out0_pix_stride, out1_pix_stride, 0, cout, flags, stream);
 }
 
 int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, const float* shift,

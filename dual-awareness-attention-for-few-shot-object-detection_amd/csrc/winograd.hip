@@ -207,7 +207,10 @@ wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int cout
 // one lane = (tile of 4x4 outputs, 4 channels): V[36][tiles][C]
 __global__ void __launch_bounds__(256)
 wino4_input_kernel(const float* __restrict__ in, float* __restrict__ V, int H, int W, int C4, int th, int tw,
-                   long tiles, int lda, unsigned in_bytes) {
+                   long tiles, int lda, unsigned in_bytes, long plane_tiles = 0, long tile_off = 0) {
+  // plane_tiles / tile_off: this launch fills tiles [tile_off, tile_off + tiles) of planes that hold plane_tiles tiles
+  // (two image groups -- query and support batch -- share one batched plane GEMM); 0 = the planes are this launch's own
+  if (plane_tiles == 0) plane_tiles = tiles;
   // 32-bit index math (tiles * C4 < 2^31 is checked by the host): the 64-bit divides cost more than the transform
   const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (unsigned)(tiles * C4)) return;
@@ -235,8 +238,8 @@ wino4_input_kernel(const float* __restrict__ in, float* __restrict__ V, int H, i
 #pragma unroll
     for (int r = 0; r < 6; ++r) tm[r][c] = o[r];
   }
-  const long plane = tiles * (long)C4;  // in float4 units
-  float4* out = (float4*)V + t * C4 + c4;
+  const long plane = plane_tiles * (long)C4;  // in float4 units
+  float4* out = (float4*)V + (tile_off + t) * C4 + c4;
 #pragma unroll
   for (int r = 0; r < 6; ++r) {  // (.) B  ==  rows of B^T applied to the row vector
     float4 o[6];
@@ -259,17 +262,18 @@ __device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&o)[4]) {
 __global__ void __launch_bounds__(256)
 wino4_output_kernel(const float* __restrict__ M, float* __restrict__ out, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ mask, long ldm, int H, int W, int N4,
-                    int th, int tw, long tiles, long ldc, int relu) {
+                    int th, int tw, long tiles, long ldc, int relu, long plane_tiles = 0, long tile_off = 0) {
   const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;  // (32-bit index math, see wino4_input_kernel)
   if (idx >= (unsigned)(tiles * N4)) return;
+  if (plane_tiles == 0) plane_tiles = tiles;
   const unsigned t = idx / (unsigned)N4;
   const int n4 = (int)(idx - t * (unsigned)N4);
   const unsigned tr = t / (unsigned)tw;
   const int j = (int)(t - tr * (unsigned)tw);
   const long img = (long)(tr / (unsigned)th);
   const int i = (int)(tr - (unsigned)img * (unsigned)th);
-  const long plane = tiles * (long)N4;
-  const float4* mp = (const float4*)M + (long)idx;
+  const long plane = plane_tiles * (long)N4;
+  const float4* mp = (const float4*)M + tile_off * N4 + (long)idx;
   float4 s[4][6];  // A^T m, column by column
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
@@ -565,6 +569,56 @@ int dana_conv3x3_winograd4_nhwc_masked(const float* input, const float* u, float
                                                                       p.th, p.tw, p.tiles, ldc,
                                                                       (flags & DANA_EPI_RELU) ? 1 : 0);
   DANA_CHECK_LAUNCH("dana_conv3x3_winograd4_nhwc(output transform)");
+  return DANA_OK;
+}
+
+size_t dana_conv3x3_winograd4_dual_workspace_bytes(int n0, int h0, int w0, int n1, int h1, int w1, int cin, int cout) {
+  if (n0 < 0 || n1 < 0 || cin <= 0 || cout <= 0) return 0;
+  const long t0 = n0 > 0 ? wino_plan(n0, h0, w0, cin, cout, 4).tiles : 0, t1 = n1 > 0 ? wino_plan(n1, h1, w1, cin, cout, 4).tiles : 0;
+  return dana_align_up((size_t)36 * (t0 + t1) * cin * 4, 256) + dana_align_up((size_t)36 * (t0 + t1) * cout * 4, 256);
+}
+
+int dana_conv3x3_winograd4_nhwc_dual(const float* input, const float* u, float* out0, float* out1, const float* scale,
+                                     const float* shift, int n0, int h0, int w0, int n1, int h1, int w1, int cin,
+                                     int cout, long in_pix_stride, long out0_pix_stride, long out1_pix_stride, int flags,
+                                     void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  const char* who = "dana_conv3x3_winograd4_nhwc_dual";
+  DANA_CHECK_ARG(n0 > 0 && n1 > 0 && h0 > 0 && w0 > 0 && h1 > 0 && w1 > 0 && cin > 0 && cout > 0 && cin % 4 == 0 && cout % 4 == 0,
+                 "%s: bad shape", who);
+  DANA_CHECK_ARG(input && u && out0 && out1, "%s: null pointer", who);
+  const long lda = in_pix_stride > 0 ? in_pix_stride : cin;
+  const long ldc0 = out0_pix_stride > 0 ? out0_pix_stride : cout, ldc1 = out1_pix_stride > 0 ? out1_pix_stride : cout;
+  DANA_CHECK_ARG(lda % 4 == 0 && ldc0 % 4 == 0 && ldc1 % 4 == 0 && ((uintptr_t)input & 15) == 0 && ((uintptr_t)out0 & 15) == 0 &&
+                     ((uintptr_t)out1 & 15) == 0, "%s: strides / pointers must be 16-byte aligned", who);
+  const long in0_bytes = (long)n0 * h0 * w0 * lda * 4, in1_bytes = (long)n1 * h1 * w1 * lda * 4;
+  DANA_CHECK_ARG(in0_bytes < (long)OOB && in1_bytes < (long)OOB, "%s: input span >= 2 GiB; split the batch", who);
+  const WinoPlan p0 = wino_plan(n0, h0, w0, cin, cout, 4), p1 = wino_plan(n1, h1, w1, cin, cout, 4);
+  const long T = p0.tiles + p1.tiles;
+  const size_t v_bytes = dana_align_up((size_t)36 * T * cin * 4, 256), need = dana_conv3x3_winograd4_dual_workspace_bytes(n0, h0, w0, n1, h1, w1, cin, cout);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("%s: workspace %zu < %zu", who, workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* V = (float*)workspace;                     // [36][T][cin]: group 0's tiles, then group 1's
+  float* M = (float*)((char*)workspace + v_bytes);  // [36][T][cout]
+  const int C4 = cin / 4, N4 = cout / 4;
+  DANA_CHECK_ARG(T * (long)(C4 > N4 ? C4 : N4) < (1L << 31), "%s: too many tiles x channels", who);
+  const float* in1 = input + (long)n0 * h0 * w0 * lda;
+  wino4_input_kernel<<<dana_ceil_div(p0.tiles * C4, 256), 256, 0, s>>>(input, V, h0, w0, C4, p0.th, p0.tw, p0.tiles, (int)lda,
+                                                                      (unsigned)in0_bytes, T, 0);
+  wino4_input_kernel<<<dana_ceil_div(p1.tiles * C4, 256), 256, 0, s>>>(in1, V, h1, w1, C4, p1.th, p1.tw, p1.tiles, (int)lda,
+                                                                      (unsigned)in1_bytes, T, p0.tiles);
+  DANA_CHECK_LAUNCH("dana_conv3x3_winograd4_nhwc_dual(input transforms)");
+  int rc = dana_gemm_nt(V, u, M, nullptr, nullptr, nullptr, (int)T, cout, cin, cin, cin, cout, 0, 36, T * cin,
+                        (long)cout * cin, T * cout, 1.f, 0, stream);
+  if (rc) return rc;
+  const int relu = (flags & DANA_EPI_RELU) ? 1 : 0;
+  wino4_output_kernel<<<dana_ceil_div(p0.tiles * N4, 256), 256, 0, s>>>(M, out0, scale, shift, nullptr, 0, h0, w0, N4, p0.th,
+                                                                       p0.tw, p0.tiles, ldc0, relu, T, 0);
+  wino4_output_kernel<<<dana_ceil_div(p1.tiles * N4, 256), 256, 0, s>>>(M, out1, scale, shift, nullptr, 0, h1, w1, N4, p1.th,
+                                                                       p1.tw, p1.tiles, ldc1, relu, T, p0.tiles);
+  DANA_CHECK_LAUNCH("dana_conv3x3_winograd4_nhwc_dual(output transforms)");
   return DANA_OK;
 }
 

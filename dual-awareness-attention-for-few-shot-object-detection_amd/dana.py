@@ -173,7 +173,7 @@ class DAnARCNN(nn.Module):
         self.query_sequential = False  # chunks of the query batch one after the other on the main stream
         # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
         # True: query + support batches share every trunk launch (dana_conv2d_nhwc_dual)
-        self.merge_trunk = False
+        self.merge_trunk = __import__('os').environ.get('DANA_MERGE_TRUNK', '1') != '0'  # query + support batch in one launch per trunk conv
         self.nms_inclusive = False  # False: IoU > thr as the reference CUDA op (nms.cu:60); True: CPU op (>=)
         dim_in = self.pool_feat_dim
 
@@ -424,9 +424,13 @@ class DAnARCNN(nn.Module):
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         return h, w
 
-    def _rcnn_base_dual(self, im, sup_ims, plan, dev):
-        """RCNN_base on the query batch AND the support batch with one launch per layer (dana.py:98,100):
-        -> (corr [B*h*w][2048] with base_feat in channels 0..1023, (h, w), sup [Ns*sh*sw][1024], (sh, sw))."""
+    def _rcnn_base_dual(self, im, sup_ims, plan, dev, save_q=None, save_s=None):
+        """RCNN_base on the query batch AND the support batch (dana.py:98,100: the same weights) with ONE launch per conv:
+        every activation is one buffer [query pixels | support pixels][channels]; the 1x1 / stride-1 convs see a plain
+        GEMM over all rows, the strided / 3x3 / stem convs carry the two image geometries (`*_dual` entry points), the
+        Winograd 3x3s run two input transforms, one batched plane GEMM over all tiles and two output transforms.
+        -> (corr [B*h*w][2048] with base_feat in channels 0..1023, (h, w), sup [Ns*sh*sw][1024], (sh, sw));
+        save_q / save_s receive the per-block dicts of `_bottleneck` (views of the merged buffers)."""
         n0, _, H0, W0 = im.shape
         n1, _, H1, W1 = sup_ims.shape
         x4 = torch.empty(((n0 * H0 * W0 + n1 * H1 * W1), 4), dtype=torch.float32, device=dev)
@@ -436,40 +440,58 @@ class DAnARCNN(nn.Module):
         x, _, g0, g1 = ops.conv2d_nhwc_dual(x4, n0, H0, W0, n1, H1, W1, 4, st["w"], 64, 7, 7, 2, 3, scale=st["scale"],
                                             shift=st["shift"], relu=True, stem=True)
         p0, p1 = ops.maxpool_out_size(*g0), ops.maxpool_out_size(*g1)
-        m0 = n0 * p0[0] * p0[1]
-        xp = torch.empty((m0 + n1 * p1[0] * p1[1], 64), dtype=torch.float32, device=dev)
+        xp = torch.empty((n0 * p0[0] * p0[1] + n1 * p1[0] * p1[1], 64), dtype=torch.float32, device=dev)
         ops.maxpool3x3s2_ceil(x, n0, g0[0], g0[1], 64, out=xp)
-        ops.maxpool3x3s2_ceil(x[n0 * g0[0] * g0[1]:], n1, g1[0], g1[1], 64, out=xp[m0:])
+        ops.maxpool3x3s2_ceil(x[n0 * g0[0] * g0[1]:], n1, g1[0], g1[1], 64, out=xp[n0 * p0[0] * p0[1]:])
         x, g0, g1 = xp, p0, p1
+        split = ops.get_mfma_mode() != 0
+        fuse_ds = getattr(self, "fuse_downsample", True) and split
 
-        def conv(xin, gin0, gin1, c, relu, res=None, out0=None, out1=None, s0=0, s1=0):
-            mi0 = n0 * gin0[0] * gin0[1]
-            r0, r1 = (res, res[mi0_res[0]:]) if res is not None else (None, None)
-            return ops.conv2d_nhwc_dual(xin, n0, gin0[0], gin0[1], n1, gin1[0], gin1[1], c["cin"], c["w"], c["cout"],
-                                        c["k"], c["k"], c["stride"], c["pad"], scale=c["scale"], shift=c["shift"],
-                                        res0=r0, res1=r1, relu=relu, out0=out0, out1=out1, out0_stride=s0,
-                                        out1_stride=s1)
+        def conv(xin, gi0, gi1, c, relu, res=None, out0=None, out1=None, s0=0, s1=0):
+            """-> (merged output or out0, (oh0, ow0), (oh1, ow1))"""
+            if c.get("u") is not None and res is None and c["u"].size(0) == 36 and out0 is None:
+                return (ops.conv3x3_winograd_dual(xin, n0, gi0[0], gi0[1], n1, gi1[0], gi1[1], c["cin"], c["u"], c["cout"],
+                                                  scale=c["scale"], shift=c["shift"], relu=relu), gi0, gi1)
+            r0 = r1 = None
+            if res is not None:
+                mr = n0 * ((gi0[0] - 1) // c["stride"] + 1) * ((gi0[1] - 1) // c["stride"] + 1)
+                r0, r1 = res, res[mr:]
+            o0, _, h0, h1 = ops.conv2d_nhwc_dual(xin, n0, gi0[0], gi0[1], n1, gi1[0], gi1[1], c["cin"], c["w"], c["cout"],
+                                                 c["k"], c["k"], c["stride"], c["pad"], scale=c["scale"],
+                                                 shift=c["shift"], res0=r0, res1=r1, relu=relu, out0=out0, out1=out1,
+                                                 out0_stride=s0, out1_stride=s1)
+            return o0, h0, h1
 
-        mi0_res = [0]
         corr = sup = None
         nl = len(plan["layers"])
         for li, layer in enumerate(plan["layers"]):
             for bi, bp in enumerate(layer):
                 last = (li == nl - 1) and (bi == len(layer) - 1)
-                o1, _, h0, h1 = conv(x, g0, g1, bp["c1"], True)
-                o2, _, _, _ = conv(o1, h0, h1, bp["c2"], True)
-                if bp["ds"] is not None:
-                    res, _, _, _ = conv(x, g0, g1, bp["ds"], False)
-                else:
-                    res = x
-                mi0_res[0] = n0 * h0[0] * h0[1]
+                o1, h0, h1 = conv(x, g0, g1, bp["c1"], True)
+                o2, _, _ = conv(o1, h0, h1, bp["c2"], True)
+                m0o = n0 * h0[0] * h0[1]
+                out0 = out1 = None
+                s0 = s1 = 0
                 if last:
-                    corr = torch.empty((n0 * h0[0] * h0[1], 2048), dtype=torch.float32, device=dev)
+                    corr = torch.empty((m0o, 2048), dtype=torch.float32, device=dev)
                     sup = torch.empty((n1 * h1[0] * h1[1], 1024), dtype=torch.float32, device=dev)
-                    conv(o2, h0, h1, bp["c3"], True, res=res, out0=corr, out1=sup, s0=2048, s1=1024)
+                    out0, out1, s0, s1 = corr, sup, 2048, 1024
+                if bp.get("cat") is not None and fuse_ds:
+                    c3, ds = bp["c3"], bp["ds"]
+                    o3, _, _, _ = ops.conv1x1_cat2_dual(o2, c3["cin"], x, ds["cin"], n0, g0[0], g0[1], n1, g1[0], g1[1],
+                                                        ds["stride"], bp["cat"]["w"], bp["cat"]["shift"], c3["cout"],
+                                                        relu=True, out0=out0, out1=out1, out0_stride=s0, out1_stride=s1)
                 else:
-                    x, _, _, _ = conv(o2, h0, h1, bp["c3"], True, res=res)
-                g0, g1 = h0, h1
+                    res = conv(x, g0, g1, bp["ds"], False)[0] if bp["ds"] is not None else x
+                    o3, _, _ = conv(o2, h0, h1, bp["c3"], True, res=res, out0=out0, out1=out1, s0=s0, s1=s1)
+                if li > 0 and save_q is not None:  # (layer1 is frozen: nothing to differentiate there)
+                    mi = n0 * g0[0] * g0[1]
+                    key = "RCNN_base.%d.%d" % (4 + li, bi)
+                    save_q.append(dict(x=x[:mi], o1=o1[:m0o], o2=o2[:m0o], o3=corr if last else o3[:m0o], h1=h0[0], w1=h0[1],
+                                       n=n0, h=g0[0], w=g0[1], bp=bp, key=key, o3_ld=s0))
+                    save_s.append(dict(x=x[mi:], o1=o1[m0o:], o2=o2[m0o:], o3=sup if last else o3[m0o:], h1=h1[0], w1=h1[1],
+                                       n=n1, h=g1[0], w=g1[1], bp=bp, key=key, o3_ld=s1 if last else 0))
+                x, g0, g1 = o3, h0, h1
         return corr, g0, sup, g1
 
     # ---- forward -----------------------------------------------------------------------------------
@@ -521,8 +543,8 @@ class DAnARCNN(nn.Module):
             # everything backward.model_backward needs. The side streams of this forward are all joined into the
             # caller's stream before it returns, and each of them starts by waiting for an event of the NEXT
             # forward's caller stream, so the saved tensors are safe for a backward that runs on that stream.
-            if self.merge_trunk or self.query_streams != 1:
-                raise RuntimeError("save_for_backward needs merge_trunk=False and query_streams=1")
+            if self.query_streams != 1 and not self.merge_trunk:
+                raise RuntimeError("save_for_backward needs query_streams=1")
             ctx = self._ctx = dict(plan=plan, B=B, shot=shot, way=way, q_saved=[], s_saved=[], l4_saved=[], heads=[])
         else:
             self._ctx = None
@@ -593,7 +615,9 @@ class DAnARCNN(nn.Module):
         dq = self.rcnn_reduce_dim
         K1 = shot * L
         if self.merge_trunk:
-            corr, (fh, fw), sup, (sh_, sw_) = self._rcnn_base_dual(im_data, sup_ims, plan, dev)
+            corr, (fh, fw), sup, (sh_, sw_) = self._rcnn_base_dual(im_data, sup_ims, plan, dev,
+                                                                   save_q=ctx["q_saved"] if ctx is not None else None,
+                                                                   save_s=ctx["s_saved"] if ctx is not None else None)
             trunk_done = torch.cuda.Event()
             trunk_done.record()
             sup_stream.wait_event(trunk_done)

@@ -609,6 +609,48 @@ def conv1x1_cat2(a0, k0, a1, k1, batch, h1, w1, stride1, w_cat, shift, cout, rel
     return out, oh, ow
 
 
+def conv1x1_cat2_dual(a0, k0, a1, k1, n0, h0, w0, n1, h1, w1, stride1, w_cat, shift, cout, relu=True, out0=None,
+                      out1=None, out0_stride=0, out1_stride=0):
+    """conv1x1_cat2 over two image groups (query batch + support batch) in one launch: a0 = [M0 + M1][k0] on the output
+    grids, a1 = group 0's [n0][h0][w0][k1] pixels then group 1's. Without out0/out1 the result is ONE merged buffer.
+    -> (out0, out1, (oh0, ow0), (oh1, ow1))"""
+    _chk(a0, "a0")
+    _chk(a1, "a1")
+    oh0, ow0 = (h0 - 1) // stride1 + 1, (w0 - 1) // stride1 + 1
+    oh1, ow1 = (h1 - 1) // stride1 + 1, (w1 - 1) // stride1 + 1
+    m0, m1 = n0 * oh0 * ow0, n1 * oh1 * ow1
+    if out0 is None:
+        merged = torch.empty((m0 + m1, cout), dtype=torch.float32, device=a0.device)
+        out0, out1 = merged, merged[m0:]
+        out0_stride = out1_stride = cout
+    e0 = _prof_begin()
+    lib().call("dana_conv1x1_cat2_nhwc_dual", _p(a0), 0, k0, _p(a1), 0, k1, n0, h0, w0, n1, h1, w1, stride1, _p(w_cat),
+               _p(out0), _p(out1), None, _p(shift), out0_stride, out1_stride, cout, EPI_RELU if relu else 0, _stream())
+    m = m0 + m1
+    _prof_end(e0, ("conv1x1cat M=%d N=%d K=%d s%d", (m, cout, k0 + k1, stride1)), 2.0 * m * cout * (k0 + k1),
+              4.0 * (m * (k0 + k1) + cout * (k0 + k1) + m * cout))
+    return out0, out1, (oh0, ow0), (oh1, ow1)
+
+
+def conv3x3_winograd_dual(x, n0, h0, w0, n1, h1, w1, cin, u, cout, scale=None, shift=None, relu=False):
+    """stride-1 pad-1 3x3 conv through Winograd F(4x4,3x3) over two image groups with ONE batched plane GEMM (x: group
+    0's pixels, then group 1's) -> merged [M0 + M1][cout]"""
+    _chk(x, "x")
+    _chk(u, "u")
+    if u.size(0) != 36:
+        raise ValueError("conv3x3_winograd_dual: F(4x4,3x3) filters only")
+    m0, m1 = n0 * h0 * w0, n1 * h1 * w1
+    out = torch.empty((m0 + m1, cout), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().query("dana_conv3x3_winograd4_dual_workspace_bytes", n0, h0, w0, n1, h1, w1, cin, cout), x.device)
+    e0 = _prof_begin()
+    lib().call("dana_conv3x3_winograd4_nhwc_dual", _p(x), _p(u), _p(out), _p(out[m0:]), _p(scale), _p(shift), n0, h0, w0,
+               n1, h1, w1, cin, cout, 0, 0, 0, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
+    tiles = n0 * ((h0 + 3) // 4) * ((w0 + 3) // 4) + n1 * ((h1 + 3) // 4) * ((w1 + 3) // 4)
+    _prof_end(e0, ("wino3x3 M=%d N=%d K=%d s1", (m0 + m1, cout, 9 * cin)), 2.0 * (m0 + m1) * cout * 9 * cin,
+              4.0 * 36 * (tiles * (cin + cout) + cout * cin), executed=2.0 * 36 * tiles * cin * cout)
+    return out
+
+
 def winograd_filter_transform(w_packed, cout, cin, tile=2):
     """U of Winograd F(tile x tile, 3x3): [16][cout][cin] (tile 2) or [36][cout][cin] (tile 4)"""
     _chk(w_packed, "w_packed")

@@ -179,6 +179,14 @@ int dana_conv3x3_winograd4_nhwc_masked(const float* input, const float* u, float
                                        const float* shift, const float* mask_act, int batch, int h, int w, int cin,
                                        int cout, long in_pix_stride, long out_pix_stride, long mask_pix_stride,
                                        int flags, void* workspace, size_t workspace_bytes, dana_stream_t stream);
+/* F(4x4,3x3) over TWO image groups (input: group 0's [n0][h0][w0] pixels, then group 1's [n1][h1][w1]): two input
+ * transforms, ONE batched plane GEMM over all tiles, two output transforms (resnet.py:92-94 on the query and the support
+ * batch of dana.py:98,100 with the same filters) */
+size_t dana_conv3x3_winograd4_dual_workspace_bytes(int n0, int h0, int w0, int n1, int h1, int w1, int cin, int cout);
+int dana_conv3x3_winograd4_nhwc_dual(const float* input, const float* u, float* out0, float* out1, const float* scale,
+                                     const float* shift, int n0, int h0, int w0, int n1, int h1, int w1, int cin,
+                                     int cout, long in_pix_stride, long out0_pix_stride, long out1_pix_stride, int flags,
+                                     void* workspace, size_t workspace_bytes, dana_stream_t stream);
 
 /* weight gradient of a stride-1 pad-1 3x3 conv in the F(4x4,3x3) domain: dU[36] = sum over tiles of
  * (A dY A^T)^T (B^T x B), dW = G^T dU G -- 4x fewer multiplies than dana_conv2d_wgrad_nhwc; same packed
@@ -458,6 +466,13 @@ int dana_conv1x1_cat2_nhwc(const float* a0, long a0_pix_stride, int k0, const fl
                            int batch, int h1, int w1, int stride1, const float* weight, float* output,
                            const float* scale, const float* shift, const float* residual, long out_pix_stride,
                            long res_pix_stride, int cout, int flags, dana_stream_t stream);
+/* the same over TWO image groups in one launch (query batch + support batch of one trunk layer): a0 holds group 0's
+ * output-grid rows, then group 1's; a1 group 0's [n0][h0][w0] pixels, then group 1's [n1][h1][w1]; results go to out0 /
+ * out1 with their own row strides (dana.py:98,100: RCNN_base runs on both batches with the same weights) */
+int dana_conv1x1_cat2_nhwc_dual(const float* a0, long a0_pix_stride, int k0, const float* a1, long a1_pix_stride, int k1,
+                                int n0, int h0, int w0, int n1, int h1, int w1, int stride1, const float* weight,
+                                float* out0, float* out1, const float* scale, const float* shift, long out0_pix_stride,
+                                long out1_pix_stride, int cout, int flags, dana_stream_t stream);
 /* Second half of a split-K contraction: out[m][n] = epi(alpha * sum_s partials[s][m][n]) with the same epilogue as
  * dana_gemm_nt (scale, shift, residual, DANA_EPI_RELU), summed in slice order (deterministic). The slices themselves
  * are one batched dana_gemm_nt launch whose batch strides walk K (batch_a = batch_b = K / slices). n % 4 == 0. */
