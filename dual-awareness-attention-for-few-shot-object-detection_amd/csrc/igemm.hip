@@ -71,6 +71,7 @@ struct IgemmParams {
   const float* A2;
   int lda2, IH2, IW2, stride2, K1;
   int IH21, IW21, pix21;  // A2's geometry for rows of the second geometry segment (image size, first pixel)
+  int bpre;               // Bw holds pre-split bf16 planes [ldb / 16][3][N][16] (dana_split_weight), ldb = K rounded up to 16
   unsigned a2_bytes;
   unsigned long long* trace;  // debug (dana_set_igemm_trace): per block {start, first MFMA, loop end, end} in 100 MHz ticks + HW id
 };
@@ -385,18 +386,19 @@ __device__ __forceinline__ void split3(const float4& v, uint2& h, uint2& m, uint
 }
 
 // Issue schedule of one K-step of the split kernel. Everything that is not an MFMA is cut into micro-items of one or two
-// INDEPENDENT instructions and dealt out over the NM gaps between the step's MFMAs so that every gap carries the same
-// number of issue slots (the 8-pass MFMA hides about five; a wave alone on its SIMD -- a launch's last round, a
+// INDEPENDENT instructions and dealt out over the NM gaps between the step's MFMAs so that every gap carries about the
+// same number of issue slots (the 8-pass MFMA hides about five; a wave alone on its SIMD -- a launch's last round, a
 // tile-starved layer -- has nothing else to cover a gap that carries more):
-//   kind 0  one half of a global load: [compare + select] / [load + offset step]            2 x NF items, weight 2
+//   kind 0  one half of a global load: [compare + select] / [load + offset step]            2 x NL items, weight 2
 //   kind 1  one fragment read (ds_read_b128) of the NEXT step's operands                    NR items, weight 1
 //   kind 2  one thirteenth of a float4's three-way split: H01 H23 R01 R23 M01 M23 L01 L23 (two elements each, so
 //           that consecutive instructions never depend on each other), PA PB PC (the packs), W1 W2 (staging writes)
-// The loads go into the first third of the step (their data is split one step later, filters first), the reads are
-// spread evenly, the split fills the rest; an item's gap is its cumulative issue weight scaled to NM.
-template <int NM, int NF, int NR>
+//   kind 3  one staging write of a PRE-SPLIT filter chunk (ds_write_b128 of 8 bf16 as loaded)   NBW items, weight 1
+// Every kind has its own time line over the step: the loads go into its first third (their data is used one step
+// later), the reads and the split are spread evenly; an item's gap is its time scaled to NM.
+template <int NM, int NL, int NR, int NCVF, int NBW>
 struct StepSched {
-  static constexpr int NCV = 13 * NF, NLH = 2 * NF, NIT = NCV + NR + NLH;
+  static constexpr int NCV = 13 * NCVF, NLH = 2 * NL, NIT = NCV + NR + NLH + NBW;
   // The step's ONE barrier sits behind MFMA number SB, not at the step boundary: it orders the LDS traffic of step t
   // (staging writes of tile t+2, fragment reads of tile t+1) against the LDS traffic of step t+1, and the MFMAs of
   // step t+1 read registers only. So the first SB MFMAs of a step run while the previous step's last staging writes
@@ -406,38 +408,41 @@ struct StepSched {
   static constexpr int SB = NM >= 24 ? 4 : (NM >= 12 ? 3 : 1);
   int kind[NIT], idx[NIT], gap[NIT];
 };
-template <int NM, int NF, int NR>
-constexpr StepSched<NM, NF, NR> make_step_sched() {
-  using S = StepSched<NM, NF, NR>;
+template <int NM, int NL, int NR, int NCVF, int NBW>
+constexpr StepSched<NM, NL, NR, NCVF, NBW> make_step_sched() {
+  using S = StepSched<NM, NL, NR, NCVF, NBW>;
   S s{};
-  int w[S::NIT] = {};
-  int n = 0, r = 0, l = 0;
-  for (int i = 0; i < S::NCV; ++i) {
-    while (l < S::NLH && l * S::NCV <= 3 * i * S::NLH) { s.kind[n] = 0; s.idx[n] = l++; w[n++] = 2; }
-    while (r < NR && i >= 11 && r * (S::NCV - 11) <= (i - 11) * NR) { s.kind[n] = 1; s.idx[n] = r++; w[n++] = 1; }
-    s.kind[n] = 2; s.idx[n] = i; w[n++] = (i % 13 == 12) ? 1 : 2;
-  }
-  while (l < S::NLH) { s.kind[n] = 0; s.idx[n] = l++; w[n++] = 2; }
-  while (r < NR) { s.kind[n] = 1; s.idx[n] = r++; w[n++] = 1; }
-  int total = 0;
-  for (int i = 0; i < S::NIT; ++i) total += w[i];
-  int cum = 0;
-  for (int i = 0; i < S::NIT; ++i) {
-    const int g = (int)((long)cum * NM / total);
-    s.gap[i] = g < NM ? g : NM - 1;
-    const bool lds = s.kind[i] == 1 || (s.kind[i] == 2 && s.idx[i] % 13 >= 11);
-    if (lds && s.gap[i] < S::SB) s.gap[i] = S::SB;
-    cum += w[i];
-  }
+  int n = 0;
+  // times in 1/10000 of a step. With pre-split filters the split work is half: it starts a quarter into the step, so
+  // that the activation rows requested at the start of the previous step have a step and a quarter to land
+  const long cv0 = NBW ? 2500 : 0;
+  auto put = [&](int kind, int idx, long t, bool lds) {
+    int g = (int)(t * NM / 10000);
+    g = g < NM ? g : NM - 1;
+    if (lds && g < S::SB) g = S::SB;
+    s.kind[n] = kind;
+    s.idx[n] = idx;
+    s.gap[n++] = g;
+  };
+  // (items of one gap are emitted in this order: loads, pre-split writes, reads, split)
+  for (int l = 0; l < S::NLH; ++l) put(0, l, (2 * l + 1) * 3000 / (2 * S::NLH), false);
+  for (int b = 0; b < NBW; ++b) put(3, b, 1800 + (2 * b + 1) * 800 / (2 * (NBW ? NBW : 1)), true);
+  for (int r = 0; r < NR; ++r) put(1, r, 1700 + (2 * r + 1) * 8000 / (2 * NR), true);
+  for (int i = 0; i < S::NCV; ++i) put(2, i, cv0 + (2 * i + 1) * (9950 - cv0) / (2 * S::NCV), i % 13 >= 11);
   return s;
 }
-template <int NM, int NF, int NR>
-inline constexpr StepSched<NM, NF, NR> kStepSched = make_step_sched<NM, NF, NR>();
+template <int NM, int NL, int NR, int NCVF, int NBW>
+inline constexpr StepSched<NM, NL, NR, NCVF, NBW> kStepSched = make_step_sched<NM, NL, NR, NCVF, NBW>();
 
-template <int BM, int BN, int STEM>
+// BPRE: the B operand is a WEIGHT that was split once per weight version (dana_split_weight: three bf16 planes per
+// K-step, [Kp / 16][3][N][16], Kp = K rounded up to 16, zero padded): its chunks of 8 bf16 go from HBM to the LDS planes as loaded, and
+// the K loop splits the activation rows only -- half the VALU work of the step.
+template <int BM, int BN, int STEM, int BPRE = 0>
 __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_split_kernel(IgemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
-  constexpr int RA = BM / 64, RB = BN / 64;  // float4 loads per thread per K-step (64 rows per pass)
+  constexpr int RA = BM / 64;                // float4 loads of A per thread per K-step (64 rows per pass)
+  // B: fp32 rows like A (64 rows per pass), or 16-byte chunks of the pre-split planes (3 planes x BN rows x 2 halves)
+  constexpr int RB = BPRE ? (3 * BN * 2 + 255) / 256 : BN / 64;
   constexpr int CLD = BN + 4;                // epilogue C-tile row, dwords
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned* As = (unsigned*)smem;      // [2][3][BM][SLD]
@@ -527,12 +532,28 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   }
   unsigned b_cur[RB];  // byte offset of this lane's float4 of the current K-step in its filter row
   int b_lim[RB];
+  int b_lds[RB];       // (BPRE) dword offset of this lane's chunk inside one staging buffer of B
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
-    const int n = n0 + r0 + 64 * j;
-    b_cur[j] = (unsigned)((n * p.ldb + c4 * 4) * 4);
-    b_lim[j] = n < p.N ? klim : DEAD;
+    if constexpr (BPRE) {
+      // chunk q = (plane, row, half): 8 bf16 = k 8*half.. of one filter row of one plane; p.ldb = Kp
+      // (a chunk index past the three planes -- 64-row tiles: 384 chunks on 512 slots -- repeats the lane's first
+      // chunk: same load, same LDS bytes, no branch in the stream)
+      const int q = (tid + 256 * j < 6 * BN) ? tid + 256 * j : tid;
+      const int pl = q / (2 * BN), rem = q - pl * (2 * BN);
+      const int row = rem >> 1, half = rem & 1;
+      const int n = n0 + row;
+      b_cur[j] = (unsigned)((((long)pl * p.N + n) * SBK + half * 8) * 2);  // (K-step 0; a K-step is 3 * N * 32 bytes)
+      b_lim[j] = n < p.N ? (p.K + SBK - 1) / SBK * SBK : DEAD;  // (rows past N: zeros; the planes are zero padded to 16 k)
+      b_lds[j] = (pl * BN + row) * SLD + half * 4;
+    } else {
+      const int n = n0 + r0 + 64 * j;
+      b_cur[j] = (unsigned)((n * p.ldb + c4 * 4) * 4);
+      b_lim[j] = n < p.N ? klim : DEAD;
+      b_lds[j] = 0;
+    }
   }
+  const unsigned B_STEP = BPRE ? (unsigned)p.N * 3u * SBK * 2u : SBK * 4;  // bytes from one K-step's chunk to the next
 
   float4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
   // K-steps are loaded in order: per step and load one compare (k0 against a per-lane limit that is DEAD for padding
@@ -585,7 +606,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     unsigned off = lt_k0 < b_lim[j] ? b_cur[j] : OOB;
     asm volatile("" : "+v"(off));
     dst = ldg_b128(rb_src, off);
-    b_cur[j] += SBK * 4;
+    b_cur[j] += B_STEP;
   };
   auto load_tile = [&](float4(&ra)[RA], float4(&rb)[RB]) {
     next_tap();
@@ -609,11 +630,15 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-      uint2 h, m, l;
-      split3(rb[j], h, m, l);
-      *(uint2*)(bs + (0 * BN + 64 * j) * SLD) = h;
-      *(uint2*)(bs + (1 * BN + 64 * j) * SLD) = m;
-      *(uint2*)(bs + (2 * BN + 64 * j) * SLD) = l;
+      if constexpr (BPRE) {
+        *(float4*)(Bs + buf * 3 * BN * SLD + b_lds[j]) = rb[j];
+      } else {
+        uint2 h, m, l;
+        split3(rb[j], h, m, l);
+        *(uint2*)(bs + (0 * BN + 64 * j) * SLD) = h;
+        *(uint2*)(bs + (1 * BN + 64 * j) * SLD) = m;
+        *(uint2*)(bs + (2 * BN + 64 * j) * SLD) = l;
+      }
     }
   };
 
@@ -630,9 +655,11 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   // -- address set-up, one global load, four fragment reads, one element's h/m/l (4 VALU), one pair's three packs (3
   // v_perm), one float4's three staging writes -- and dealt out evenly between the MFMAs.
   constexpr int NM = 6 * TM * TN;  // MFMAs per K-step
-  constexpr int NF = RA + RB;      // float4s loaded / split per thread per K-step
+  constexpr int NF = RA + RB;      // 16-byte loads per thread per K-step
+  constexpr int NCVF = BPRE ? RA : RA + RB;  // float4s split per thread per K-step
+  constexpr int NBW = BPRE ? RB : 0;         // pre-split chunks written per thread per K-step
   constexpr int NR = 3 * (TM + TN);  // fragment reads per K-step
-  using SCH = StepSched<NM, NF, NR>;        // the step's issue schedule (make_step_sched)
+  using SCH = StepSched<NM, NF, NR, NCVF, NBW>;  // the step's issue schedule (make_step_sched)
   const int nk = (p.K + SBK - 1) / SBK;
 
   u32x4 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];  // fragments as raw dwords (8 bf16 each)
@@ -695,15 +722,16 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
       if constexpr (q == SCH::SB) __syncthreads();  // (see StepSched::SB)
       static_for<0, SCH::NIT>([&](auto ic) {
         constexpr int it = decltype(ic)::value;
-        constexpr int kind = kStepSched<NM, NF, NR>.kind[it], ix = kStepSched<NM, NF, NR>.idx[it];
-        if constexpr (kStepSched<NM, NF, NR>.gap[it] != q) {
+        constexpr int kind = kStepSched<NM, NF, NR, NCVF, NBW>.kind[it], ix = kStepSched<NM, NF, NR, NCVF, NBW>.idx[it];
+        if constexpr (kStepSched<NM, NF, NR, NCVF, NBW>.gap[it] != q) {
         } else if constexpr (kind == 0) {
           // filters first: they are L2 hits and in front of the in-order load counter, the activation rows (possible
           // HBM misses) behind them -- and the split below takes the filters first, so an activation row has until the
           // middle of the NEXT step to land
+          // load order: fp32 filters first (they are split first); with pre-split filters the activation rows first
           constexpr int f = ix / 2, half = ix % 2;
-          constexpr bool isb = f < RB;
-          constexpr int j = isb ? f : f - RB;
+          constexpr bool isb = BPRE ? f >= RA : f < RB;
+          constexpr int j = BPRE ? (isb ? f - RA : f) : (isb ? f : f - RB);
           if constexpr (half == 0) {
             unsigned off = isb ? (lt_k0 < b_lim[isb ? j : 0] ? b_cur[isb ? j : 0] : OOB)
                                : (lt_k0 < a_lim[isb ? 0 : j] ? a_cur[isb ? 0 : j] : OOB);
@@ -712,7 +740,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
           } else {
             if constexpr (isb) {
               ld_b[isb ? j : 0] = ldg_b128(rb_src, ld_off[f]);
-              b_cur[isb ? j : 0] += SBK * 4;
+              b_cur[isb ? j : 0] += B_STEP;
             } else {
               ld_a[isb ? 0 : j] = ldg_b128(ra_src, ld_off[f]);
               a_cur[isb ? 0 : j] += SBK * 4;
@@ -727,9 +755,13 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
           constexpr int pc = r / (TM + TN), x = r % (TM + TN);
           if constexpr (x < TM) na[pc][x < TM ? x : 0] = *(const u32x4*)(as + (pc * BM + x * 32) * SLD);
           else nb[pc][x < TM ? 0 : x - TM] = *(const u32x4*)(bs + (pc * BN + (x - TM) * 32) * SLD);
+        } else if constexpr (kind == 3) {
+          // pre-split filter chunk: as loaded
+          *(float4*)(Bs + bw_ * 3 * BN * SLD + b_lds[ix]) = cv_b[ix];
         } else {
           constexpr int fo = ix / 13, r = ix % 13;
-          constexpr int f = fo < RB ? RA + fo : fo - RB;  // order of work: B floats, then A floats (f indexes A then B)
+          // order of work: B floats, then A floats (f indexes A then B); pre-split filters: A floats only
+          constexpr int f = BPRE ? fo : (fo < RB ? RA + fo : fo - RB);
           const float4 v = f < RA ? cv_a[f < RA ? f : 0] : cv_b[f < RA ? 0 : f - RA];
           constexpr int e0 = (r & 1) * 2, e1 = e0 + 1;  // the two elements of items 0..7
           if constexpr (r < 2) {  // H: top 16 bits
@@ -985,6 +1017,35 @@ gemm_skinny_kernel(const float* __restrict__ a, const float* __restrict__ b, flo
     }
 }
 
+// fp32 [n][k] (row stride ldw) -> three bf16 planes per K-step [kp / 16][3][n][16], kp = k rounded up to 16 (zero padded): the exact split
+// of igemm_split_kernel's staging path (h = top 16 bits, m = top 16 bits of x - h, l = x - h - m), done once per weight
+// version instead of once per K-step and tile. One lane = four consecutive k of one row.
+__global__ void __launch_bounds__(256)
+split_weight_kernel(const float* __restrict__ w, long ldw, long batch_w, int n, int k, int kp,
+                    unsigned short* __restrict__ out) {
+  const int kq = kp / 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * kq) return;
+  const int row = (int)(idx / kq), k4 = (int)(idx - (long)row * kq) * 4;
+  const float* src = w + blockIdx.y * batch_w + (long)row * ldw + k4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k4 + 3 < k) v = *(const float4*)src;
+  else {
+    if (k4 < k) v.x = src[0];
+    if (k4 + 1 < k) v.y = src[1];
+    if (k4 + 2 < k) v.z = src[2];
+  }
+  uint2 h, m, l;
+  split3(v, h, m, l);
+  // K-step-major blocks: [kp / 16][3 planes][n][16 bf16] -- the 32 bytes of one (K-step, plane, row) are contiguous and so
+  // are the rows of a tile: a wave's staging load of the kernel reads 1 KB of consecutive bytes
+  const int ks = k4 / SBK, kk = k4 - ks * SBK;
+  unsigned short* o = out + blockIdx.y * 3 * (long)n * kp + (((long)ks * 3) * n + row) * SBK + kk;
+  *(uint2*)o = h;
+  *(uint2*)(o + (long)n * SBK) = m;
+  *(uint2*)(o + 2 * (long)n * SBK) = l;
+}
+
 template <int BM, int BN, int STEM>
 int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   IgemmParams p = p0;
@@ -1004,8 +1065,9 @@ int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   return 0;
 }
 
-template <int BM, int BN, int STEM = 0>
+template <int BM, int BN, int STEM = 0, int BPRE = 0>
 int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
+  if (BPRE == 0 && p0.bpre) return launch_split<BM, BN, STEM, 1>(p0, batch, s);
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
@@ -1014,12 +1076,12 @@ int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
   if (lds_c > lds) lds = lds_c;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-  igemm_split_kernel<BM, BN, STEM><<<grid, 256, lds, s>>>(p);
+  igemm_split_kernel<BM, BN, STEM, BPRE><<<grid, 256, lds, s>>>(p);
   return 0;
 }
 
@@ -1166,11 +1228,16 @@ static int conv2d_impl(const char* who, const float* input, const float* weight,
     lda = in_pix_stride > 0 ? in_pix_stride : cin;
     DANA_CHECK_ARG(lda % 4 == 0 && lda >= cin, "%s: bad in_pix_stride", who);
   }
-  const long a_bytes = ((long)batch0 * h0 * w0 + (long)batch1 * h1 * w1) * lda * 4, b_bytes = (long)cout * p.K * 4;
+  p.bpre = (flags & DANA_W_SPLIT3) ? 1 : 0;
+  DANA_CHECK_ARG(!p.bpre || (dana_get_mfma_mode() != 0 && (stem || kh * kw <= 32)),
+                 "%s: DANA_W_SPLIT3 weights need the split kernel (dana_set_mfma_mode != 0, at most 32 taps)", who);
+  const int kpad = (p.K + SBK - 1) / SBK * SBK;
+  const long a_bytes = ((long)batch0 * h0 * w0 + (long)batch1 * h1 * w1) * lda * 4;
+  const long b_bytes = p.bpre ? (long)3 * cout * kpad * 2 : (long)cout * p.K * 4;
   DANA_CHECK_ARG(a_bytes < (long)OOB && b_bytes < (long)OOB,
                  "%s: operand spans >= 2 GiB are not addressable by one buffer descriptor; split the batch", who);
   p.lda = (int)lda;
-  p.ldb = p.K;
+  p.ldb = p.bpre ? kpad : p.K;
   p.a_bytes = (unsigned)a_bytes;
   p.b_bytes = (unsigned)b_bytes;
   p.ldc = out0_stride > 0 ? out0_stride : cout;
@@ -1233,7 +1300,8 @@ static int cat2_impl(const char* who, const float* a0, long a0_pix_stride, int k
   DANA_CHECK_ARG(lda0 % 4 == 0 && lda0 >= k0 && lda1 % 4 == 0 && lda1 >= k1, "%s: bad pixel stride", who);
   const long m0 = (long)n0 * oh0 * ow0, m1 = (long)n1 * oh1 * ow1;
   const long a0_bytes = (m0 + m1) * lda0 * 4, a1_bytes = ((long)n0 * h0 * w0 + (long)n1 * h1 * w1) * lda1 * 4;
-  const long b_bytes = (long)cout * (k0 + k1) * 4;
+  const int bpre = (flags & DANA_W_SPLIT3) ? 1 : 0;  // (k0 + k1 is a multiple of 16: no padding)
+  const long b_bytes = bpre ? (long)3 * cout * (k0 + k1) * 2 : (long)cout * (k0 + k1) * 4;
   DANA_CHECK_ARG(a0_bytes < (long)OOB && a1_bytes < (long)OOB && b_bytes < (long)OOB, "%s: operand spans >= 2 GiB", who);
   DANA_CHECK_ARG(((uintptr_t)a0 & 15) == 0 && ((uintptr_t)a1 & 15) == 0 && ((uintptr_t)weight & 15) == 0,
                  "%s: operands must be 16-byte aligned", who);
@@ -1268,6 +1336,7 @@ static int cat2_impl(const char* who, const float* a0, long a0_pix_stride, int k
   p.ldb = p.K;
   p.a_bytes = (unsigned)a0_bytes;
   p.b_bytes = (unsigned)b_bytes;
+  p.bpre = bpre;
   p.A2 = a1;
   p.lda2 = (int)lda1;
   p.IH2 = h0;
@@ -1303,6 +1372,22 @@ int dana_conv1x1_cat2_nhwc_dual(const float* a0, long a0_pix_stride, int k0, con
                    stride1, weight, out0, out1, scale, shift, nullptr, out0_pix_stride, out1_pix_stride, 0, cout, flags, stream);
 }
 
+size_t dana_split_weight_bytes(int n, int k, int batch) {
+  if (n <= 0 || k <= 0 || batch <= 0) return 0;
+  return (size_t)batch * 3 * n * ((k + SBK - 1) / SBK * SBK) * 2;
+}
+
+int dana_split_weight(const float* w, long ldw, int n, int k, int batch, long batch_w, void* out, dana_stream_t stream) {
+  DANA_CHECK_ARG(n > 0 && k > 0 && batch > 0 && ldw >= k, "dana_split_weight: bad shape");
+  DANA_CHECK_ARG(w && out && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0 && ldw % 4 == 0 && batch_w % 4 == 0,
+                 "dana_split_weight: pointers / strides must be 16-byte aligned");
+  const int kp = (k + SBK - 1) / SBK * SBK;
+  dim3 grid((unsigned)dana_ceil_div((long)n * (kp / 4), 256), batch);
+  split_weight_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w, ldw, batch_w, n, k, kp, (unsigned short*)out);
+  DANA_CHECK_LAUNCH("dana_split_weight");
+  return DANA_OK;
+}
+
 int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, const float* shift,
                  const float* residual, int m, int n, int k, long lda, long ldb, long ldc, long ldr, int batch,
                  long batch_a, long batch_b, long batch_c, float alpha, int flags, dana_stream_t stream) {
@@ -1311,6 +1396,9 @@ int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, c
   DANA_CHECK_ARG(a && b && c, "dana_gemm_nt: null pointer");
   DANA_CHECK_ARG(k % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && batch_a % 4 == 0 && batch_b % 4 == 0,
                  "dana_gemm_nt: k, lda, ldb and batch strides must be multiples of 4 (16-byte rows)");
+  const int bpre = (flags & DANA_W_SPLIT3) ? 1 : 0;  // b = bf16 planes [3][n][ldb], ldb (and batch_b) in bf16 elements
+  DANA_CHECK_ARG(!bpre || (dana_get_mfma_mode() != 0 && ldb % SBK == 0 && ldb >= k && batch_b % 8 == 0 && n > 8),
+                 "dana_gemm_nt: DANA_W_SPLIT3 needs the split kernel, ldb = k rounded up to 16, n > 8");
   DANA_CHECK_ARG(lda >= k && ldb >= k && ldc >= n, "dana_gemm_nt: leading dimension smaller than the row");
   DANA_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "dana_gemm_nt: a/b must be 16-byte aligned");
   DANA_CHECK_ARG(!residual || batch == 1, "dana_gemm_nt: residual only with batch == 1");
@@ -1321,7 +1409,7 @@ int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, c
     DANA_CHECK_LAUNCH("dana_gemm_nt(skinny)");
     return DANA_OK;
   }
-  const long a_bytes = ((long)(m - 1) * lda + k) * 4, b_bytes = ((long)(n - 1) * ldb + k) * 4;
+  const long a_bytes = ((long)(m - 1) * lda + k) * 4, b_bytes = bpre ? (long)3 * n * ldb * 2 : ((long)(n - 1) * ldb + k) * 4;
   DANA_CHECK_ARG(a_bytes < (long)OOB && b_bytes < (long)OOB, "dana_gemm_nt: operand slice >= 2 GiB; split it");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -1350,8 +1438,9 @@ int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, c
   p.ldc = ldc;
   p.ldr = ldr > 0 ? ldr : ldc;
   p.batch_a = batch_a;
-  p.batch_b = batch_b;
+  p.batch_b = bpre ? batch_b / 2 : batch_b;  // (the kernel steps the filter pointer in floats)
   p.batch_c = batch_c;
+  p.bpre = bpre;
   p.alpha = alpha;
   p.relu = (flags & DANA_EPI_RELU) ? 1 : 0;
   run(p, batch, 0, s);

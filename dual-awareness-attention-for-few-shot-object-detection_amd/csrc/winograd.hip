@@ -562,8 +562,12 @@ int dana_conv3x3_winograd4_nhwc_masked(const float* input, const float* u, float
   wino4_input_kernel<<<dana_ceil_div(p.tiles * C4, 256), 256, 0, s>>>(input, V, h, w, C4, p.th, p.tw, p.tiles, (int)lda,
                                                                      (unsigned)in_bytes);
   DANA_CHECK_LAUNCH("dana_conv3x3_winograd4_nhwc(input transform)");
-  int rc = dana_gemm_nt(V, u, M, nullptr, nullptr, nullptr, (int)p.tiles, cout, cin, cin, cin, cout, 0, 36,
-                        p.tiles * cin, (long)cout * cin, p.tiles * cout, 1.f, 0, stream);
+  // (DANA_W_SPLIT3: u = dana_split_weight of the 36 transformed filter planes, [36][3][cout][kp] bf16)
+  const bool w3 = (flags & DANA_W_SPLIT3) != 0;
+  const long kp = (cin + 15) / 16 * 16;
+  int rc = dana_gemm_nt(V, u, M, nullptr, nullptr, nullptr, (int)p.tiles, cout, cin, cin, w3 ? kp : cin, cout, 0, 36,
+                        p.tiles * cin, w3 ? 3 * cout * kp : (long)cout * cin, p.tiles * cout, 1.f, w3 ? DANA_W_SPLIT3 : 0,
+                        stream);
   if (rc) return rc;
   wino4_output_kernel<<<dana_ceil_div(p.tiles * N4, 256), 256, 0, s>>>(M, output, scale, shift, mask_act, ldm, h, w, N4,
                                                                       p.th, p.tw, p.tiles, ldc,
@@ -610,8 +614,10 @@ int dana_conv3x3_winograd4_nhwc_dual(const float* input, const float* u, float* 
   wino4_input_kernel<<<dana_ceil_div(p1.tiles * C4, 256), 256, 0, s>>>(in1, V, h1, w1, C4, p1.th, p1.tw, p1.tiles, (int)lda,
                                                                       (unsigned)in1_bytes, T, p0.tiles);
   DANA_CHECK_LAUNCH("dana_conv3x3_winograd4_nhwc_dual(input transforms)");
-  int rc = dana_gemm_nt(V, u, M, nullptr, nullptr, nullptr, (int)T, cout, cin, cin, cin, cout, 0, 36, T * cin,
-                        (long)cout * cin, T * cout, 1.f, 0, stream);
+  const bool w3 = (flags & DANA_W_SPLIT3) != 0;
+  const long kp = (cin + 15) / 16 * 16;
+  int rc = dana_gemm_nt(V, u, M, nullptr, nullptr, nullptr, (int)T, cout, cin, cin, w3 ? kp : cin, cout, 0, 36, T * cin,
+                        w3 ? 3 * cout * kp : (long)cout * cin, T * cout, 1.f, w3 ? DANA_W_SPLIT3 : 0, stream);
   if (rc) return rc;
   const int relu = (flags & DANA_EPI_RELU) ? 1 : 0;
   wino4_output_kernel<<<dana_ceil_div(p0.tiles * N4, 256), 256, 0, s>>>(M, out0, scale, shift, nullptr, 0, h0, w0, N4, p0.th,

@@ -173,7 +173,13 @@ class DAnARCNN(nn.Module):
         self.query_sequential = False  # chunks of the query batch one after the other on the main stream
         # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
         # True: query + support batches share every trunk launch (dana_conv2d_nhwc_dual)
-        self.merge_trunk = __import__('os').environ.get('DANA_MERGE_TRUNK', '1') != '0'  # query + support batch in one launch per trunk conv
+        self.presplit_weights = __import__('os').environ.get('DANA_PRESPLIT', '1') != '0'  # weights as bf16x3 planes, split once per version
+        # query + support batch through ONE set of activation buffers (_rcnn_base_dual; merge_from says which stages also share
+        # their launches). 0: two independent _rcnn_base calls
+        self.merge_trunk = __import__('os').environ.get('DANA_MERGE_TRUNK', '0') != '0'
+        # first trunk stage whose convs run as ONE launch over both batches (0: stem + layer1 .. 2: layer3 only, 3: none);
+        # the stages in front of it run the two batches on two streams (_rcnn_base_dual)
+        self.merge_from = int(__import__('os').environ.get('DANA_MERGE_FROM', '0'))
         self.nms_inclusive = False  # False: IoU > thr as the reference CUDA op (nms.cu:60); True: CPU op (>=)
         dim_in = self.pool_feat_dim
 
@@ -258,14 +264,15 @@ class DAnARCNN(nn.Module):
         if cached is None or cached[0] != dev:  # module.to(device) swaps buffers: re-collect the tensor list
             cached = (dev, list(self.state_dict(keep_vars=True).values()))
             self._consts["sig_tensors"] = cached
-        return (dev, self.use_winograd, self.winograd_min_cin, self.winograd_tile, self._epoch) + tuple(
+        return (dev, self.use_winograd, self.winograd_min_cin, self.winograd_tile, self._epoch, ops.get_mfma_mode(),
+                self.presplit_weights) + tuple(
             t._version for t in cached[1])
 
     def _conv_bn(self, conv, bn, stem=False):
         """packed weight + folded frozen BN (+ Winograd filter) of one conv, re-derived only when ITS tensors changed:
         a training step touches the trainable conv weights only (BN and conv1/layer1 are frozen, dana.py:350-385)"""
         wsig = (conv.weight.data_ptr(), conv.weight._version, self._epoch if conv.weight.requires_grad else -1,
-                self.use_winograd, self.winograd_min_cin, self.winograd_tile)
+                self.use_winograd, self.winograd_min_cin, self.winograd_tile, ops.get_mfma_mode(), self.presplit_weights)
         bsig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
         e = self._conv_cache.get(id(conv))
         if e is not None and e["wsig"] == wsig and e["bsig"] == bsig:
@@ -276,10 +283,18 @@ class DAnARCNN(nn.Module):
             scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         w = ops.pack_conv_weight(conv.weight, stem=stem)
         d = dict(w=w, scale=scale, shift=shift, cin=conv.in_channels, cout=conv.out_channels,
-                 k=conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0], u=None, wsig=wsig, bsig=bsig)
+                 k=conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0], u=None, ws=None, us=None, wsig=wsig,
+                 bsig=bsig)
         if (self.use_winograd and d["k"] == 3 and d["stride"] == 1 and d["pad"] == 1 and not stem
                 and d["cin"] >= self.winograd_min_cin):
             d["u"] = ops.winograd_filter_transform(w, d["cout"], d["cin"], self.winograd_tile)
+        # the contraction's B operand, split into its three bf16 planes once per weight version (ops.split_weight; None
+        # with the f32-MFMA kernel): "w" / "u" stay fp32 for the backward's derived weights
+        if self.presplit_weights:
+            if d["u"] is not None and d["u"].size(0) == 36:
+                d["us"] = ops.split_weight(d["u"], d["cout"], d["cin"], batch=36)
+            else:
+                d["ws"] = ops.split_weight(w, d["cout"], w.numel() // d["cout"])
         self._conv_cache[id(conv)] = d
         return d
 
@@ -296,7 +311,8 @@ class DAnARCNN(nn.Module):
             if e is None or e["sig"] != sig:
                 w_cat, shift = ops.pack_cat2_weight(c3["w"], c3["scale"], c3["shift"], c3["cin"], ds["w"], ds["scale"],
                                                     ds["shift"], ds["cin"], c3["cout"])
-                e = self._conv_cache[("cat", id(blk))] = dict(sig=sig, w=w_cat, shift=shift)
+                e = self._conv_cache[("cat", id(blk))] = dict(sig=sig, w=w_cat, shift=shift, ws=(
+                    ops.split_weight(w_cat, c3["cout"], c3["cin"] + ds["cin"]) if self.presplit_weights else None))
             d["cat"] = e
         return d
 
@@ -316,9 +332,17 @@ class DAnARCNN(nn.Module):
         p["rpn_conv_u"] = (ops.winograd_filter_transform(p["rpn_conv_w"], 512, rpn.din, self.winograd_tile)
                            if self.use_winograd and rpn.din >= self.winograd_min_cin else None)
         p["rpn_conv_b"] = rpn.RPN_Conv.bias.detach().contiguous()
+        p["rpn_conv_b3"] = None  # B operand of the RPN conv as split planes (Winograd filters or the packed weight)
+        if self.presplit_weights:
+            if p["rpn_conv_u"] is not None and p["rpn_conv_u"].size(0) == 36:
+                p["rpn_conv_b3"] = ops.split_weight(p["rpn_conv_u"], 512, rpn.din, batch=36)
+            elif p["rpn_conv_u"] is None:
+                p["rpn_conv_b3"] = ops.split_weight(p["rpn_conv_w"], 512, 9 * rpn.din)
         p["rpn_head_w"] = torch.cat([rpn.RPN_cls_score.weight.detach().view(rpn.nc_score_out, -1),
                                      rpn.RPN_bbox_pred.weight.detach().view(rpn.nc_bbox_out, -1)], 0).contiguous()
         p["rpn_head_b"] = torch.cat([rpn.RPN_cls_score.bias.detach(), rpn.RPN_bbox_pred.bias.detach()], 0).contiguous()
+        p["rpn_head_w3"] = (ops.split_weight(p["rpn_head_w"], p["rpn_head_w"].size(0), p["rpn_head_w"].size(1))
+                            if self.presplit_weights else None)
         ck = ("tables", str(dev), tuple(cfg.ANCHOR_SCALES), tuple(cfg.ANCHOR_RATIOS))
         tables = self._consts.get(ck)
         if tables is None:  # weight-independent constants: built once per device, not per weight update
@@ -359,13 +383,28 @@ class DAnARCNN(nn.Module):
     def _w(layer):
         return layer.weight.detach().contiguous(), layer.bias.detach().contiguous()
 
+    def _lin_b(self, layer, col0=0, cols=None):
+        """B operand of a GEMM against nn.Linear / 1x1-conv weights [n][ktot] (columns col0 .. col0+cols): (b, ldb) for
+        ops.gemm_nt -- the weight split into its three bf16 planes once per weight version (ldb 0), or the fp32 rows"""
+        w = layer.weight
+        n, ktot = w.size(0), w[0].numel()
+        k = cols or ktot
+        if not self.presplit_weights or ops.get_mfma_mode() == 0 or n <= 8:
+            return w.detach().contiguous().view(-1)[col0:], ktot
+        key = ("lin3", id(layer), col0, k)
+        sig = (w.data_ptr(), w._version, self._epoch if w.requires_grad else -1)
+        e = self._conv_cache.get(key)
+        if e is None or e[0] != sig:
+            e = self._conv_cache[key] = (sig, ops.split_weight(w.detach().contiguous().view(-1)[col0:], n, k, ldw=ktot))
+        return e[1], 0
+
     # ---- trunk -----------------------------------------------------------------------------------
     @staticmethod
     def _conv(x, n, h, w, c, relu, residual=None, res_stride=0, out=None, out_stride=0, in_stride=0):
         if c.get("u") is not None and residual is None:
-            return ops.conv3x3_winograd(x, n, h, w, c["cin"], c["u"], c["cout"], scale=c["scale"], shift=c["shift"],
-                                        relu=relu, in_stride=in_stride, out=out, out_stride=out_stride)
-        return ops.conv2d_nhwc(x, n, h, w, c["cin"], c["w"], c["cout"], c["k"], c["k"], c["stride"], c["pad"],
+            return ops.conv3x3_winograd(x, n, h, w, c["cin"], c.get("us") or c["u"], c["cout"], scale=c["scale"],
+                                        shift=c["shift"], relu=relu, in_stride=in_stride, out=out, out_stride=out_stride)
+        return ops.conv2d_nhwc(x, n, h, w, c["cin"], c.get("ws") or c["w"], c["cout"], c["k"], c["k"], c["stride"], c["pad"],
                                scale=c["scale"], shift=c["shift"], residual=residual, relu=relu,
                                in_stride=in_stride, out=out, out_stride=out_stride, res_stride=res_stride)
 
@@ -375,7 +414,7 @@ class DAnARCNN(nn.Module):
         o2, _, _ = self._conv(o1, n, h1, w1, bp["c2"], True)
         if bp.get("cat") is not None and getattr(self, "fuse_downsample", True) and ops.get_mfma_mode() != 0:
             c3, ds = bp["c3"], bp["ds"]
-            o3, _, _ = ops.conv1x1_cat2(o2, c3["cin"], x, ds["cin"], n, h, w, ds["stride"], bp["cat"]["w"],
+            o3, _, _ = ops.conv1x1_cat2(o2, c3["cin"], x, ds["cin"], n, h, w, ds["stride"], bp["cat"].get("ws") or bp["cat"]["w"],
                                         bp["cat"]["shift"], c3["cout"], relu=True, a1_stride=in_stride, out=out,
                                         out_stride=out_stride)
             if save is not None:
@@ -398,8 +437,8 @@ class DAnARCNN(nn.Module):
         n, _, H, W = im.shape
         x4 = ops.nchw_to_nhwc(im, cpad=4)
         st = plan["stem"]
-        x, h, w = ops.conv2d_nhwc(x4, n, H, W, 4, st["w"], 64, 7, 7, 2, 3, scale=st["scale"], shift=st["shift"],
-                                  relu=True, stem=True)
+        x, h, w = ops.conv2d_nhwc(x4, n, H, W, 4, st.get("ws") or st["w"], 64, 7, 7, 2, 3, scale=st["scale"],
+                                  shift=st["shift"], relu=True, stem=True)
         x, h, w = ops.maxpool3x3s2_ceil(x, n, h, w, 64)
         nl = len(plan["layers"])
         for li, layer in enumerate(plan["layers"]):
@@ -424,74 +463,143 @@ class DAnARCNN(nn.Module):
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         return h, w
 
-    def _rcnn_base_dual(self, im, sup_ims, plan, dev, save_q=None, save_s=None):
-        """RCNN_base on the query batch AND the support batch (dana.py:98,100: the same weights) with ONE launch per conv:
-        every activation is one buffer [query pixels | support pixels][channels]; the 1x1 / stride-1 convs see a plain
-        GEMM over all rows, the strided / 3x3 / stem convs carry the two image geometries (`*_dual` entry points), the
-        Winograd 3x3s run two input transforms, one batched plane GEMM over all tiles and two output transforms.
-        -> (corr [B*h*w][2048] with base_feat in channels 0..1023, (h, w), sup [Ns*sh*sw][1024], (sh, sw));
+    def _rcnn_base_dual(self, im, sup_ims, plan, dev, save_q=None, save_s=None, sup_stream=None, merge_from=0):
+        """RCNN_base on the query batch AND the support batch (dana.py:98,100: the same weights). Every activation is one
+        buffer [query pixels | support pixels][channels]. Stages >= `merge_from` (0: stem + layer1, 1: layer2, 2: layer3)
+        issue ONE launch per conv over both batches -- the 1x1 / stride-1 convs see a plain GEMM over all rows, the strided
+        / 3x3 / stem convs carry the two image geometries (`*_dual` entry points), the Winograd 3x3s run two input
+        transforms, one batched plane GEMM over all tiles and two output transforms. The stages in front of it run the two
+        batches as two launches on two streams (the caller's and `sup_stream`) over the two row ranges of the same buffers:
+        the big early layers fill the chip alone and overlap each other's tails, the tile-starved late layers share
+        their launches. -> (corr [B*h*w][2048] with base_feat in channels 0..1023, (h, w), sup [Ns*sh*sw][1024], (sh, sw));
         save_q / save_s receive the per-block dicts of `_bottleneck` (views of the merged buffers)."""
         n0, _, H0, W0 = im.shape
         n1, _, H1, W1 = sup_ims.shape
-        x4 = torch.empty(((n0 * H0 * W0 + n1 * H1 * W1), 4), dtype=torch.float32, device=dev)
-        ops.nchw_to_nhwc(im, cpad=4, out=x4)
-        ops.nchw_to_nhwc(sup_ims, cpad=4, out=x4[n0 * H0 * W0:])
+        main = torch.cuda.current_stream()
+        if sup_stream is None or sup_stream == main:
+            sup_stream = main  # (bench.py's per-launch timing pass: the same launches, one stream)
+        two = [merge_from > 0]  # currently issuing the two batches as two launches (on two streams)
+
+        def buf(rows, cols):
+            t = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+            if sup_stream is not main:
+                t.record_stream(sup_stream)
+            return t
+
+        def on_sup():
+            return torch.cuda.stream(sup_stream)
+
+        def join():
+            """the support chain joins the caller's stream: everything after it is one launch over both batches"""
+            if two[0]:
+                if sup_stream is not main:
+                    ev = torch.cuda.Event()
+                    ev.record(sup_stream)
+                    main.wait_event(ev)
+                two[0] = False
+
+        m0i, m1i = n0 * H0 * W0, n1 * H1 * W1
+        x4 = buf(m0i + m1i, 4)
         st = plan["stem"]
-        x, _, g0, g1 = ops.conv2d_nhwc_dual(x4, n0, H0, W0, n1, H1, W1, 4, st["w"], 64, 7, 7, 2, 3, scale=st["scale"],
-                                            shift=st["shift"], relu=True, stem=True)
+        stw = st.get("ws") or st["w"]
+        g0, g1 = ((H0 + 6 - 7) // 2 + 1, (W0 + 6 - 7) // 2 + 1), ((H1 + 6 - 7) // 2 + 1, (W1 + 6 - 7) // 2 + 1)
         p0, p1 = ops.maxpool_out_size(*g0), ops.maxpool_out_size(*g1)
-        xp = torch.empty((n0 * p0[0] * p0[1] + n1 * p1[0] * p1[1], 64), dtype=torch.float32, device=dev)
-        ops.maxpool3x3s2_ceil(x, n0, g0[0], g0[1], 64, out=xp)
-        ops.maxpool3x3s2_ceil(x[n0 * g0[0] * g0[1]:], n1, g1[0], g1[1], 64, out=xp[n0 * p0[0] * p0[1]:])
+        mq, ms_ = n0 * g0[0] * g0[1], n1 * g1[0] * g1[1]
+        xs = buf(mq + ms_, 64)
+        xp = buf(n0 * p0[0] * p0[1] + n1 * p1[0] * p1[1], 64)
+        ops.nchw_to_nhwc(im, cpad=4, out=x4)
+        if two[0]:
+            ops.conv2d_nhwc(x4, n0, H0, W0, 4, stw, 64, 7, 7, 2, 3, scale=st["scale"], shift=st["shift"], relu=True,
+                            stem=True, out=xs, out_stride=64)
+            ops.maxpool3x3s2_ceil(xs, n0, g0[0], g0[1], 64, out=xp)
+            with on_sup():
+                ops.nchw_to_nhwc(sup_ims, cpad=4, out=x4[m0i:])
+                ops.conv2d_nhwc(x4[m0i:], n1, H1, W1, 4, stw, 64, 7, 7, 2, 3, scale=st["scale"], shift=st["shift"],
+                                relu=True, stem=True, out=xs[mq:], out_stride=64)
+                ops.maxpool3x3s2_ceil(xs[mq:], n1, g1[0], g1[1], 64, out=xp[n0 * p0[0] * p0[1]:])
+        else:
+            ops.nchw_to_nhwc(sup_ims, cpad=4, out=x4[m0i:])
+            ops.conv2d_nhwc_dual(x4, n0, H0, W0, n1, H1, W1, 4, stw, 64, 7, 7, 2, 3, scale=st["scale"], shift=st["shift"],
+                                 relu=True, stem=True, out0=xs, out1=xs[mq:], out0_stride=64, out1_stride=64)
+            ops.maxpool3x3s2_ceil(xs, n0, g0[0], g0[1], 64, out=xp)
+            ops.maxpool3x3s2_ceil(xs[mq:], n1, g1[0], g1[1], 64, out=xp[n0 * p0[0] * p0[1]:])
         x, g0, g1 = xp, p0, p1
         split = ops.get_mfma_mode() != 0
         fuse_ds = getattr(self, "fuse_downsample", True) and split
 
         def conv(xin, gi0, gi1, c, relu, res=None, out0=None, out1=None, s0=0, s1=0):
-            """-> (merged output or out0, (oh0, ow0), (oh1, ow1))"""
-            if c.get("u") is not None and res is None and c["u"].size(0) == 36 and out0 is None:
-                return (ops.conv3x3_winograd_dual(xin, n0, gi0[0], gi0[1], n1, gi1[0], gi1[1], c["cin"], c["u"], c["cout"],
-                                                  scale=c["scale"], shift=c["shift"], relu=relu), gi0, gi1)
-            r0 = r1 = None
-            if res is not None:
-                mr = n0 * ((gi0[0] - 1) // c["stride"] + 1) * ((gi0[1] - 1) // c["stride"] + 1)
-                r0, r1 = res, res[mr:]
-            o0, _, h0, h1 = ops.conv2d_nhwc_dual(xin, n0, gi0[0], gi0[1], n1, gi1[0], gi1[1], c["cin"], c["w"], c["cout"],
-                                                 c["k"], c["k"], c["stride"], c["pad"], scale=c["scale"],
-                                                 shift=c["shift"], res0=r0, res1=r1, relu=relu, out0=out0, out1=out1,
-                                                 out0_stride=s0, out1_stride=s1)
+            """one conv over both batches -> (merged output or out0, (oh0, ow0), (oh1, ow1))"""
+            st_, k_, pd = c["stride"], c["k"], c["pad"]
+            h0 = ((gi0[0] + 2 * pd - k_) // st_ + 1, (gi0[1] + 2 * pd - k_) // st_ + 1)
+            h1 = ((gi1[0] + 2 * pd - k_) // st_ + 1, (gi1[1] + 2 * pd - k_) // st_ + 1)
+            mi, mo = n0 * gi0[0] * gi0[1], n0 * h0[0] * h0[1]
+            wino = c.get("u") is not None and res is None and (c["u"].size(0) == 36 or two[0])
+            if two[0]:
+                if out0 is None:
+                    o = buf(mo + n1 * h1[0] * h1[1], c["cout"])
+                    out0, out1, s0, s1 = o, o[mo:], c["cout"], c["cout"]
+                else:
+                    o = out0
+                r0, r1 = (res, res[mo:]) if res is not None else (None, None)
+                for grp, (xi, n_, gi, oo, so, rr) in enumerate(((xin, n0, gi0, out0, s0, r0), (xin[mi:], n1, gi1, out1, s1, r1))):
+                    with (on_sup() if grp else torch.cuda.stream(main)):
+                        if wino:
+                            ops.conv3x3_winograd(xi, n_, gi[0], gi[1], c["cin"], c.get("us") or c["u"], c["cout"],
+                                                 scale=c["scale"], shift=c["shift"], relu=relu, out=oo, out_stride=so)
+                        else:
+                            ops.conv2d_nhwc(xi, n_, gi[0], gi[1], c["cin"], c.get("ws") or c["w"], c["cout"], k_, k_, st_, pd,
+                                            scale=c["scale"], shift=c["shift"], residual=rr, relu=relu, out=oo, out_stride=so)
+                return o, h0, h1
+            if wino and out0 is None:
+                return (ops.conv3x3_winograd_dual(xin, n0, gi0[0], gi0[1], n1, gi1[0], gi1[1], c["cin"], c.get("us") or c["u"],
+                                                  c["cout"], scale=c["scale"], shift=c["shift"], relu=relu), gi0, gi1)
+            r0, r1 = (res, res[mo:]) if res is not None else (None, None)
+            o0, _, _, _ = ops.conv2d_nhwc_dual(xin, n0, gi0[0], gi0[1], n1, gi1[0], gi1[1], c["cin"], c.get("ws") or c["w"],
+                                               c["cout"], k_, k_, st_, pd, scale=c["scale"], shift=c["shift"], res0=r0,
+                                               res1=r1, relu=relu, out0=out0, out1=out1, out0_stride=s0, out1_stride=s1)
             return o0, h0, h1
 
         corr = sup = None
         nl = len(plan["layers"])
         for li, layer in enumerate(plan["layers"]):
+            if li >= merge_from:
+                join()
             for bi, bp in enumerate(layer):
                 last = (li == nl - 1) and (bi == len(layer) - 1)
                 o1, h0, h1 = conv(x, g0, g1, bp["c1"], True)
                 o2, _, _ = conv(o1, h0, h1, bp["c2"], True)
-                m0o = n0 * h0[0] * h0[1]
+                m0o, mi = n0 * h0[0] * h0[1], n0 * g0[0] * g0[1]
                 out0 = out1 = None
                 s0 = s1 = 0
                 if last:
                     corr = torch.empty((m0o, 2048), dtype=torch.float32, device=dev)
-                    sup = torch.empty((n1 * h1[0] * h1[1], 1024), dtype=torch.float32, device=dev)
+                    sup = buf(n1 * h1[0] * h1[1], 1024)
                     out0, out1, s0, s1 = corr, sup, 2048, 1024
                 if bp.get("cat") is not None and fuse_ds:
                     c3, ds = bp["c3"], bp["ds"]
-                    o3, _, _, _ = ops.conv1x1_cat2_dual(o2, c3["cin"], x, ds["cin"], n0, g0[0], g0[1], n1, g1[0], g1[1],
-                                                        ds["stride"], bp["cat"]["w"], bp["cat"]["shift"], c3["cout"],
-                                                        relu=True, out0=out0, out1=out1, out0_stride=s0, out1_stride=s1)
+                    wc = bp["cat"].get("ws") or bp["cat"]["w"]
+                    if two[0]:
+                        o3 = buf(m0o + n1 * h1[0] * h1[1], c3["cout"])
+                        ops.conv1x1_cat2(o2, c3["cin"], x, ds["cin"], n0, g0[0], g0[1], ds["stride"], wc, bp["cat"]["shift"],
+                                         c3["cout"], relu=True, out=o3, out_stride=c3["cout"])
+                        with on_sup():
+                            ops.conv1x1_cat2(o2[m0o:], c3["cin"], x[mi:], ds["cin"], n1, g1[0], g1[1], ds["stride"], wc,
+                                             bp["cat"]["shift"], c3["cout"], relu=True, out=o3[m0o:], out_stride=c3["cout"])
+                    else:
+                        o3, _, _, _ = ops.conv1x1_cat2_dual(o2, c3["cin"], x, ds["cin"], n0, g0[0], g0[1], n1, g1[0], g1[1],
+                                                            ds["stride"], wc, bp["cat"]["shift"], c3["cout"], relu=True,
+                                                            out0=out0, out1=out1, out0_stride=s0, out1_stride=s1)
                 else:
                     res = conv(x, g0, g1, bp["ds"], False)[0] if bp["ds"] is not None else x
                     o3, _, _ = conv(o2, h0, h1, bp["c3"], True, res=res, out0=out0, out1=out1, s0=s0, s1=s1)
                 if li > 0 and save_q is not None:  # (layer1 is frozen: nothing to differentiate there)
-                    mi = n0 * g0[0] * g0[1]
                     key = "RCNN_base.%d.%d" % (4 + li, bi)
                     save_q.append(dict(x=x[:mi], o1=o1[:m0o], o2=o2[:m0o], o3=corr if last else o3[:m0o], h1=h0[0], w1=h0[1],
                                        n=n0, h=g0[0], w=g0[1], bp=bp, key=key, o3_ld=s0))
                     save_s.append(dict(x=x[mi:], o1=o1[m0o:], o2=o2[m0o:], o3=sup if last else o3[m0o:], h1=h1[0], w1=h1[1],
                                        n=n1, h=g1[0], w=g1[1], bp=bp, key=key, o3_ld=s1 if last else 0))
                 x, g0, g1 = o3, h0, h1
+        join()
         return corr, g0, sup, g1
 
     # ---- forward -----------------------------------------------------------------------------------
@@ -615,9 +723,11 @@ class DAnARCNN(nn.Module):
         dq = self.rcnn_reduce_dim
         K1 = shot * L
         if self.merge_trunk:
+            sup_stream.wait_event(inputs_ready)
             corr, (fh, fw), sup, (sh_, sw_) = self._rcnn_base_dual(im_data, sup_ims, plan, dev,
                                                                    save_q=ctx["q_saved"] if ctx is not None else None,
-                                                                   save_s=ctx["s_saved"] if ctx is not None else None)
+                                                                   save_s=ctx["s_saved"] if ctx is not None else None,
+                                                                   sup_stream=sup_stream, merge_from=int(self.merge_from))
             trunk_done = torch.cuda.Event()
             trunk_done.record()
             sup_stream.wait_event(trunk_done)
@@ -667,7 +777,8 @@ class DAnARCNN(nn.Module):
                     ctx.update(s_pre=s_pe.clone(), ba_w=wgt)
                 ops.ba_apply_(s_pe, wgt, B * shot, L, 1024, gamma=self.channel_gamma, slope=0.01)
             wk, bk = self._w(self.rpn_adapt_k_layer)
-            kp = ops.gemm_nt(s_pe, wk, B * shot * L, d, 1024, shift=bk)
+            kb3, kld = self._lin_b(self.rpn_adapt_k_layer)
+            kp = ops.gemm_nt(s_pe, kb3, B * shot * L, d, 1024, ldb=kld, shift=bk)
             ops.colmean_sub_(kp, B * shot, L, d)
             wu, bu = self._w(self.rpn_unary_layer)
             unary = ops.rowdot(s_pe, wu, bu, B * shot * L, 1024)
@@ -682,7 +793,8 @@ class DAnARCNN(nn.Module):
 
         # -- RPN-level dual-awareness attention, query side (dana.py:118-154) --
         wq, bq = self._w(self.rpn_adapt_q_layer)
-        qp = ops.gemm_nt(corr, wq, B * hw, d, 1024, lda=2048, shift=bq)
+        qb3, qld = self._lin_b(self.rpn_adapt_q_layer)
+        qp = ops.gemm_nt(corr, qb3, B * hw, d, 1024, lda=2048, ldb=qld, shift=bq)
         ops.colmean_sub_(qp, B, hw, d)
         main.wait_event(support_done)
         scores = torch.empty((B, hw, K1), dtype=torch.float32, device=dev)
@@ -700,13 +812,13 @@ class DAnARCNN(nn.Module):
         # -- RPN head + proposals (rpn.py:58-78, proposal_layer.py:49-190) --
         rpn = self.RCNN_rpn
         if plan["rpn_conv_u"] is not None:
-            x, _, _ = ops.conv3x3_winograd(corr, B, fh, fw, 2048, plan["rpn_conv_u"], 512, shift=plan["rpn_conv_b"],
-                                           relu=True)
+            x, _, _ = ops.conv3x3_winograd(corr, B, fh, fw, 2048, plan["rpn_conv_b3"] or plan["rpn_conv_u"], 512,
+                                           shift=plan["rpn_conv_b"], relu=True)
         else:
-            x, _, _ = ops.conv2d_nhwc(corr, B, fh, fw, 2048, plan["rpn_conv_w"], 512, 3, 3, 1, 1,
+            x, _, _ = ops.conv2d_nhwc(corr, B, fh, fw, 2048, plan["rpn_conv_b3"] or plan["rpn_conv_w"], 512, 3, 3, 1, 1,
                                       shift=plan["rpn_conv_b"], relu=True)
         nh = rpn.nc_score_out + rpn.nc_bbox_out
-        heads = ops.gemm_nt(x, plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])  # [B*hw][2A | 4A]
+        heads = ops.gemm_nt(x, plan["rpn_head_w3"] or plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])  # [B*hw][2A | 4A]
         mark("rpn conv + heads")
         # -- RoI-level support side (dana.py:105-108,258,271-277): K / unary projections once per support (the
         #    reference recomputes them for every RoI). Only the RoI heads need them, so they are queued behind the RPN
@@ -725,7 +837,8 @@ class DAnARCNN(nn.Module):
             sp = ops.avgpool(sup, Ns, sh_, sw_, 1024, pool[0], pool[1])  # [Ns][49][1024]
             sp_pe = ops.add_pe(sp, plan["pe49"], Ns * P2, P2, 1024)
             wk2, bk2 = self._w(self.rcnn_adapt_k_layer)
-            k2 = ops.gemm_nt(sp_pe, wk2, Ns * P2, dq, 1024, shift=bk2)
+            k2b3, k2ld = self._lin_b(self.rcnn_adapt_k_layer)
+            k2 = ops.gemm_nt(sp_pe, k2b3, Ns * P2, dq, 1024, ldb=k2ld, shift=bk2)
             ops.colmean_sub_(k2, Ns, P2, dq)
             wu2, bu2 = self._w(self.rcnn_unary_layer)
             un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
@@ -839,14 +952,18 @@ class DAnARCNN(nn.Module):
         if support_roi_done is not None:
             main.wait_event(support_roi_done)
         wq2, bq2 = self._w(self.rcnn_adapt_q_layer)
-        q2 = ops.gemm_nt(q_pe, wq2, n_roi * P2, dq, 1024, shift=bq2)
+        q2b3, q2ld = self._lin_b(self.rcnn_adapt_q_layer)
+        q2 = ops.gemm_nt(q_pe, q2b3, n_roi * P2, dq, 1024, ldb=q2ld, shift=bq2)
         ops.colmean_sub_(q2, n_roi, P2, dq)
         K2 = shot * P2
         K2p = (K2 + 31) // 32 * 32
         wt, bt_ = self._w(self.rcnn_transform_layer)
         w1, b1 = self._w(self.output_score_layer.linear1)
         w2, b2 = self._w(self.output_score_layer.linear2)
-        tr_q = ops.gemm_nt(q_pe, wt, n_roi * P2, self.rcnn_dim, 1024, ldb=2048, shift=bt_)  # [n*49][64]
+        wt_q, wt_q_ld = self._lin_b(self.rcnn_transform_layer, 0, 1024)      # the two column halves of Wt [64][2048]
+        wt_a, wt_a_ld = self._lin_b(self.rcnn_transform_layer, 1024, 1024)
+        w1b3, w1ld = self._lin_b(self.output_score_layer.linear1)
+        tr_q = ops.gemm_nt(q_pe, wt_q, n_roi * P2, self.rcnn_dim, 1024, ldb=wt_q_ld, shift=bt_)  # [n*49][64]
         q_ready = torch.cuda.Event()
         q_ready.record()
 
@@ -863,9 +980,9 @@ class DAnARCNN(nn.Module):
             dense = torch.empty((n_roi * P2, 1024), dtype=torch.float32, device=dev)
             ops.gemm_nt(sc2, st2, R * P2, 1024, K2p, lda=K2p, ldb=K2p, out=dense, ldc=1024, batch=B,
                         batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 1024, k_true=K2)
-            tr = ops.gemm_nt(dense, wt.view(-1)[1024:], n_roi * P2, self.rcnn_dim, 1024, ldb=2048,
+            tr = ops.gemm_nt(dense, wt_a, n_roi * P2, self.rcnn_dim, 1024, ldb=wt_a_ld,
                              residual=tr_q, ldr=self.rcnn_dim)  # [n*49][64] == [n][3136]
-            hid = ops.gemm_nt(tr, w1, n_roi, w1.size(0), P2 * self.rcnn_dim, shift=b1, relu=True)
+            hid = ops.gemm_nt(tr, w1b3, n_roi, w1.size(0), P2 * self.rcnn_dim, ldb=w1ld, shift=b1, relu=True)
             score = ops.gemm_nt(hid, w2, n_roi, 2, w1.size(0), shift=b2)
             prob = ops.softmax_rows_(score.clone(), n_roi, 2)
             if ctx is not None:

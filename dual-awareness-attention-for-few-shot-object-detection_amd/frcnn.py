@@ -30,6 +30,7 @@ class FasterRCNN(DAnARCNN):
         self.winograd_min_cin = int(__import__("os").environ.get("DANA_WINO_MIN_CIN",
                                                                  128 if self.winograd_tile == 4 else 256))
         self.query_streams, self.query_sequential, self.merge_trunk = 1, False, False
+        self.presplit_weights = __import__("os").environ.get("DANA_PRESPLIT", "1") != "0"
         self.nms_inclusive = False
         self.device_rng, self.rng_seed, self._rng_calls = False, 1996, 0
         self.RCNN_rpn = _RPNParams(self.dout_base_model)
@@ -72,13 +73,13 @@ class FasterRCNN(DAnARCNN):
         hw = fh * fw
         rpn = self.RCNN_rpn
         if plan["rpn_conv_u"] is not None:
-            x, _, _ = ops.conv3x3_winograd(rfeat, B, fh, fw, rpn.din, plan["rpn_conv_u"], 512, shift=plan["rpn_conv_b"],
+            x, _, _ = ops.conv3x3_winograd(rfeat, B, fh, fw, rpn.din, plan["rpn_conv_b3"] or plan["rpn_conv_u"], 512, shift=plan["rpn_conv_b"],
                                            relu=True)
         else:
-            x, _, _ = ops.conv2d_nhwc(rfeat, B, fh, fw, rpn.din, plan["rpn_conv_w"], 512, 3, 3, 1, 1,
+            x, _, _ = ops.conv2d_nhwc(rfeat, B, fh, fw, rpn.din, plan["rpn_conv_b3"] or plan["rpn_conv_w"], 512, 3, 3, 1, 1,
                                       shift=plan["rpn_conv_b"], relu=True)
         nh = rpn.nc_score_out + rpn.nc_bbox_out
-        heads = ops.gemm_nt(x, plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])
+        heads = ops.gemm_nt(x, plan["rpn_head_w3"] or plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])
         A = plan["anchors"].size(0)
         key = "TRAIN" if training else "TEST"
         rois = ops.proposal_layer(heads, (hw * nh, 1, nh), False, heads.view(-1)[rpn.nc_score_out:], (hw * nh, 1, nh),

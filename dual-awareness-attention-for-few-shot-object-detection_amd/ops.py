@@ -13,7 +13,7 @@ from ._lib import lib, DanaError  # noqa: F401
 HOST_WAIT = [0.0]  # seconds the host spent blocked in the training forward's one D2H read (bench.py / tools/hosttime.py)
 
 NCHW, NHWC = 0, 1
-EPI_RELU, CONV_STEM7 = 1, 2
+EPI_RELU, CONV_STEM7, W_SPLIT3 = 1, 2, 256
 
 # bench.py sets this to a list to time every MFMA contraction launch with HIP events recorded on the
 # stream the kernel is launched on; entries are (tag, algorithmic_flops, start_event, end_event).
@@ -84,6 +84,33 @@ def _h2d_int32(arr, device):
 
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+class W3:
+    """a weight after dana_split_weight: three bf16 planes per K-step, [batch][kp/16][3][n][16], of the same fp32 values (exact split), for
+    the DANA_W_SPLIT3 flag of the contraction entry points. `t` owns the bytes."""
+    __slots__ = ("t", "n", "k", "kp", "batch")
+
+    def __init__(self, t, n, k, kp, batch):
+        self.t, self.n, self.k, self.kp, self.batch = t, n, k, kp, batch
+
+
+def split_weight(w, n, k, batch=1, ldw=0, batch_w=0):
+    """fp32 rows [batch][n][k] -> W3 (None when the f32-MFMA kernel is selected: it takes fp32 weights only)"""
+    if get_mfma_mode() == 0:
+        return None
+    _chk(w, "w")
+    kp = (k + 15) // 16 * 16
+    out = torch.empty(int(lib().query("dana_split_weight_bytes", n, k, batch)), dtype=torch.uint8, device=w.device)
+    lib().call("dana_split_weight", _p(w), ldw or k, n, k, batch, batch_w or n * k, _p(out), _stream())
+    return W3(out, n, k, kp, batch)
+
+
+def _wf(weight):
+    """(pointer, flag) of a weight argument that is either fp32 rows or a W3"""
+    if isinstance(weight, W3):
+        return _p(weight.t), W_SPLIT3
+    return _p(_chk(weight, "weight")), 0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -539,15 +566,15 @@ def conv2d_nhwc(x, batch, in_h, in_w, cin, weight, cout, kh, kw, stride, pad, sc
                 residual=None, relu=False, in_stride=0, out=None, out_stride=0, res_stride=0, stem=False):
     """x: flat NHWC buffer; weight packed [cout][kh][kw][cin]. Returns (out, OH, OW)."""
     _chk(x, "x")
-    _chk(weight, "weight")
+    wp, wfl = _wf(weight)
     oh = (in_h + 2 * pad - kh) // stride + 1
     ow = (in_w + 2 * pad - kw) // stride + 1
     if out is None:
         out = torch.empty((batch * oh * ow, cout), dtype=torch.float32, device=x.device)
         out_stride = cout
-    flags = (EPI_RELU if relu else 0) | (CONV_STEM7 if stem else 0)
+    flags = (EPI_RELU if relu else 0) | (CONV_STEM7 if stem else 0) | wfl
     e0 = _prof_begin()
-    lib().call("dana_conv2d_nhwc", _p(x), _p(weight), _p(out), _p(scale), _p(shift), _p(residual), batch, in_h,
+    lib().call("dana_conv2d_nhwc", _p(x), wp, _p(out), _p(scale), _p(shift), _p(residual), batch, in_h,
                in_w, cin, cout, kh, kw, stride, pad, in_stride, out_stride, res_stride, flags, _stream())
     # algorithmic flops: the stem counts its 3 real channels x 49 real taps, not the padded K=224
     _prof_end(e0, ("conv%dx%d M=%d N=%d K=%d s%d", (kh, kw, batch * oh * ow, cout, kh * kw * cin, stride)),
@@ -563,7 +590,7 @@ def conv2d_nhwc_dual(x, n0, h0, w0, n1, h1, w1, cin, weight, cout, kh, kw, strid
     """One launch over two image groups (query batch + support batch); x holds group 0's pixels then group 1's.
     Without out0/out1 the result is ONE merged buffer [M0 + M1][cout]. Returns (out0, out1, (oh0, ow0), (oh1, ow1))."""
     _chk(x, "x")
-    _chk(weight, "weight")
+    wp, wfl = _wf(weight)
     oh0, ow0 = (h0 + 2 * pad - kh) // stride + 1, (w0 + 2 * pad - kw) // stride + 1
     oh1, ow1 = (h1 + 2 * pad - kh) // stride + 1, (w1 + 2 * pad - kw) // stride + 1
     m0, m1 = n0 * oh0 * ow0, n1 * oh1 * ow1
@@ -571,9 +598,9 @@ def conv2d_nhwc_dual(x, n0, h0, w0, n1, h1, w1, cin, weight, cout, kh, kw, strid
         merged = torch.empty((m0 + m1, cout), dtype=torch.float32, device=x.device)
         out0, out1 = merged, merged[m0:]
         out0_stride = out1_stride = cout
-    flags = (EPI_RELU if relu else 0) | (CONV_STEM7 if stem else 0)
+    flags = (EPI_RELU if relu else 0) | (CONV_STEM7 if stem else 0) | wfl
     e0 = _prof_begin()
-    lib().call("dana_conv2d_nhwc_dual", _p(x), _p(weight), _p(out0), _p(out1), _p(scale), _p(shift), _p(res0),
+    lib().call("dana_conv2d_nhwc_dual", _p(x), wp, _p(out0), _p(out1), _p(scale), _p(shift), _p(res0),
                _p(res1), n0, h0, w0, n1, h1, w1, cin, cout, kh, kw, stride, pad, in_stride, out0_stride, out1_stride,
                res0_stride, res1_stride, flags, _stream())
     _prof_end(e0, ("conv%dx%d M=%d N=%d K=%d s%d", (kh, kw, m0 + m1, cout, kh * kw * cin, stride)),
@@ -601,8 +628,9 @@ def conv1x1_cat2(a0, k0, a1, k1, batch, h1, w1, stride1, w_cat, shift, cout, rel
         out = torch.empty((batch * oh * ow, cout), dtype=torch.float32, device=a0.device)
         out_stride = cout
     e0 = _prof_begin()
-    lib().call("dana_conv1x1_cat2_nhwc", _p(a0), a0_stride, k0, _p(a1), a1_stride, k1, batch, h1, w1, stride1, _p(w_cat),
-               _p(out), None, _p(shift), None, out_stride, 0, cout, EPI_RELU if relu else 0, _stream())
+    wp, wfl = _wf(w_cat)
+    lib().call("dana_conv1x1_cat2_nhwc", _p(a0), a0_stride, k0, _p(a1), a1_stride, k1, batch, h1, w1, stride1, wp,
+               _p(out), None, _p(shift), None, out_stride, 0, cout, (EPI_RELU if relu else 0) | wfl, _stream())
     m = batch * oh * ow
     _prof_end(e0, ("conv1x1cat M=%d N=%d K=%d s%d", (m, cout, k0 + k1, stride1)), 2.0 * m * cout * (k0 + k1),
               4.0 * (m * (k0 + k1) + cout * (k0 + k1) + m * cout))
@@ -624,8 +652,10 @@ def conv1x1_cat2_dual(a0, k0, a1, k1, n0, h0, w0, n1, h1, w1, stride1, w_cat, sh
         out0, out1 = merged, merged[m0:]
         out0_stride = out1_stride = cout
     e0 = _prof_begin()
-    lib().call("dana_conv1x1_cat2_nhwc_dual", _p(a0), 0, k0, _p(a1), 0, k1, n0, h0, w0, n1, h1, w1, stride1, _p(w_cat),
-               _p(out0), _p(out1), None, _p(shift), out0_stride, out1_stride, cout, EPI_RELU if relu else 0, _stream())
+    wp, wfl = _wf(w_cat)
+    lib().call("dana_conv1x1_cat2_nhwc_dual", _p(a0), 0, k0, _p(a1), 0, k1, n0, h0, w0, n1, h1, w1, stride1, wp,
+               _p(out0), _p(out1), None, _p(shift), out0_stride, out1_stride, cout, (EPI_RELU if relu else 0) | wfl,
+               _stream())
     m = m0 + m1
     _prof_end(e0, ("conv1x1cat M=%d N=%d K=%d s%d", (m, cout, k0 + k1, stride1)), 2.0 * m * cout * (k0 + k1),
               4.0 * (m * (k0 + k1) + cout * (k0 + k1) + m * cout))
@@ -636,15 +666,15 @@ def conv3x3_winograd_dual(x, n0, h0, w0, n1, h1, w1, cin, u, cout, scale=None, s
     """stride-1 pad-1 3x3 conv through Winograd F(4x4,3x3) over two image groups with ONE batched plane GEMM (x: group
     0's pixels, then group 1's) -> merged [M0 + M1][cout]"""
     _chk(x, "x")
-    _chk(u, "u")
-    if u.size(0) != 36:
+    up, wfl = _wf(u)
+    if (u.batch if isinstance(u, W3) else u.size(0)) != 36:
         raise ValueError("conv3x3_winograd_dual: F(4x4,3x3) filters only")
     m0, m1 = n0 * h0 * w0, n1 * h1 * w1
     out = torch.empty((m0 + m1, cout), dtype=torch.float32, device=x.device)
     ws = _ws(lib().query("dana_conv3x3_winograd4_dual_workspace_bytes", n0, h0, w0, n1, h1, w1, cin, cout), x.device)
     e0 = _prof_begin()
-    lib().call("dana_conv3x3_winograd4_nhwc_dual", _p(x), _p(u), _p(out), _p(out[m0:]), _p(scale), _p(shift), n0, h0, w0,
-               n1, h1, w1, cin, cout, 0, 0, 0, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
+    lib().call("dana_conv3x3_winograd4_nhwc_dual", _p(x), up, _p(out), _p(out[m0:]), _p(scale), _p(shift), n0, h0, w0,
+               n1, h1, w1, cin, cout, 0, 0, 0, (EPI_RELU if relu else 0) | wfl, _p(ws), ws.numel(), _stream())
     tiles = n0 * ((h0 + 3) // 4) * ((w0 + 3) // 4) + n1 * ((h1 + 3) // 4) * ((w1 + 3) // 4)
     _prof_end(e0, ("wino3x3 M=%d N=%d K=%d s1", (m0 + m1, cout, 9 * cin)), 2.0 * (m0 + m1) * cout * 9 * cin,
               4.0 * 36 * (tiles * (cin + cout) + cout * cin), executed=2.0 * 36 * tiles * cin * cout)
@@ -665,16 +695,19 @@ def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=
                      out_stride=0, mask=None, mask_stride=0):
     """stride-1 pad-1 3x3 conv through Winograd F(2x2,3x3) or F(4x4,3x3), chosen by u (winograd_filter_transform)."""
     _chk(x, "x")
-    _chk(u, "u")
+    up, wfl = _wf(u)
     if out is None:
         out = torch.empty((batch * h * w, cout), dtype=torch.float32, device=x.device)
         out_stride = cout
-    m = 2 if u.size(0) == 16 else 4
+    m = 2 if (u.batch if isinstance(u, W3) else u.size(0)) == 16 else 4
+    if wfl and m != 4:
+        raise ValueError("conv3x3_winograd: split filters with F(4x4,3x3) only")
     sfx = "" if m == 2 else "4"
     ws = _ws(lib().query("dana_conv3x3_winograd%s_workspace_bytes" % sfx, batch, h, w, cin, cout), x.device)
     e0 = _prof_begin()
-    lib().call("dana_conv3x3_winograd%s_nhwc_masked" % sfx, _p(x), _p(u), _p(out), _p(scale), _p(shift), _p(mask), batch,
-               h, w, cin, cout, in_stride, out_stride, mask_stride, EPI_RELU if relu else 0, _p(ws), ws.numel(), _stream())
+    lib().call("dana_conv3x3_winograd%s_nhwc_masked" % sfx, _p(x), up, _p(out), _p(scale), _p(shift), _p(mask), batch,
+               h, w, cin, cout, in_stride, out_stride, mask_stride, (EPI_RELU if relu else 0) | wfl, _p(ws), ws.numel(),
+               _stream())
     _prof_end(e0, ("wino3x3 M=%d N=%d K=%d s1", (batch * h * w, cout, 9 * cin)), 2.0 * batch * h * w * cout * 9 * cin,
               # bytes of the batched GEMM launch itself: V[planes][tiles][cin], U[planes][cout][cin], M[planes][tiles][cout]
               4.0 * (m + 2) * (m + 2) * (batch * ((h + m - 1) // m) * ((w + m - 1) // m) * (cin + cout) + cout * cin),
@@ -716,27 +749,35 @@ def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None
             batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False, k_true=0):
     """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous."""
     _chk(a, "a")
-    _chk(b, "b")
+    bp, wfl = _wf(b)
     lda = lda or k
-    ldb = ldb or k
+    if wfl:
+        if ldb not in (0, k) or batch != 1 or b.n != n or b.k != k:
+            raise ValueError("gemm_nt: a split weight is used whole ([n][k] as split)")
+        ldb = b.kp
+    else:
+        ldb = ldb or k
     if out is None:
         out = torch.empty((batch, m, n) if batch > 1 else (m, n), dtype=torch.float32, device=a.device)
         ldc = n
         batch_c = m * n
     e0 = _prof_begin()
     slices = _splitk_slices(m, n, k, batch) if SPLIT_K else 1
+    if wfl and slices > 1 and (k // slices) % 16:
+        slices = 1
     if slices > 1:
         # too few output tiles to fill the chip and a long K: the K range is cut into `slices` batched launches-in-one
         # (blockIdx.z walks K) into fp32 slabs, summed in slice order with the epilogue by a second small kernel
         kc = k // slices
         part = torch.empty((slices, m, n), dtype=torch.float32, device=a.device)
-        lib().call("dana_gemm_nt", _p(a), _p(b), _p(part), None, None, None, m, n, kc, lda, ldb, n, 0, slices, kc, kc,
-                   m * n, 1.0, 0, _stream())
+        # (split planes are K-step-major: slice z's first K-step starts kc * 3 * n bf16 elements after slice z-1's)
+        lib().call("dana_gemm_nt", _p(a), bp, _p(part), None, None, None, m, n, kc, lda, ldb, n, 0, slices, kc,
+                   kc * 3 * n if wfl else kc, m * n, 1.0, wfl, _stream())
         lib().call("dana_splitk_reduce", _p(part), slices, m, n, _p(out), ldc, _p(scale), _p(shift), _p(residual), ldr,
                    float(alpha), EPI_RELU if relu else 0, _stream())
     else:
-        lib().call("dana_gemm_nt", _p(a), _p(b), _p(out), _p(scale), _p(shift), _p(residual), m, n, k, lda, ldb, ldc,
-                   ldr, batch, batch_a, batch_b, batch_c, float(alpha), EPI_RELU if relu else 0, _stream())
+        lib().call("dana_gemm_nt", _p(a), bp, _p(out), _p(scale), _p(shift), _p(residual), m, n, k, lda, ldb, ldc,
+                   ldr, batch, batch_a, batch_b, batch_c, float(alpha), (EPI_RELU if relu else 0) | wfl, _stream())
     _prof_end(e0, ("gemm M=%d N=%d K=%d b%d", (m, n, k, batch)), 2.0 * batch * m * n * (k_true or k),
               4.0 * batch * (m * k + n * k + m * n * (2 if residual is not None else 1)))
     return out

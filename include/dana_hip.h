@@ -27,6 +27,11 @@ typedef void* dana_stream_t; /* hipStream_t */
 /* epilogue flags of dana_conv2d_nhwc / dana_gemm_nt */
 #define DANA_EPI_RELU 1
 #define DANA_CONV_STEM7 2 /* 7x7/2 stem over NHWC4 input, weight packed [cout][7][8][4] */
+/* the weight / `b` / `u` argument points at dana_split_weight's output instead of fp32 rows: three bf16 planes per
+ * 16-wide K-step, [kp / 16][3][n][16], of the SAME values (exact split, kp = k rounded up to 16; dana_gemm_nt: ldb = kp,
+ * batch_b = bf16 elements between the slices' first K-steps). Split kernel only (dana_set_mfma_mode != 0);
+ * results are bit-identical to the fp32-weight call, the K loop just does not repeat the split per tile and step. */
+#define DANA_W_SPLIT3 256
 
 const char* dana_last_error(void);
 int dana_abi_version(void);
@@ -456,6 +461,12 @@ int dana_proposal_target_sample(const int* counts, int B, int n_candidates, int 
 int dana_anchor_target_subsample(float* labels, const int* fg_list, const int* bg_list, const int* counts, int B,
                                  int anchors_per_image, int rpn_batchsize, int num_fg, unsigned long long seed,
                                  unsigned long long offset, float* inv_num_examples, dana_stream_t stream);
+/* fp32 weight rows [batch][n][k] (row stride ldw, batch stride batch_w floats) -> bf16 planes [batch][kp / 16][3][n][16]
+ * (out: dana_split_weight_bytes bytes) for the DANA_W_SPLIT3 flag of the contraction entry points. A weight of the
+ * reference (conv: packed [cout][kh*kw*cin]; nn.Linear: [out][in]) is split once per weight version. */
+size_t dana_split_weight_bytes(int n, int k, int batch);
+int dana_split_weight(const float* w, long ldw, int n, int k, int batch, long batch_w, void* out, dana_stream_t stream);
+
 /* One contraction over TWO concatenated channel segments: out[m][n] = epi(sum_{k<k0} a0[m][k] w[n][k] +
  * sum_{k<k1} a1[pix1(m)][k] w[n][k0+k]) where a0 is an NHWC map on the OUTPUT grid [batch][oh][ow] (pixel stride
  * a0_pix_stride) and a1 an NHWC map [batch][h1][w1] sampled at (oh*stride1, ow*stride1). This is a Caffe-ResNet

@@ -332,3 +332,69 @@ def test_split_k_gemm_matches_single_chain_and_fp64(dev, m, n, k):
     scale = float(ref.abs().max())
     assert float((got.double() - ref).abs().max()) <= 2e-6 * scale * (k ** 0.5)
     assert float((got - one).abs().max()) <= 2e-6 * scale * (k ** 0.5)
+
+
+def test_presplit_weights_are_bit_identical_to_fp32_weights(dev, mfma_mode):
+    """DANA_W_SPLIT3 (ops.split_weight): the B operand split into its three bf16 planes once per weight version feeds the
+    same six products as the in-loop split -> every entry point returns the SAME BITS as with fp32 weight rows. Also the
+    dual-geometry (query + support batch) forms against two single launches."""
+    ops = _ops()
+    if mfma_mode == 0:
+        assert ops.split_weight(torch.zeros(16, 16, device=dev), 16, 16) is None  # f32-MFMA kernel: fp32 weights only
+        return
+    g = torch.Generator().manual_seed(77)
+    for (n, h, w, ci, co, k, st, pad) in [(2, 19, 23, 64, 256, 1, 1, 0), (1, 20, 24, 128, 96, 3, 1, 1), (2, 21, 25, 256, 128, 1, 2, 0),
+                                          (3, 7, 7, 1024, 512, 1, 2, 0), (2, 9, 9, 64, 64, 3, 1, 1)]:
+        x = torch.randn(n * h * w, ci, generator=g).to(dev)
+        wt = (torch.randn(co, k * k * ci, generator=g) / np.sqrt(ci * k * k)).to(dev)
+        sc, sh = (torch.rand(co, generator=g) + 0.5).to(dev), torch.randn(co, generator=g).to(dev)
+        a, oh, ow = ops.conv2d_nhwc(x, n, h, w, ci, wt, co, k, k, st, pad, scale=sc, shift=sh, relu=True)
+        w3 = ops.split_weight(wt, co, k * k * ci)
+        b, _, _ = ops.conv2d_nhwc(x, n, h, w, ci, w3, co, k, k, st, pad, scale=sc, shift=sh, relu=True)
+        assert torch.equal(a, b), (n, h, w, ci, co, k)
+    # GEMM (incl. the split-K route, a K tail of 4 and an N tail), Linear-style column halves of one weight
+    for (m, n, k) in [(300, 256, 1024), (512, 1024, 3136), (100, 72, 512), (77, 40, 36), (4800, 256, 1024)]:
+        a_ = torch.randn(m, k, generator=g).to(dev)
+        b_ = (torch.randn(n, k, generator=g) / np.sqrt(k)).to(dev)
+        ref = ops.gemm_nt(a_, b_, m, n, k)
+        got = ops.gemm_nt(a_, ops.split_weight(b_, n, k), m, n, k)
+        assert torch.equal(ref, got), (m, n, k)
+    wt2 = torch.randn(64, 2048, generator=g).to(dev) / 32
+    a_ = torch.randn(500, 1024, generator=g).to(dev)
+    ref = ops.gemm_nt(a_, wt2.view(-1)[1024:], 500, 64, 1024, ldb=2048)
+    got = ops.gemm_nt(a_, ops.split_weight(wt2.view(-1)[1024:], 64, 1024, ldw=2048), 500, 64, 1024)
+    assert torch.equal(ref, got)
+    # Winograd F(4x4,3x3) with split filter planes; two image groups with one plane GEMM == two single launches
+    n0, h0, w0, n1, h1, w1, ci, co = 2, 19, 31, 3, 10, 10, 128, 160
+    x = torch.randn(n0 * h0 * w0 + n1 * h1 * w1, ci, generator=g).to(dev)
+    wt = (torch.randn(co, 9 * ci, generator=g) / np.sqrt(9 * ci)).to(dev)
+    sc, sh = (torch.rand(co, generator=g) + 0.5).to(dev), torch.randn(co, generator=g).to(dev)
+    u = ops.winograd_filter_transform(wt, co, ci, 4)
+    u3 = ops.split_weight(u, co, ci, batch=36)
+    a0, _, _ = ops.conv3x3_winograd(x, n0, h0, w0, ci, u, co, scale=sc, shift=sh, relu=True)
+    a1, _, _ = ops.conv3x3_winograd(x[n0 * h0 * w0:], n1, h1, w1, ci, u, co, scale=sc, shift=sh, relu=True)
+    b0, _, _ = ops.conv3x3_winograd(x, n0, h0, w0, ci, u3, co, scale=sc, shift=sh, relu=True)
+    assert torch.equal(a0, b0)
+    for filt in (u, u3):
+        d = ops.conv3x3_winograd_dual(x, n0, h0, w0, n1, h1, w1, ci, filt, co, scale=sc, shift=sh, relu=True)
+        assert torch.equal(d[:n0 * h0 * w0], a0) and torch.equal(d[n0 * h0 * w0:], a1)
+    # two-segment expand + strided downsample contraction over two image groups == two single launches
+    k0, k1, co, s_ = 64, 256, 256, 2
+    oh0, ow0, oh1, ow1 = (h0 - 1) // s_ + 1, (w0 - 1) // s_ + 1, (h1 - 1) // s_ + 1, (w1 - 1) // s_ + 1
+    m0, m1 = n0 * oh0 * ow0, n1 * oh1 * ow1
+    t = torch.randn(m0 + m1, k0, generator=g).to(dev)
+    xin = torch.randn(n0 * h0 * w0 + n1 * h1 * w1, k1, generator=g).to(dev)
+    wc = (torch.randn(co, k0 + k1, generator=g) / 16).to(dev)
+    shc = torch.randn(co, generator=g).to(dev)
+    r0, _, _ = ops.conv1x1_cat2(t, k0, xin, k1, n0, h0, w0, s_, wc, shc, co)
+    r1, _, _ = ops.conv1x1_cat2(t[m0:], k0, xin[n0 * h0 * w0:], k1, n1, h1, w1, s_, wc, shc, co)
+    for filt in (wc, ops.split_weight(wc, co, k0 + k1)):
+        d0, d1, _, _ = ops.conv1x1_cat2_dual(t, k0, xin, k1, n0, h0, w0, n1, h1, w1, s_, filt, shc, co)
+        assert torch.equal(d0[:m0], r0) and torch.equal(d1[:m1], r1)
+    # the 7x7 stem over NHWC4 with its packed [64][7][8][4] weight
+    im = torch.randn(2, 3, 64, 80, generator=g).to(dev)
+    x4 = ops.nchw_to_nhwc(im, cpad=4)
+    wst = ops.pack_conv_weight((torch.randn(64, 3, 7, 7, generator=g) / 12).to(dev), stem=True)
+    a, _, _ = ops.conv2d_nhwc(x4, 2, 64, 80, 4, wst, 64, 7, 7, 2, 3, relu=True, stem=True)
+    b, _, _ = ops.conv2d_nhwc(x4, 2, 64, 80, 4, ops.split_weight(wst, 64, wst.numel() // 64), 64, 7, 7, 2, 3, relu=True, stem=True)
+    assert torch.equal(a, b)
