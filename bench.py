@@ -78,6 +78,18 @@ def parse():
     return ap.parse_args()
 
 
+def config_label(args):
+    """which BASELINE.json configuration the arguments are (per-GPU shape), or that they are none of them"""
+    if args.model != "DAnA" or args.support_size != 320 or args.way != 2:
+        return "no BASELINE configuration"
+    if (args.height, args.width, args.shot) == (600, 1000, 3) and args.batch == 4:
+        return "BASELINE configs[2]" if args.ba else "BASELINE configs[1]"
+    if (args.height, args.width, args.shot) == (800, 1333, 10) and args.ba:
+        return "BASELINE configs[4] (per-GPU shape: %d of its 16 episodes%s)" % (
+            args.batch, "" if args.batch == 2 else "; the configuration puts 2 on each of 8 GPUs")
+    return "no BASELINE configuration (configs[2]'s model at another shape)"
+
+
 def cpu_baseline(args, sd):
     """The oracle port (oracle/model_ref.py) on the host cores: ONE episode of the same workload."""
     from dana_amd import synthetic as S
@@ -289,11 +301,18 @@ def main():
         kt = max(5, min(20, args.steps))
         launch_trial = {"graph_ms_per_step": round(trial(graph_step, kt), 3), "eager_ms_per_step": round(trial(eager_step, kt), 3),
                         "steps_each": kt}
-        if world > 1:  # every rank must take the same path
+        prefer_eager = launch_trial["eager_ms_per_step"] < launch_trial["graph_ms_per_step"]
+        if world > 1:
+            # every rank must take the same path, and N ranks share the host's cores: graph replay (a few launches per
+            # step) unless the trial prefers eager issue on EVERY rank
             t = torch.tensor([launch_trial["graph_ms_per_step"], launch_trial["eager_ms_per_step"]], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             launch_trial["graph_ms_per_step"], launch_trial["eager_ms_per_step"] = round(float(t[0]), 3), round(float(t[1]), 3)
-        if launch_trial["eager_ms_per_step"] < launch_trial["graph_ms_per_step"]:
+            v = torch.tensor([1.0 if prefer_eager else 0.0], device=dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            prefer_eager = bool(v.item() > 0.5)
+            launch_trial["ranks_preferring_eager"] = "all" if prefer_eager else "not all"
+        if prefer_eager:
             step = eager_step
     timed_graphs = use_graphs and step is not eager_step
     for _ in range(args.warmup):
@@ -333,10 +352,13 @@ def main():
         marks_f[-1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = torch.zeros(world, device=dev, dtype=torch.float64)
+        every[rank] = dt
+        dist.all_reduce(every)  # (a straggler must be visible: every rank's own time next to the max the metric uses)
+        per_rank_ms = [round(1000.0 * float(x) / args.steps, 3) for x in every.tolist()]
+        dt = float(every.max().item())
 
     host_ms_graph = host_enqueue_ms(graph_step) if use_graphs else None
     host_ms_eager = host_enqueue_ms(eager_step, 10)
@@ -355,6 +377,8 @@ def main():
         "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "ms_per_episode": round(1000.0 * dt / args.steps / args.batch, 3),
         "ms_per_step_median": median_interval(marks_f),
+        "ms_per_step_per_rank": ({"min": min(per_rank_ms), "max": max(per_rank_ms), "all": per_rank_ms}
+                                 if per_rank_ms else None),
         "launch": ("hipGraph replay, %d graph launches per step (graphs.py)" % (
             (len(graphed["trainer"].graphs) + (graphed["trainer"].g_anchor is not None)) if args.mode == "step" else
             (1 + (graphed["forward"].g0 is not None) + (graphed["forward"].g2 is not None))))
@@ -368,9 +392,9 @@ def main():
                  if ops.get_mfma_mode() else "f32",
         "data": "synthetic (seeded N(0,64^2) query/support pixels, 3 gt boxes/image, random-init weights)",
         "config": {"workload": ("" if args.model == "DAnA" else "[sibling detector '%s'] " % args.model) +
-                               "BASELINE configs[%d]: res50 way=%d shot=%d bs=%d, %dx%d queries + %d %dx%d "
+                               "%s: res50 way=%d shot=%d bs=%d, %dx%d queries + %d %dx%d "
                                "supports/episode%s, %s, %s" % (
-                                   2 if args.ba else 1, args.way, args.shot, args.batch, args.height, args.width,
+                                   config_label(args), args.way, args.shot, args.batch, args.height, args.width,
                                    way * args.shot, args.support_size, args.support_size,
                                    "" if args.support_size == 320 else " (generalised support pooling: NOT a reference "
                                    "configuration, no oracle)", "BA+CISA" if args.ba else "CISA only", what),
@@ -401,11 +425,15 @@ def main():
             if args.launch == "auto":
                 ts_trial = {"graph_ms_per_step": round(trial(graph_train_step, 8), 3),
                             "eager_ms_per_step": round(trial(eager_train_step, 8), 3)}
+                ts_eager = ts_trial["eager_ms_per_step"] < ts_trial["graph_ms_per_step"]
                 if world > 1:
                     t = torch.tensor([ts_trial["graph_ms_per_step"], ts_trial["eager_ms_per_step"]], device=dev)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     ts_trial["graph_ms_per_step"], ts_trial["eager_ms_per_step"] = round(float(t[0]), 3), round(float(t[1]), 3)
-                if ts_trial["eager_ms_per_step"] < ts_trial["graph_ms_per_step"]:
+                    v = torch.tensor([1.0 if ts_eager else 0.0], device=dev)
+                    dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                    ts_eager = bool(v.item() > 0.5)
+                if ts_eager:
                     train_step = eager_train_step
             for _ in range(3):
                 train_step()
@@ -438,6 +466,23 @@ def main():
                                          "eager": host_enqueue_ms(eager_train_step, 5)},
         }
 
+    tprof, tprof_steps = None, 0
+    if "train_step" in result and not args.no_roofline:
+        # variant S's roofline: per-launch brackets over the whole training iteration (forward + data gradients + weight
+        # gradients), one stream. EVERY rank runs these iterations (they carry the gradient all-reduce: a rank-0-only
+        # pass would wait for its peers forever); rank 0 reports its own launches.
+        ops.PROFILE = []
+        model._single_stream = True
+        tprof_steps = max(2, min(5, args.steps))
+        for _ in range(2):
+            eager_train_step()
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        for _ in range(tprof_steps):
+            eager_train_step()
+        torch.cuda.synchronize()
+        model._single_stream = bool(args.single_stream)
+        tprof, ops.PROFILE = ops.PROFILE, None
     if rank == 0 and not args.no_roofline and args.mode != "step":
         # dominant kernel family: the implicit-GEMM contraction (every conv / Linear / bmm). Same K steps, each launch
         # bracketed by HIP events recorded on the stream the kernel is launched on (torch's current stream).
@@ -536,6 +581,64 @@ def main():
                 result["roofline"]["traffic_source"] = "profiles/r2_pmc_traffic.json (committed PMC run, not this run)"
             except (OSError, KeyError, ValueError):
                 pass
+        if tprof is not None:
+            kts = tprof_steps
+            def kind_of(tag):
+                t0_ = tag.split(" ")[0]
+                return "wgrad" if t0_.startswith("wgrad") else ("dgrad" if t0_.startswith("dgrad") else "forward_and_linear_adjoints")
+
+            fam = {}
+            for row in tprof:
+                a = fam.setdefault(kind_of(row[0]), [0.0, 0.0, 0.0, 0])
+                a[0] += row[1]
+                a[1] += row[5]
+                a[2] += row[2].elapsed_time(row[3]) * 1e-3
+                a[3] += 1
+            ft, xt, tt = sum(a[0] for a in fam.values()), sum(a[1] for a in fam.values()), sum(a[2] for a in fam.values())
+            result["train_step"]["roofline"] = {
+                "bound": "mfma", "achieved": round(ft / tt / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ft / tt / 1e12 / peak, 4),
+                "algorithmic_gflop_per_step": round(ft / kts / 1e9, 1), "executed_gflop_per_step": round(xt / kts / 1e9, 1),
+                "kernel_ms_per_step": round(tt * 1e3 / kts, 3), "launches_per_step": len(tprof) // kts,
+                "families": {k: {"algorithmic_tflops": round(a[0] / a[2] / 1e12, 2), "frac_of_peak": round(a[0] / a[2] / 1e12 / peak, 4),
+                                 "ms_per_step": round(a[2] * 1e3 / kts, 3), "gflop_per_step": round(a[0] / kts / 1e9, 1),
+                                 "launches_per_step": a[3] // kts} for k, a in sorted(fam.items())},
+                "what": "every contraction launch of the iteration (igemm_split_kernel, wgrad_split_128_kernel, the "
+                        "Winograd-domain forward / data-gradient / weight-gradient launches with their transforms), each "
+                        "bracketed alone on one stream; forward_and_linear_adjoints = the forward's launches plus the "
+                        "GEMMs of the Linear / attention adjoints",
+            }
+        if rank == 0 and args.model == "DAnA" and training and not args.no_secondary:
+            # the same step with the query and the support batch sharing ONE launch per trunk conv (model.merge_trunk,
+            # merge_from 0): fewer, fuller launches -- a better per-launch roofline -- but a single stream of them, and the
+            # two-stream default overlaps each launch's tail with the other batch's kernels. Both are reported.
+            keep_merge = (model.merge_trunk, model.merge_from)
+            model.merge_trunk, model.merge_from = True, 0
+            for _ in range(3):
+                eager_step()
+            torch.cuda.synchronize()
+            km = max(5, args.steps // 4)
+            t0 = time.perf_counter()
+            for _ in range(km):
+                eager_step()
+            torch.cuda.synchronize()
+            dtm = time.perf_counter() - t0
+            keep_steps, args.steps = args.steps, km
+            profm = contraction_pass()
+            args.steps = keep_steps
+            model.merge_trunk, model.merge_from = keep_merge
+            fm, xm, tm_ = family(profm)
+            dm = [r for r in profm if not r[0].startswith("wino")]
+            fdm, _xdm, tdm = family(dm)
+            result["merged_trunk"] = {
+                "what": "query + support batch in one launch per trunk conv (dual-geometry contraction, one batched Winograd "
+                        "plane GEMM), eager",
+                "value": round(args.batch * km / dtm, 3), "unit": result["unit"], "ms_per_step": round(dtm / km * 1e3, 3),
+                "roofline": {"achieved": round(fm / tm_ / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                             "frac": round(fm / tm_ / 1e12 / peak, 4), "launches_per_step": len(profm) // km,
+                             "kernel_ms_per_step": round(tm_ * 1e3 / km, 3),
+                             "direct_frac_of_peak": round(fdm / tdm / 1e12 / peak, 4)},
+            }
         if split and not args.no_secondary:
             # For reference: the same step and the same contraction pass with every contraction on the f32 MFMA.
             ops.set_mfma_mode(0)

@@ -258,6 +258,11 @@ class DAnARCNN(nn.Module):
         return self
 
     # ---- weight plan: packed conv weights + folded BN, cached by parameter versions ------------
+    def _live(self):
+        """this forward belongs to a training iteration: the optimizer is about to rewrite the trainable weights, so
+        per-version derived copies that only pay when reused (the split planes) are not made for them"""
+        return self.training and (torch.is_grad_enabled() or getattr(self, "save_for_backward", False))
+
     def _sig(self):
         dev = str(self.RCNN_bbox_pred.weight.device)
         cached = self._consts.get("sig_tensors")
@@ -265,14 +270,15 @@ class DAnARCNN(nn.Module):
             cached = (dev, list(self.state_dict(keep_vars=True).values()))
             self._consts["sig_tensors"] = cached
         return (dev, self.use_winograd, self.winograd_min_cin, self.winograd_tile, self._epoch, ops.get_mfma_mode(),
-                self.presplit_weights) + tuple(
+                self.presplit_weights, self._live()) + tuple(
             t._version for t in cached[1])
 
     def _conv_bn(self, conv, bn, stem=False):
         """packed weight + folded frozen BN (+ Winograd filter) of one conv, re-derived only when ITS tensors changed:
         a training step touches the trainable conv weights only (BN and conv1/layer1 are frozen, dana.py:350-385)"""
         wsig = (conv.weight.data_ptr(), conv.weight._version, self._epoch if conv.weight.requires_grad else -1,
-                self.use_winograd, self.winograd_min_cin, self.winograd_tile, ops.get_mfma_mode(), self.presplit_weights)
+                self.use_winograd, self.winograd_min_cin, self.winograd_tile, ops.get_mfma_mode(), self.presplit_weights,
+                self._live() and conv.weight.requires_grad)
         bsig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
         e = self._conv_cache.get(id(conv))
         if e is not None and e["wsig"] == wsig and e["bsig"] == bsig:
@@ -290,7 +296,9 @@ class DAnARCNN(nn.Module):
             d["u"] = ops.winograd_filter_transform(w, d["cout"], d["cin"], self.winograd_tile)
         # the contraction's B operand, split into its three bf16 planes once per weight version (ops.split_weight; None
         # with the f32-MFMA kernel): "w" / "u" stay fp32 for the backward's derived weights
-        if self.presplit_weights:
+        # (a weight that the optimizer rewrites every iteration would be re-split every iteration: ~60 small launches per
+        # step for ~1 % of the forward -- frozen weights and inference only)
+        if self.presplit_weights and not (self._live() and conv.weight.requires_grad):
             if d["u"] is not None and d["u"].size(0) == 36:
                 d["us"] = ops.split_weight(d["u"], d["cout"], d["cin"], batch=36)
             else:
@@ -311,8 +319,9 @@ class DAnARCNN(nn.Module):
             if e is None or e["sig"] != sig:
                 w_cat, shift = ops.pack_cat2_weight(c3["w"], c3["scale"], c3["shift"], c3["cin"], ds["w"], ds["scale"],
                                                     ds["shift"], ds["cin"], c3["cout"])
+                live = self._live() and (blk.conv3.weight.requires_grad or blk.downsample[0].weight.requires_grad)
                 e = self._conv_cache[("cat", id(blk))] = dict(sig=sig, w=w_cat, shift=shift, ws=(
-                    ops.split_weight(w_cat, c3["cout"], c3["cin"] + ds["cin"]) if self.presplit_weights else None))
+                    ops.split_weight(w_cat, c3["cout"], c3["cin"] + ds["cin"]) if self.presplit_weights and not live else None))
             d["cat"] = e
         return d
 
@@ -333,7 +342,8 @@ class DAnARCNN(nn.Module):
                            if self.use_winograd and rpn.din >= self.winograd_min_cin else None)
         p["rpn_conv_b"] = rpn.RPN_Conv.bias.detach().contiguous()
         p["rpn_conv_b3"] = None  # B operand of the RPN conv as split planes (Winograd filters or the packed weight)
-        if self.presplit_weights:
+        live = self._live() and rpn.RPN_Conv.weight.requires_grad
+        if self.presplit_weights and not live:
             if p["rpn_conv_u"] is not None and p["rpn_conv_u"].size(0) == 36:
                 p["rpn_conv_b3"] = ops.split_weight(p["rpn_conv_u"], 512, rpn.din, batch=36)
             elif p["rpn_conv_u"] is None:
@@ -342,7 +352,7 @@ class DAnARCNN(nn.Module):
                                      rpn.RPN_bbox_pred.weight.detach().view(rpn.nc_bbox_out, -1)], 0).contiguous()
         p["rpn_head_b"] = torch.cat([rpn.RPN_cls_score.bias.detach(), rpn.RPN_bbox_pred.bias.detach()], 0).contiguous()
         p["rpn_head_w3"] = (ops.split_weight(p["rpn_head_w"], p["rpn_head_w"].size(0), p["rpn_head_w"].size(1))
-                            if self.presplit_weights else None)
+                            if self.presplit_weights and not live else None)
         ck = ("tables", str(dev), tuple(cfg.ANCHOR_SCALES), tuple(cfg.ANCHOR_RATIOS))
         tables = self._consts.get(ck)
         if tables is None:  # weight-independent constants: built once per device, not per weight update
@@ -389,7 +399,7 @@ class DAnARCNN(nn.Module):
         w = layer.weight
         n, ktot = w.size(0), w[0].numel()
         k = cols or ktot
-        if not self.presplit_weights or ops.get_mfma_mode() == 0 or n <= 8:
+        if not self.presplit_weights or ops.get_mfma_mode() == 0 or n <= 8 or (self._live() and w.requires_grad):
             return w.detach().contiguous().view(-1)[col0:], ktot
         key = ("lin3", id(layer), col0, k)
         sig = (w.data_ptr(), w._version, self._epoch if w.requires_grad else -1)

@@ -485,3 +485,42 @@ def test_sibling_backward_vs_oracle_autograd_and_trainer_step(dev, mfma_mode, na
     assert all(np.isfinite(float(x.detach())) for x in o[3:7])
     moved = sum(1 for k, v in m.named_parameters() if v.requires_grad and not torch.equal(v.detach(), before[k]))
     assert moved >= len(before) - 2, "only %d of %d trainable tensors moved" % (moved, len(before))
+
+
+@pytest.mark.parametrize("merge_from", [0, 2, 3])
+def test_merged_trunk_modes_equal_the_two_stream_trunk(dev, mfma_mode, merge_from):
+    """DAnARCNN.merge_trunk: query + support batch through one set of [query | support] activation buffers, the stages
+    >= merge_from with ONE launch per conv over both batches (dual-geometry contraction / dual-group Winograd), the
+    earlier ones as two launches on two streams. Same kernels, same per-element summation order -> the forward outputs
+    are the SAME BITS as the default (two independent trunk calls) and so is every gradient of the training backward."""
+    import dana_amd
+    from dana_amd import synthetic as S, backward as BW
+    B, way, shot, H, W = 2, 2, 2, 160, 224
+    outs, grads = [], []
+    for merged in (False, True):
+        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=way, shot=shot, classes=["fg", "bg"])
+        m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=21, profile="test"))
+        m.to(dev).train()
+        m.merge_trunk, m.merge_from = merged, merge_from
+        m.save_for_backward = True
+        inputs = [t.to(dev) for t in S.episode_inputs(B, way, shot, H, W, seed=4)]
+        np.random.seed(7)
+        with torch.no_grad():
+            out = m(*inputs)
+        for p_ in m.parameters():
+            p_.grad = None
+        BW.model_backward(m, (1.0, 1.0, 1.0, 1.0))
+        torch.cuda.synchronize()
+        outs.append([t.detach().clone() if torch.is_tensor(t) else t for t in out])
+        grads.append({k: p_.grad.detach().clone() for k, p_ in m.named_parameters() if p_.grad is not None})
+    for a, b in zip(*outs):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b)
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) >= 60
+    for k in grads[0]:
+        ga, gb = grads[0][k], grads[1][k]
+        if "RCNN_base" in k or "RCNN_top" in k:
+            # (RoIAlign-backward atomics are unordered: the trunk's gradients agree to roundoff, not bits)
+            assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-12, k
+        else:
+            assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-12, k
