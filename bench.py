@@ -135,7 +135,7 @@ def pmc_passes(args, kernel):
             "--mode", args.mode] + ([] if args.ba else ["--no-ba"])
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
-    short = kernel.replace(" ", "")
+    short = kernel.replace(" ", "").rstrip(">")  # (prefix match: the BPRE template argument follows BM, BN, STEM)
     sums = {}
     for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]):
         out = tempfile.mkdtemp(prefix="dana_pmc_", dir="/tmp")
@@ -575,10 +575,13 @@ def main():
             result["roofline"].update(pmc)
         else:
             try:
-                with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")) as fh:
                     j = json.load(fh)
-                result["roofline"]["traffic"] = round(j[traffic_kernel]["hbm_bytes_per_launch_corrected"])
-                result["roofline"]["traffic_source"] = "profiles/r2_pmc_traffic.json (committed PMC run, not this run)"
+                pre = traffic_kernel.replace(" ", "").rstrip(">")
+                ms_ = [v for k, v in j.items() if k.replace(" ", "").startswith(pre)]
+                result["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ms_) /
+                                                      sum(v["launches"] for v in ms_))
+                result["roofline"]["traffic_source"] = "profiles/r3_pmc_traffic.json (committed PMC run, not this run)"
             except (OSError, KeyError, ValueError):
                 pass
         if tprof is not None:

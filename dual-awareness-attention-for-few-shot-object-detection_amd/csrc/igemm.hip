@@ -33,6 +33,7 @@
 #include "common.h"
 #include "../../include/dana_hip.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -1090,20 +1091,25 @@ int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
 // barrier/staging bubbles of the 64-cycle f32 MFMA better than 2 blocks of 128x128, and its finer
 // granularity shortens the tail (a CU finishes ceil(tiles/256) tiles while the average is tiles/256).
 // DANA_IGEMM_TILE=1|2|3 forces 128x128 | 128x64 | 64x64 for tuning.
-int g_mfma_mode = -1;  // -1: read DANA_MFMA_SPLIT on first use
+// Process-wide kernel choice (every device, every thread: nn.DataParallel's replica threads all see the same value).
+// An atomic that is initialised ONCE from DANA_MFMA_SPLIT (thread-safe function-local static) and read ONCE per call:
+// a call never mixes modes, concurrent callers never race on the first read. dana_set_mfma_mode is a configuration
+// call -- issue it between forwards, not while other threads are inside one.
+std::atomic<int>& mfma_mode_cell() {
+  static std::atomic<int> cell(getenv("DANA_MFMA_SPLIT") ? atoi(getenv("DANA_MFMA_SPLIT")) : 1);
+  return cell;
+}
 unsigned long long* g_trace = nullptr;  // debug: per-block timestamps of the next split launches (dana_set_igemm_trace)
 
 int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   if (stem) {
-    const int smode = g_mfma_mode < 0 ? (g_mfma_mode = getenv("DANA_MFMA_SPLIT") ? atoi(getenv("DANA_MFMA_SPLIT")) : 1)
-                                      : g_mfma_mode;
+    const int smode = mfma_mode_cell().load(std::memory_order_relaxed);
     return smode ? launch_split<128, 64, 1>(p, batch, s) : launch<128, 64, 1>(p, batch, s);
   }
   // fp32 contractions run on the bf16 matrix cores by default (exact 3-way split, 6 products: igemm_split_kernel);
   // dana_set_mfma_mode(0) / DANA_MFMA_SPLIT=0 selects the f32-MFMA kernel. 128x128 blocks amortise the split best; a
   // launch that cannot give most CUs one of those falls back to 64x64 blocks (measured: tools/conv_sweep.py).
-  const int mode = g_mfma_mode < 0 ? (g_mfma_mode = getenv("DANA_MFMA_SPLIT") ? atoi(getenv("DANA_MFMA_SPLIT")) : 1)
-                                   : g_mfma_mode;
+  const int mode = mfma_mode_cell().load(std::memory_order_relaxed);
   if (mode && p.KH * p.KW <= 32) {
     if (mode == 2) return launch_split<128, 64>(p, batch, s);
     if (mode == 3) return launch_split<64, 64>(p, batch, s);
@@ -1145,7 +1151,7 @@ extern "C" {
 
 int dana_set_mfma_mode(int mode) {
   DANA_CHECK_ARG(mode >= 0 && mode <= 5, "dana_set_mfma_mode: mode must be 0 (f32 MFMA) or 1 (bf16x6 split; 2-5: forced tiles)");
-  g_mfma_mode = mode;
+  mfma_mode_cell().store(mode, std::memory_order_relaxed);
   return DANA_OK;
 }
 
@@ -1155,8 +1161,7 @@ int dana_set_igemm_trace(unsigned long long* buffer) {
 }
 
 int dana_get_mfma_mode(void) {
-  if (g_mfma_mode < 0) g_mfma_mode = getenv("DANA_MFMA_SPLIT") ? atoi(getenv("DANA_MFMA_SPLIT")) : 1;
-  return g_mfma_mode;
+  return mfma_mode_cell().load(std::memory_order_relaxed);
 }
 
 static int conv2d_impl(const char* who, const float* input, const float* weight, float* out0, float* out1,

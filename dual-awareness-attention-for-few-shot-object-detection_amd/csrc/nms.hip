@@ -306,18 +306,22 @@ int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, 
   // Band edges in units of max_keep boxes x 100 (DANA_NMS_BANDS="250,500": the first pass covers 2.5 x max_keep boxes,
   // the second up to 5 x, the last the rest; "0": a single pass). An edge that would leave less than a quarter of the
   // problem for the later bands is dropped.
-  static int edges_pct[8], n_edges = -1;
-  if (n_edges < 0) {
-    const char* e = getenv("DANA_NMS_BANDS");
-    if (!e) e = "250,500";
-    n_edges = 0;
-    while (*e && n_edges < 8) {
-      const int v = atoi(e);
-      if (v > 0) edges_pct[n_edges++] = v;
-      while (*e && *e != ',') ++e;
-      if (*e == ',') ++e;
+  struct Bands {
+    int pct[8], n;
+    Bands() : n(0) {  // (parsed once, under the thread-safe initialisation of the function-local static below)
+      const char* e = getenv("DANA_NMS_BANDS");
+      if (!e) e = "250,500";
+      while (*e && n < 8) {
+        const int v = atoi(e);
+        if (v > 0) pct[n++] = v;
+        while (*e && *e != ',') ++e;
+        if (*e == ',') ++e;
+      }
     }
-  }
+  };
+  static const Bands bands;
+  const int* edges_pct = bands.pct;
+  const int n_edges = bands.n;
   int edge[10], nb = 0;  // band i = column blocks [edge[i], edge[i+1])
   edge[nb++] = 0;
   // (worth it only when the full triangle is a real cost: a band that turns out to be needed adds ~25 us of restart)

@@ -168,6 +168,7 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba, mfma_mode):
     params = dict(m.named_parameters())
     worst = []
     gmax = max(v.grad.abs().max().item() for v in osd.values() if v.dtype.is_floating_point and v.requires_grad)
+    worst_l2 = []
     for k, v in osd.items():
         if not (v.dtype.is_floating_point and v.requires_grad):
             continue
@@ -178,8 +179,14 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba, mfma_mode):
         # round-off there (1e-9), hence the floor relative to the largest gradient of the model
         scale = v.grad.abs().max().item() + 1e-3 * gmax
         worst.append(((g.cpu() - v.grad).abs().max().item() / scale, k, scale))
+        # ... and in the L2 sense: ||g - g_ref|| / (||g_ref|| + floor); measured <= 4e-5 in the trunk, <= 7e-4 in layer4
+        # (fp32 summation order over 4 096-row reductions on both sides)
+        l2 = (g.cpu() - v.grad).double().norm().item() / (v.grad.double().norm().item() + 1e-3 * gmax * v.grad.numel() ** 0.5)
+        worst_l2.append((l2, k))
     worst.sort(reverse=True)
+    worst_l2.sort(reverse=True)
     assert worst[0][0] <= 5e-3, "largest relative gradient errors: %s" % (worst[:8],)
+    assert worst_l2[0][0] <= 1.5e-3, "largest relative L2 gradient errors: %s" % (worst_l2[:8],)
 
 
 def test_trainer_step_matches_reference_loop_with_torch_sgd(dev):
