@@ -45,17 +45,18 @@ rowdot_kernel(const float* __restrict__ x, const float* __restrict__ w, const fl
 
 // in-place softmax over the last dim of x[G][L] (ld = row stride); one wave per row
 __global__ void __launch_bounds__(256)
-softmax_rows_kernel(float* __restrict__ x, long G, int L, long ld) {
+softmax_rows_kernel(float* __restrict__ x, long G, int L, long ld, const float* __restrict__ src = nullptr, long ld_src = 0) {
   const int lane = threadIdx.x & 63;
   const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (g >= G) return;
   float* r = x + g * ld;
+  const float* in = src ? src + g * ld_src : r;  // (src: out-of-place, the scores stay as they are)
   float m = -FLT_MAX;
-  for (int l = lane; l < L; l += 64) m = fmaxf(m, r[l]);
+  for (int l = lane; l < L; l += 64) m = fmaxf(m, in[l]);
   m = wave_max(m);
   float s = 0.f;
   for (int l = lane; l < L; l += 64) {
-    const float e = expf(r[l] - m);
+    const float e = expf(in[l] - m);
     r[l] = e;
     s += e;
   }
@@ -195,6 +196,17 @@ int dana_softmax_rows(float* x, long groups, int length, long ld, dana_stream_t 
   if (ld <= 0) ld = length;
   softmax_rows_kernel<<<dana_ceil_div(groups, 4), 256, 0, (hipStream_t)stream>>>(x, groups, length, ld);
   DANA_CHECK_LAUNCH("dana_softmax_rows");
+  return DANA_OK;
+}
+
+int dana_softmax_rows_to(const float* x, float* out, long groups, int length, long ld_in, long ld_out, dana_stream_t stream) {
+  DANA_CHECK_ARG(groups >= 0 && length > 0, "dana_softmax_rows_to: bad shape");
+  if (groups == 0) return DANA_OK;
+  DANA_CHECK_ARG(x && out, "dana_softmax_rows_to: null pointer");
+  if (ld_in <= 0) ld_in = length;
+  if (ld_out <= 0) ld_out = length;
+  softmax_rows_kernel<<<dana_ceil_div(groups, 4), 256, 0, (hipStream_t)stream>>>(out, groups, length, ld_out, x, ld_in);
+  DANA_CHECK_LAUNCH("dana_softmax_rows_to");
   return DANA_OK;
 }
 

@@ -391,10 +391,11 @@ colmean_apply_kernel(float* __restrict__ x, const float* __restrict__ partial, i
   for (int l = l0 + rl; l < l1; l += 4) base[(long)l * ld + col] -= mean;
 }
 
-// batched transpose in[g][R][C] -> out[g][C][ldo] (32x32 LDS tiles); columns R..ldo-1 are left untouched
+// batched transpose in[g][R][C] -> out[g][C][ldo] (32x32 LDS tiles); zero_pad: the grid covers ldo (not R) output
+// columns and columns R..ldo-1 are written as zeros (a K-padded GEMM operand needs no separate fill launch)
 __global__ void __launch_bounds__(256)
 transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, long ldi, long ldo,
-                 long in_batch, long out_batch) {
+                 long in_batch, long out_batch, int zero_pad) {
   __shared__ float t[32][33];
   const float* ib = in + (long)blockIdx.z * in_batch;
   float* ob = out + (long)blockIdx.z * out_batch;
@@ -407,8 +408,17 @@ transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, i
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int c = c0 + j, r = r0 + tx;
-    if (c < C && r < R) ob[(long)c * ldo + r] = t[tx][j];
+    if (c < C && (r < R || (zero_pad && r < ldo))) ob[(long)c * ldo + r] = t[tx][j];  // (t holds zeros for r >= R)
   }
+}
+
+// rois_label of the training forward (dana.py:191-194): labels of the positive-support head, zeros for the
+// negative-support head, as int64 [2n] -- one launch instead of a float->long copy, a fill and a cat
+__global__ void __launch_bounds__(256)
+labels_posneg_kernel(const float* __restrict__ labels, long long* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * n) return;
+  out[i] = i < n ? (long long)labels[i] : 0ll;
 }
 
 // Adjoint of a TRAIN-mode BatchNorm (batch statistics; fgn.py:147-153's bn1 / bn2): with xhat = (x - mean) * istd,
@@ -765,9 +775,19 @@ int dana_transpose_batched(const float* in, float* out, int groups, int rows, in
   DANA_CHECK_ARG(groups >= 0 && rows > 0 && cols > 0 && ldi >= cols && ldo >= rows, "dana_transpose_batched: bad shape");
   if (groups == 0) return DANA_OK;
   DANA_CHECK_ARG(in && out, "dana_transpose_batched: null pointer");
-  dim3 grid(dana_ceil_div(cols, 32), dana_ceil_div(rows, 32), groups);
-  transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, out, rows, cols, ldi, ldo, in_batch, out_batch);
+  const int zero_pad = ldo > rows ? 1 : 0;  // (the output rows' tail is part of the result: zeros)
+  dim3 grid(dana_ceil_div(cols, 32), dana_ceil_div(zero_pad ? (int)ldo : rows, 32), groups);
+  transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, out, rows, cols, ldi, ldo, in_batch, out_batch, zero_pad);
   DANA_CHECK_LAUNCH("dana_transpose_batched");
+  return DANA_OK;
+}
+
+int dana_labels_posneg_i64(const float* labels, long long* out, long n, dana_stream_t stream) {
+  DANA_CHECK_ARG(n >= 0, "dana_labels_posneg_i64: bad shape");
+  if (n == 0) return DANA_OK;
+  DANA_CHECK_ARG(labels && out, "dana_labels_posneg_i64: null pointer");
+  labels_posneg_kernel<<<dana_ceil_div(2 * n, 256), 256, 0, (hipStream_t)stream>>>(labels, out, n);
+  DANA_CHECK_LAUNCH("dana_labels_posneg_i64");
   return DANA_OK;
 }
 

@@ -919,7 +919,7 @@ class DAnARCNN(nn.Module):
             if tl is not None:
                 tl.append(("rpn losses + proposal targets (waits for rois)", _time.perf_counter()))
             labels_f = rois_label.reshape(-1).contiguous()
-            rois_label = labels_f.long()
+            rois_label = None  # (int64 [2n], built with the negative head's zeros at the end: ops.labels_posneg)
             rois_target = rois_target.view(-1, 4)
             rois_inside_ws = rois_inside_ws.view(-1, 4)
             rois_outside_ws = rois_outside_ws.view(-1, 4)
@@ -977,6 +977,9 @@ class DAnARCNN(nn.Module):
         q_ready = torch.cuda.Event()
         q_ready.record()
 
+        # cls_prob of both heads in one buffer (positive rows, then negative rows: the torch.cat of dana.py:193)
+        prob_all = torch.empty((2 * n_roi if training else n_roi, 2), dtype=torch.float32, device=dev)
+
         def head(offset):  # offset 0: positive supports, `shot`: negatives (dana.py:189-190)
             kb = k2.view(-1)[offset * P2 * dq:]
             ub = un2.view(-1)[offset * P2:]
@@ -994,7 +997,7 @@ class DAnARCNN(nn.Module):
                              residual=tr_q, ldr=self.rcnn_dim)  # [n*49][64] == [n][3136]
             hid = ops.gemm_nt(tr, w1b3, n_roi, w1.size(0), P2 * self.rcnn_dim, ldb=w1ld, shift=b1, relu=True)
             score = ops.gemm_nt(hid, w2, n_roi, 2, w1.size(0), shift=b2)
-            prob = ops.softmax_rows_(score.clone(), n_roi, 2)
+            prob = ops.softmax_rows_to(score, prob_all[(n_roi if offset else 0):], n_roi, 2)[:n_roi]
             if ctx is not None:
                 ctx["heads"].append(dict(offset=offset, sc2=sc2, dense=dense, tr=tr, hid=hid))
             return prob, score
@@ -1008,7 +1011,7 @@ class DAnARCNN(nn.Module):
                 neg_prob, neg_score = head(shot)
                 for t_ in (neg_prob, neg_score):
                     t_.record_stream(main)
-                for t_ in (q2, tr_q, q_pe):
+                for t_ in (q2, tr_q, q_pe, prob_all):
                     t_.record_stream(neg_stream)
                 neg_done = torch.cuda.Event()
                 neg_done.record()
@@ -1024,8 +1027,8 @@ class DAnARCNN(nn.Module):
             tl.append(("enqueued roialign..head", _time.perf_counter()))
         RCNN_loss_cls = RCNN_loss_bbox = 0
         if training:
-            cls_prob = torch.cat([cls_prob, neg_prob], 0)
-            rois_label = torch.cat([rois_label, torch.zeros_like(rois_label)], 0)
+            cls_prob = prob_all  # (both heads wrote their halves)
+            rois_label = ops.labels_posneg(labels_f)
             # box smooth-L1 + 2-way cross-entropy with the 1:2:1 hard-negative mining (dana.py:203-217): one fused
             # pass on the device, no host sync (the nonzero / sort / index chain of the reference has three)
             rl, seeds = ops.rcnn_losses(cls_score_all, neg_score, labels_f, bbox_pred,

@@ -942,8 +942,8 @@ def transpose_batched(x, groups, rows, cols, ldi=0, out=None, ldo=0, in_batch=0,
     ldo = ldo or rows
     in_batch = in_batch or rows * ldi
     out_batch = out_batch or cols * ldo
-    if out is None:
-        out = torch.zeros((groups, cols, ldo), dtype=torch.float32, device=x.device)
+    if out is None:  # (the kernel writes the zero tail of padded rows itself)
+        out = torch.empty((groups, cols, ldo), dtype=torch.float32, device=x.device)
     lib().call("dana_transpose_batched", _p(x), _p(out), groups, rows, cols, ldi, ldo, in_batch, out_batch, _stream())
     return out
 
@@ -998,6 +998,20 @@ def softmax_rows_(x, groups, length, ld=0):
     _chk(x, "x")
     lib().call("dana_softmax_rows", _p(x), groups, length, ld, _stream())
     return x
+
+
+def softmax_rows_to(x, out, groups, length, ld_in=0, ld_out=0):
+    """out[g][:length] = softmax(x[g][:length]), x untouched"""
+    lib().call("dana_softmax_rows_to", _p(_chk(x, "x")), _p(_chk(out, "out")), groups, length, ld_in, ld_out, _stream())
+    return out
+
+
+def labels_posneg(labels_f):
+    """float labels [n] -> int64 [2n]: the labels, then n zeros (rois_label of dana.py:191-194)"""
+    n = labels_f.numel()
+    out = torch.empty(2 * n, dtype=torch.int64, device=labels_f.device)
+    lib().call("dana_labels_posneg_i64", _p(_chk(labels_f, "labels")), _p(out), n, _stream())
+    return out
 
 
 def ba_apply_(s, w, groups, length, dim, ld=0, gamma=0.1, slope=0.01):

@@ -290,6 +290,10 @@ int dana_rowdot(const float* x, const float* w, const float* bias, float* out, l
                 dana_stream_t stream);
 /* F.softmax(x, last dim), in place, x[groups][length] */
 int dana_softmax_rows(float* x, long groups, int length, long ld, dana_stream_t stream);
+/* out-of-place: out[g][:length] = softmax(x[g][:length]) (cls_prob next to the untouched cls_score, dana.py:290-292) */
+int dana_softmax_rows_to(const float* x, float* out, long groups, int length, long ld_in, long ld_out, dana_stream_t stream);
+/* rois_label of the training forward (dana.py:191-194): out[0..n) = (int64) labels[i], out[n..2n) = 0 */
+int dana_labels_posneg_i64(const float* labels, long long* out, long n, dana_stream_t stream);
 /* S += gamma * leaky_relu(w^T S): dana.py:136-137; s[groups][length][ld], w[groups][length] */
 int dana_ba_apply(float* s, const float* w, int groups, int length, int dim, long ld, float gamma, float slope,
                   dana_stream_t stream);
