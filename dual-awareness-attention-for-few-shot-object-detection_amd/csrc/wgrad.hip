@@ -386,6 +386,247 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_128_kernel(WgradParams p) 
     }
 }
 
+// ---- the same tile and the same LDS image, software-pipelined like igemm_split_kernel (igemm.hip): three stages in
+// flight (global -> registers one step ahead, registers -> split -> LDS planes, LDS -> fragments one step ahead), every
+// non-MFMA instruction of a step cut into micro-items of two independent instructions and dealt out over the 24 MFMAs,
+// the step's one barrier behind the fourth MFMA. For the launches whose operand rows ARE pixel rows (every 1x1 /
+// stride-1 conv, every Linear, the Winograd-domain batched planes): no per-load geometry, one compare + select + add per
+// load. The loop above (compiler-scheduled: fragments read at the top of the step, the split behind the MFMAs) stays
+// for the strided / multi-tap launches.
+template <int V>
+struct WIC {
+  static constexpr int value = V;
+};
+template <int I, int N, class F>
+__device__ __forceinline__ void wstatic_for(F&& f) {
+  if constexpr (I < N) {
+    f(WIC<I>{});
+    wstatic_for<I + 1, N>(f);
+  }
+}
+struct WStepSched {  // (make_step_sched of igemm.hip for NM = 24, four loads, twelve reads, four split units)
+  static constexpr int NM = 24, NL = 4, NR = 12, NU = 4, NCV = 13 * NU, NLH = 2 * NL, NIT = NCV + NR + NLH, SB = 4;
+  int kind[NIT], idx[NIT], gap[NIT];
+};
+constexpr WStepSched make_wstep_sched() {
+  WStepSched s{};
+  int n = 0;
+  auto put = [&](int kind, int idx, long t, bool lds) {
+    int g = (int)(t * WStepSched::NM / 10000);
+    g = g < WStepSched::NM ? g : WStepSched::NM - 1;
+    if (lds && g < WStepSched::SB) g = WStepSched::SB;
+    s.kind[n] = kind;
+    s.idx[n] = idx;
+    s.gap[n++] = g;
+  };
+  for (int l = 0; l < WStepSched::NLH; ++l) put(0, l, (2 * l + 1) * 3000 / (2 * WStepSched::NLH), false);
+  for (int r = 0; r < WStepSched::NR; ++r) put(1, r, 1700 + (2 * r + 1) * 8000 / (2 * WStepSched::NR), true);
+  for (int i = 0; i < WStepSched::NCV; ++i) put(2, i, (2 * i + 1) * 9950 / (2 * WStepSched::NCV), i % 13 >= 11);
+  return s;
+}
+inline constexpr WStepSched kWStepSched = make_wstep_sched();
+
+__global__ void __launch_bounds__(256, 2) wgrad_split_128p_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned wsm[];  // [2 operands][2 buffers][3 planes][128 rows][WSLD]
+  using SCH = WStepSched;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int plane = blockIdx.z / p.nsplit, slice = blockIdx.z - plane * p.nsplit;
+  const int m_begin = slice * p.m_chunk;
+  const int m_end = min(p.M, m_begin + p.m_chunk);
+  const int op = tid >> 7;                       // 0: dY (waves 0, 1), 1: X (waves 2, 3) -- wave-uniform
+  const int cq = tid & 31, mg = (tid >> 5) & 3;  // column quad, pixel group of 4
+  const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(op ? p.X + plane * p.batch_x : p.dY + plane * p.batch_y), 0, (int)(op ? p.x_bytes : p.y_bytes), 0x00020000);
+  unsigned* const stage = wsm + op * (2 * 3 * 128 * WSLD) + cq * WSLD + mg * 2;
+  const int col = (op ? k0 : n0) + cq * 4;
+  const bool col_ok = col < (op ? p.K : p.N);
+  const int ld4 = (op ? p.ldx : p.ldy) * 4;
+  constexpr int DEAD = (int)0x80000000;
+  // row m_begin + 4 mg + i of the operand (advancing by 16 per step); a row is live while its pixel index < lim
+  unsigned cur[4];
+  int mrow[4];
+  const int lim = col_ok ? m_end : DEAD;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mrow[i] = m_begin + mg * 4 + i;
+    cur[i] = (unsigned)(mrow[i] * ld4 + col * 4);
+  }
+  const unsigned step_bytes = (unsigned)(WSK * ld4);
+  auto load_one = [&](int i, float4& dst) {
+    unsigned off = mrow[i] < lim ? cur[i] : OOB;
+    asm volatile("" : "+v"(off));
+    dst = ldg_b128(src, off);
+    cur[i] += step_bytes;
+    mrow[i] += WSK;
+  };
+  float4 r0[4], r1[4];
+  auto load_slab = [&](float4(&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_one(i, r[i]);
+  };
+  auto store_slab = [&](int buf, const float4(&r)[4]) {
+    unsigned* w = stage + buf * (3 * 128 * WSLD);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // channel e of the quad: its four pixels -> 4 bf16 per plane
+      unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x = e == 0 ? r[i].x : e == 1 ? r[i].y : e == 2 ? r[i].z : r[i].w;
+        hb[i] = __float_as_uint(x) & 0xffff0000u;
+        const float t1 = x - __uint_as_float(hb[i]);
+        mb[i] = __float_as_uint(t1) & 0xffff0000u;
+        lb[i] = __float_as_uint(t1 - __uint_as_float(mb[i]));
+      }
+      uint2 h, m, l;
+      h.x = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
+      h.y = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+      m.x = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+      m.y = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+      l.x = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+      l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+      *(uint2*)(w + (0 * 128 + e * 32) * WSLD) = h;
+      *(uint2*)(w + (1 * 128 + e * 32) * WSLD) = m;
+      *(uint2*)(w + (2 * 128 + e * 32) * WSLD) = l;
+    }
+  };
+  // fragments: [plane][0..1] = dY rows wn*64 + {0, 32} + li, [plane][2..3] = X rows wk*64 + {0, 32} + li
+  u32x4 f0[3][4], f1[3][4];
+  auto frag_ptr = [&](int buf, int x) {
+    return x < 2 ? wsm + buf * (3 * 128 * WSLD) + (wn * 64 + x * 32 + li) * WSLD + lh * 4
+                 : wsm + (2 + buf) * (3 * 128 * WSLD) + (wk * 64 + (x - 2) * 32 + li) * WSLD + lh * 4;
+  };
+  auto read_frags = [&](int buf, u32x4(&f)[3][4]) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) f[pc][x] = *(const u32x4*)(frag_ptr(buf, x) + pc * 128 * WSLD);
+  };
+
+  f32x16 acc[2][2];
+  const int steps = (m_end - m_begin + WSK - 1) / WSK;
+  load_slab(r0);  // tile 0
+  load_slab(r1);  // tile 1
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+      asm volatile("" : "+a"(acc[i][j]));
+    }
+  __builtin_amdgcn_sched_barrier(0);
+  store_slab(0, r0);
+  __syncthreads();
+  load_slab(r0);  // tile 2
+  read_frags(0, f0);
+  store_slab(1, r1);
+  __syncthreads();
+
+  // step t: MFMAs on tile t (f), reads tile t+1 into nf, splits tile t+2 (cv) into LDS[t & 1], requests tile t+3 (ld)
+  auto k_step = [&](int par, const u32x4(&f)[3][4], u32x4(&nf)[3][4], const float4(&cv)[4], float4(&ld)[4]) {
+    const int bw_ = par, br_ = par ^ 1;
+    unsigned* w = stage + bw_ * (3 * 128 * WSLD);
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
+    constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
+    unsigned hb[4][4], mb[4][4], lb[4][4], ld_off[4];
+    float t1[4][4];
+    uint2 hp[4], mp[4], lp[4];
+    __builtin_amdgcn_sched_barrier(0);
+    wstatic_for<0, SCH::NM>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int pq = q / 4, ti = (q / 2) % 2, tj = q % 2;
+      acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[PA[pq]][ti]),
+                                                            __builtin_bit_cast(bf16x8, f[PB[pq]][2 + tj]), acc[ti][tj], 0, 0, 0);
+      asm volatile("" : "+a"(acc[ti][tj]));
+      if constexpr (q == SCH::SB) __syncthreads();
+      wstatic_for<0, SCH::NIT>([&](auto ic) {
+        constexpr int it = decltype(ic)::value;
+        constexpr int kind = kWStepSched.kind[it], ix = kWStepSched.idx[it];
+        if constexpr (kWStepSched.gap[it] != q) {
+        } else if constexpr (kind == 0) {
+          constexpr int i = ix / 2, half = ix % 2;
+          if constexpr (half == 0) {
+            unsigned off = mrow[i] < lim ? cur[i] : OOB;
+            asm volatile("" : "+v"(off));
+            ld_off[i] = off;
+          } else {
+            ld[i] = ldg_b128(src, ld_off[i]);
+            cur[i] += step_bytes;
+            mrow[i] += WSK;
+          }
+        } else if constexpr (kind == 1) {
+          constexpr int pc = ix / 4, x = ix % 4;
+          nf[pc][x] = *(const u32x4*)(frag_ptr(br_, x) + pc * 128 * WSLD);
+        } else {
+          constexpr int e = ix / 13, r = ix % 13;  // unit e = channel e of the quad, its elements = the four pixels
+          constexpr int i0 = (r & 1) * 2, i1 = i0 + 1;
+          auto el = [&](int i) { return e == 0 ? cv[i].x : e == 1 ? cv[i].y : e == 2 ? cv[i].z : cv[i].w; };
+          if constexpr (r < 2) {
+            hb[e][i0] = __float_as_uint(el(i0)) & 0xffff0000u;
+            hb[e][i1] = __float_as_uint(el(i1)) & 0xffff0000u;
+            asm volatile("" : "+v"(hb[e][i0]), "+v"(hb[e][i1]));
+          } else if constexpr (r < 4) {
+            t1[e][i0] = el(i0) - __uint_as_float(hb[e][i0]);
+            t1[e][i1] = el(i1) - __uint_as_float(hb[e][i1]);
+            asm volatile("" : "+v"(t1[e][i0]), "+v"(t1[e][i1]));
+          } else if constexpr (r < 6) {
+            mb[e][i0] = __float_as_uint(t1[e][i0]) & 0xffff0000u;
+            mb[e][i1] = __float_as_uint(t1[e][i1]) & 0xffff0000u;
+            asm volatile("" : "+v"(mb[e][i0]), "+v"(mb[e][i1]));
+          } else if constexpr (r < 8) {
+            lb[e][i0] = __float_as_uint(t1[e][i0] - __uint_as_float(mb[e][i0]));
+            lb[e][i1] = __float_as_uint(t1[e][i1] - __uint_as_float(mb[e][i1]));
+            asm volatile("" : "+v"(lb[e][i0]), "+v"(lb[e][i1]));
+          } else if constexpr (r == 8) {
+            hp[e].x = __builtin_amdgcn_perm(hb[e][1], hb[e][0], 0x07060302u);
+            hp[e].y = __builtin_amdgcn_perm(hb[e][3], hb[e][2], 0x07060302u);
+            asm volatile("" : "+v"(hp[e].x), "+v"(hp[e].y));
+          } else if constexpr (r == 9) {
+            mp[e].x = __builtin_amdgcn_perm(mb[e][1], mb[e][0], 0x07060302u);
+            mp[e].y = __builtin_amdgcn_perm(mb[e][3], mb[e][2], 0x07060302u);
+            asm volatile("" : "+v"(mp[e].x), "+v"(mp[e].y));
+          } else if constexpr (r == 10) {
+            lp[e].x = __builtin_amdgcn_perm(lb[e][1], lb[e][0], 0x07060302u);
+            lp[e].y = __builtin_amdgcn_perm(lb[e][3], lb[e][2], 0x07060302u);
+            asm volatile("" : "+v"(lp[e].x), "+v"(lp[e].y));
+          } else if constexpr (r == 11) {
+            *(uint2*)(w + (0 * 128 + e * 32) * WSLD) = hp[e];
+            *(uint2*)(w + (1 * 128 + e * 32) * WSLD) = mp[e];
+          } else {
+            *(uint2*)(w + (2 * 128 + e * 32) * WSLD) = lp[e];
+          }
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  for (int t = 0; t < steps; t += 2) {  // (whole pairs: an odd count runs one all-zero step)
+    k_step(0, f0, f1, r0, r1);
+    k_step(1, f1, f0, r1, r0);
+  }
+  // C/D map: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5) within a 32x32 tile; LDS row rho <-> channel
+  // 4*(rho & 31) + (rho >> 5) of the 128-wide tile
+  float* out = p.partial + (long)blockIdx.z * p.N * p.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rk = wk * 64 + j * 32 + li;
+      const int k = k0 + 4 * (rk & 31) + (rk >> 5);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rn = wn * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        const int n = n0 + 4 * (rn & 31) + (rn >> 5);
+        if (n < p.N && k < p.K) out[(long)n * p.K + k] = acc[i][j][q];
+      }
+    }
+}
+
 // dW[i] = (accumulate ? dW[i] : 0) + row_scale[row(i)] * sum_s partial[s][i], fixed order. row_scale (optional) is the
 // frozen-BN scale of the output channel: with it the launch writes straight into the parameter's gradient.
 // A block = 64 float4 outputs x 4 slice-lanes (lane q sums slices q, q+4, ...; the four are combined in a fixed order
@@ -528,7 +769,19 @@ void launch_wgrad_128(const WgradParams& p, dim3 grid, hipStream_t s) {
       (void)hipFuncSetAttribute((const void*)wgrad_split_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_set = true;
     }
-    wgrad_split_128_kernel<<<grid, 256, lds, s>>>(p);
+    // rows of both operands are pixel rows (1x1 / stride 1 / no padding: every Linear, most convs, the Winograd-domain
+    // planes): the software-pipelined kernel; strided / multi-tap launches: the general one
+    static const bool pipelined = !getenv("DANA_WGRAD_PIPELINED") || atoi(getenv("DANA_WGRAD_PIPELINED")) != 0;
+    if (pipelined && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {
+      static bool attr_set_p = false;
+      if (!attr_set_p) {
+        (void)hipFuncSetAttribute((const void*)wgrad_split_128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set_p = true;
+      }
+      wgrad_split_128p_kernel<<<grid, 256, lds, s>>>(p);
+    } else {
+      wgrad_split_128_kernel<<<grid, 256, lds, s>>>(p);
+    }
   } else {
     wgrad_f32_128_kernel<<<grid, 256, 0, s>>>(p);
   }
