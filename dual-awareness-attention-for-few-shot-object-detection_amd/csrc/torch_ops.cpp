@@ -59,13 +59,21 @@ at::Tensor nms(const at::Tensor& dets, const at::Tensor& scores, double threshol
   return std::get<0>(at::sort(kept));
 }
 
+// shape / dtype / device contract shared by the RoI operators (ROIAlign.h:11-42, ROIPool.h:11-41: 4-D float maps,
+// rois [R][5] float on the same device)
+void check_map(const at::Tensor& t, const at::Tensor& rois, const char* who, const char* what) {
+  TORCH_CHECK(t.dim() == 4 && t.scalar_type() == at::kFloat, who, ": ", what, " must be a 4-D float tensor");
+  TORCH_CHECK(rois.dim() == 2 && rois.size(1) == 5 && rois.scalar_type() == at::kFloat, who, ": rois must be [R, 5] float");
+  TORCH_CHECK(rois.device() == t.device(), who, ": rois and ", what, " must be on the same device");
+}
+
 at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, double spatial_scale, int64_t pooled_height,
                              int64_t pooled_width, int64_t sampling_ratio) {
   on_gpu(input, "input");
   on_gpu(rois, "rois");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
   const auto in = input.contiguous(), r = rois.contiguous();
-  TORCH_CHECK(in.dim() == 4 && r.dim() == 2 && r.size(1) == 5 && in.scalar_type() == at::kFloat, "roi_align_forward: bad args");
+  check_map(in, r, "roi_align_forward", "input");
   const int B = (int)in.size(0), C = (int)in.size(1), H = (int)in.size(2), W = (int)in.size(3), R = (int)r.size(0);
   auto out = at::empty({R, C, pooled_height, pooled_width}, in.options());
   if (R == 0) return out;
@@ -80,6 +88,9 @@ at::Tensor roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, do
                               int64_t sampling_ratio) {
   on_gpu(grad, "grad");
   on_gpu(rois, "rois");
+  check_map(grad, rois, "roi_align_backward", "grad");
+  TORCH_CHECK(grad.size(0) == rois.size(0) && grad.size(1) == channels && grad.size(2) == pooled_height &&
+              grad.size(3) == pooled_width, "roi_align_backward: grad must be [R, C, pooled_height, pooled_width]");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(grad.device());
   const auto g = grad.contiguous(), r = rois.contiguous();
   auto gin = at::empty({batch_size, channels, height, width}, g.options());
@@ -94,6 +105,7 @@ std::tuple<at::Tensor, at::Tensor> roi_pool_forward(const at::Tensor& input, con
                                                     int64_t pooled_height, int64_t pooled_width) {
   on_gpu(input, "input");
   on_gpu(rois, "rois");
+  check_map(input, rois, "roi_pool_forward", "input");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
   const auto in = input.contiguous(), r = rois.contiguous();
   const int B = (int)in.size(0), C = (int)in.size(1), H = (int)in.size(2), W = (int)in.size(3), R = (int)r.size(0);
@@ -110,6 +122,12 @@ at::Tensor roi_pool_backward(const at::Tensor& grad, const at::Tensor& input, co
                              const at::Tensor& argmax, double spatial_scale, int64_t pooled_height, int64_t pooled_width,
                              int64_t batch_size, int64_t channels, int64_t height, int64_t width) {
   on_gpu(grad, "grad");
+  on_gpu(rois, "rois");
+  on_gpu(argmax, "argmax");
+  check_map(grad, rois, "roi_pool_backward", "grad");
+  TORCH_CHECK(argmax.scalar_type() == at::kInt && argmax.device() == grad.device() && argmax.sizes() == grad.sizes(),
+              "roi_pool_backward: argmax must be the int32 tensor roi_pool_forward returned (same shape and device as grad)");
+  TORCH_CHECK(grad.size(0) == rois.size(0) && grad.size(1) == channels, "roi_pool_backward: grad must be [R, C, ph, pw]");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(grad.device());
   const auto g = grad.contiguous(), r = rois.contiguous(), a = argmax.contiguous();
   auto gin = at::empty({batch_size, channels, height, width}, g.options());
@@ -206,4 +224,17 @@ TORCH_LIBRARY_IMPL(dana, CompositeExplicitAutograd, m) {
 TORCH_LIBRARY_IMPL(dana, Autograd, m) {
   m.impl("roi_align", &roi_align);
   m.impl("roi_pool", &roi_pool);
+}
+
+// ... and below the Autograd key (torch.inference_mode(), or any context that excludes it): the plain forward
+at::Tensor roi_align_plain(const at::Tensor& input, const at::Tensor& rois, double spatial_scale, int64_t ph, int64_t pw,
+                           int64_t sampling_ratio) {
+  return roi_align_forward(input, rois, spatial_scale, ph, pw, sampling_ratio);
+}
+at::Tensor roi_pool_plain(const at::Tensor& input, const at::Tensor& rois, double spatial_scale, int64_t ph, int64_t pw) {
+  return std::get<0>(roi_pool_forward(input, rois, spatial_scale, ph, pw));
+}
+TORCH_LIBRARY_IMPL(dana, CompositeExplicitAutograd, m) {  // (every backend: CPU tensors get the reference's error text)
+  m.impl("roi_align", &roi_align_plain);
+  m.impl("roi_pool", &roi_pool_plain);
 }
