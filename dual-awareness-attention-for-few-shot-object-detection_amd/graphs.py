@@ -130,11 +130,27 @@ class GraphedTrainer:
         self.ones = torch.ones(4, dtype=torch.float32, device=dev)  # d(sum of the four losses) / d(each)
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
+        # eager warm-up iterations (caches, kernel attributes, allocator pools) must not move the training trajectory:
+        # parameters, optimizer state and the step count are put back afterwards (warmup=0: the caller's own first
+        # iterations are the warm-up)
+        snap = None
+        if warmup > 0:
+            snap = ([fb.params.clone() for fb, _, _ in trainer.groups], [b.clone() for b in trainer.bufs], trainer.steps,
+                    self.model._rng_calls)
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
-                trainer.step(*self.inputs)  # eager iterations: caches, kernel attributes, allocator pools
+                trainer.step(*self.inputs)
         torch.cuda.synchronize(dev)
+        if snap is not None:
+            for (fb, _, _), p0 in zip(trainer.groups, snap[0]):
+                fb.params.copy_(p0)
+            for b, b0 in zip(trainer.bufs, snap[1]):
+                b.copy_(b0)
+            trainer.steps, self.model._rng_calls = snap[2], snap[3]
+            self.model._epoch += 1
+            torch.cuda.synchronize(dev)
         cur.wait_stream(self.stream)
+        self._captured_once = False
         self._capture()
 
     def recapture(self):
@@ -170,8 +186,12 @@ class GraphedTrainer:
             seen.extend(fresh)
             return fresh
 
-        if getattr(model, "device_rng", False):
+        if getattr(model, "device_rng", False) and not getattr(self, "_captured_once", False):
+            # first capture: the device counter continues the eager call sequence. A RE-capture (learning-rate change)
+            # keeps the counter where the replays left it -- refilling it from the host count, which replays do not
+            # advance, would rewind the Philox stream and repeat the draws of earlier iterations
             model._rng_counter(dev).fill_(2 * model._rng_calls)
+        self._captured_once = True
         torch.cuda.synchronize(dev)
         try:
             with torch.no_grad():
