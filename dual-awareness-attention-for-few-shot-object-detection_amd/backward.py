@@ -137,11 +137,11 @@ def _dgrad_weights(c):
     return c["wd"], c["ud"]
 
 
-def conv_dgrad(g, n, h, w, c, residual=None, mask=None, compact_out=False):
+def conv_dgrad(g, n, h, w, c, residual=None, mask=None, compact_out=False, out=None):
     """dL/d(conv input) [n*h*w][cin] from g = dL/d(conv+BN output); + residual, then the ReLU adjoint of `mask`"""
     wd, ud = _dgrad_weights(c)
     return ops.conv2d_dgrad(g, c["w"], n, h, w, c["cin"], c["cout"], c["k"], c["k"], c["stride"], c["pad"], wd=wd, ud=ud,
-                            residual=residual, mask=mask, compact_out=compact_out)
+                            residual=residual, mask=mask, compact_out=compact_out, out=out)
 
 
 def conv_backward(g, x, n, h, w, c, grads, key, need_dx=True, in_stride=0):
@@ -181,6 +181,25 @@ def bottleneck_backward(g, saved, n, h, w, bp, grads, key, need_dx=True, mask_dx
     # both 1x1 convs are strided (resnet.py:71, downsample): sum the compact gradients, scatter once
     cr = conv_dgrad(g, n, h, w, bp["ds"], compact_out=True)
     return conv_dgrad(g1, n, h, w, bp["c1"], residual=cr, mask=mk)
+
+
+def bottleneck_backward_merged(g, sq, ss, sm, bp, grads, key):
+    """bottleneck_backward for an identity-shortcut block (no downsample, stride 1) over the [query | support] buffers of
+    DAnARCNN._rcnn_base_dual: g = dL/d(o3) of BOTH batches in one [Mq + Ms][cout] tensor, ReLU adjoint applied. The three
+    1x1 convs are row-wise contractions -- their weight gradients and data gradients run ONCE over all rows (half the
+    launches, twice the reduction length per weight-gradient slice); the 3x3 conv in the middle keeps one call per batch
+    (its Winograd tiles follow the image geometry), writing into the two row ranges of one buffer. -> dL/dx, merged, with
+    the ReLU adjoint of the layer that produced x applied."""
+    mq, mt = sm["mq_out"], sm["m_out"]
+    c1, c2, c3 = bp["c1"], bp["c2"], bp["c3"]
+    grads.add_conv(key + ".conv3", g, sm["o2"], 1, mt, 1, c3)
+    g2 = conv_dgrad(g, 1, mt, 1, c3, mask=sm["o2"])
+    g1 = torch.empty((mt, c2["cin"]), dtype=torch.float32, device=g.device)
+    for part, s_ in ((slice(0, mq), sq), (slice(mq, mt), ss)):
+        grads.add_conv(key + ".conv2", g2[part], sm["o1"][part], s_["n"], s_["h1"], s_["w1"], c2)
+        conv_dgrad(g2[part], s_["n"], s_["h1"], s_["w1"], c2, mask=sm["o1"][part], out=g1[part])
+    grads.add_conv(key + ".conv1", g1, sm["x"], 1, mt, 1, c1)
+    return conv_dgrad(g1, 1, mt, 1, c1, residual=g, mask=sm["x"])
 
 
 def _block_convs(prefix, bp):
@@ -486,13 +505,31 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     #    while the earlier blocks are still being differentiated
     gq, gs = g, d_sup.view(Ns * L, 1024)
     qs, ss = ctx["q_saved"], ctx["s_saved"]
+    ms = ctx.get("m_saved") or []
+    merged_ok = len(ms) == len(qs) and getattr(model, "merge_backward", True)
     nblk = len(qs)
+    gm = None  # dL/d(block output) of both batches in one buffer (while the blocks run merged)
     for i in range(nblk - 1, -1, -1):
         sq, s_ = qs[i], ss[i]
-        gq = bottleneck_backward(gq, sq, sq["n"], sq["h"], sq["w"], sq["bp"], grads, sq["key"], need_dx=i > 0,
-                                 g_masked=i < nblk - 1)
-        gs = bottleneck_backward(gs, s_, s_["n"], s_["h"], s_["w"], s_["bp"], grads, s_["key"], need_dx=i > 0,
-                                 g_masked=i < nblk - 1)
+        bp = sq["bp"]
+        if merged_ok and bp["ds"] is None and bp["c1"]["stride"] == 1 and i > 0:
+            sm = ms[i]
+            if gm is None:  # enter the merged form: the two gradients into the two row ranges of one buffer
+                cout = bp["c3"]["cout"]
+                if i == nblk - 1:  # (the last block's outputs live in corr / sup: mask per batch, then join)
+                    ops.relu_mask_(gq, sq["o3"], sm["mq_out"], cout, ld_act=sq.get("o3_ld", 0))
+                    ops.relu_mask_(gs, s_["o3"], sm["m_out"] - sm["mq_out"], cout, ld_act=s_.get("o3_ld", 0))
+                gm = torch.empty((sm["m_out"], cout), dtype=torch.float32, device=dev)
+                ops.axpy_rows_(gm, gq, sm["mq_out"], cout, accumulate=False)
+                ops.axpy_rows_(gm[sm["mq_out"]:], gs, sm["m_out"] - sm["mq_out"], cout, accumulate=False)
+            gm = bottleneck_backward_merged(gm, sq, s_, sm, bp, grads, sq["key"])
+            gq, gs = gm[:sm["mq_in"]], gm[sm["mq_in"]:]
+        else:
+            gm = None
+            gq = bottleneck_backward(gq, sq, sq["n"], sq["h"], sq["w"], sq["bp"], grads, sq["key"], need_dx=i > 0,
+                                     g_masked=i < nblk - 1)
+            gs = bottleneck_backward(gs, s_, s_["n"], s_["h"], s_["w"], s_["bp"], grads, s_["key"], need_dx=i > 0,
+                                     g_masked=i < nblk - 1)
         grads.finish_all(model, sq["key"] + ".")
         _ready(model, _block_convs(sq["key"], sq["bp"]))
     assert not grads.packed

@@ -1119,7 +1119,8 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
     // a narrow last column tile (N = 147: 128 + 19) wastes most of a 128-wide tile: 64-wide ones pad less
     if (mode == 1 && p.N <= 256 && p.N % 128 != 0 && p.N % 128 <= 32) return launch_split<64, 64>(p, batch, s);
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-    if (mode == 1 && t128 < 160) return launch_split<64, 64>(p, batch, s);
+    // (re-measured with the round-3 K-step: tools/tile_sweep.py -- 150 tiles now prefer 128x128 by ~5 %, 76 tiles tie)
+    if (mode == 1 && t128 < 100) return launch_split<64, 64>(p, batch, s);
     return launch_split<128, 128>(p, batch, s);
   }
   static const int force = getenv("DANA_IGEMM_TILE") ? atoi(getenv("DANA_IGEMM_TILE")) : 0;

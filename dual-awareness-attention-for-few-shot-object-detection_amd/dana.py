@@ -473,7 +473,7 @@ class DAnARCNN(nn.Module):
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         return h, w
 
-    def _rcnn_base_dual(self, im, sup_ims, plan, dev, save_q=None, save_s=None, sup_stream=None, merge_from=0):
+    def _rcnn_base_dual(self, im, sup_ims, plan, dev, save_q=None, save_s=None, sup_stream=None, merge_from=0, save_m=None):
         """RCNN_base on the query batch AND the support batch (dana.py:98,100: the same weights). Every activation is one
         buffer [query pixels | support pixels][channels]. Stages >= `merge_from` (0: stem + layer1, 1: layer2, 2: layer3)
         issue ONE launch per conv over both batches -- the 1x1 / stride-1 convs see a plain GEMM over all rows, the strided
@@ -608,6 +608,9 @@ class DAnARCNN(nn.Module):
                                        n=n0, h=g0[0], w=g0[1], bp=bp, key=key, o3_ld=s0))
                     save_s.append(dict(x=x[mi:], o1=o1[m0o:], o2=o2[m0o:], o3=sup if last else o3[m0o:], h1=h1[0], w1=h1[1],
                                        n=n1, h=g1[0], w=g1[1], bp=bp, key=key, o3_ld=s1 if last else 0))
+                    if save_m is not None:  # the [query | support] buffers themselves: backward.bottleneck_backward_merged
+                        save_m.append(dict(x=x, o1=o1, o2=o2, o3=None if last else o3, mq_in=mi, mq_out=m0o,
+                                           m_in=x.size(0), m_out=o1.size(0)))
                 x, g0, g1 = o3, h0, h1
         join()
         return corr, g0, sup, g1
@@ -663,7 +666,7 @@ class DAnARCNN(nn.Module):
             # forward's caller stream, so the saved tensors are safe for a backward that runs on that stream.
             if self.query_streams != 1 and not self.merge_trunk:
                 raise RuntimeError("save_for_backward needs query_streams=1")
-            ctx = self._ctx = dict(plan=plan, B=B, shot=shot, way=way, q_saved=[], s_saved=[], l4_saved=[], heads=[])
+            ctx = self._ctx = dict(plan=plan, B=B, shot=shot, way=way, q_saved=[], s_saved=[], m_saved=[], l4_saved=[], heads=[])
         else:
             self._ctx = None
         mark("begin")
@@ -737,7 +740,8 @@ class DAnARCNN(nn.Module):
             corr, (fh, fw), sup, (sh_, sw_) = self._rcnn_base_dual(im_data, sup_ims, plan, dev,
                                                                    save_q=ctx["q_saved"] if ctx is not None else None,
                                                                    save_s=ctx["s_saved"] if ctx is not None else None,
-                                                                   sup_stream=sup_stream, merge_from=int(self.merge_from))
+                                                                   sup_stream=sup_stream, merge_from=int(self.merge_from),
+                                                                   save_m=ctx["m_saved"] if ctx is not None else None)
             trunk_done = torch.cuda.Event()
             trunk_done.record()
             sup_stream.wait_event(trunk_done)

@@ -1078,7 +1078,7 @@ def conv2d_dgrad_weight(w_packed, cout, cin, kh, kw, scale=None):
 
 
 def conv2d_dgrad(grad_out, w_packed, batch, in_h, in_w, cin, cout, kh, kw, stride, pad, scale=None, wd=None, ud=None,
-                 residual=None, mask=None, mask_stride=0, compact_out=False):
+                 residual=None, mask=None, mask_stride=0, compact_out=False, out=None):
     """grad w.r.t. the NHWC conv input [batch*in_h*in_w][cin]; grad_out [batch*oh*ow][cout].
     wd / ud: cached conv2d_dgrad_weight() / its Winograd transform. residual: added to the result; mask: activation
     whose ReLU adjoint is applied last (zero where mask <= 0). For a strided 1x1 conv residual must be COMPACT
@@ -1091,9 +1091,10 @@ def conv2d_dgrad(grad_out, w_packed, batch, in_h, in_w, cin, cout, kh, kw, strid
     ow = (in_w + 2 * pad - kw) // stride + 1
     if stride == 1:
         if ud is not None and residual is None:
-            gx, _, _ = conv3x3_winograd(grad_out, batch, oh, ow, cout, ud, cin, mask=mask, mask_stride=mask_stride)
+            gx, _, _ = conv3x3_winograd(grad_out, batch, oh, ow, cout, ud, cin, mask=mask, mask_stride=mask_stride, out=out,
+                                        out_stride=cin if out is not None else 0)
             return gx
-        gx = torch.empty((batch * in_h * in_w, cin), dtype=torch.float32, device=grad_out.device)
+        gx = out if out is not None else torch.empty((batch * in_h * in_w, cin), dtype=torch.float32, device=grad_out.device)
         e0 = _prof_begin()
         lib().call("dana_conv2d_nhwc_masked", _p(grad_out), _p(wd), _p(gx), None, None, _p(residual), _p(mask), batch, oh,
                    ow, cout, cin, kh, kw, 1, kh - 1 - pad, 0, cin, 0, mask_stride, 0, _stream())
