@@ -352,7 +352,13 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 // fragment is k = 8*(lane>>5) .. +7 of row lane&31 -- the operand layout of the 32x32x16 MFMA.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int SBK = 16;  // K per step
-constexpr int SLD = 12;  // LDS row of one plane, dwords (32 B of bf16 + 16 B pad)
+// LDS row of one plane: 16 bf16 = 32 B, UNPADDED (round 3; rounds 1-2 padded to 48 B). The two 16-byte halves of row r
+// (k 0..7, k 8..15) swap places when bit 3 of r is set: with that XOR the ds_read_b128 fragment reads (hardware lane groups
+// {0-3,12-15,20-27}, ...: 16 rows each) and the ds_write_b64 / b128 staging writes (16 / 8 consecutive lanes = 128
+// consecutive bytes) are bank-conflict-free without padding, and the staging buffers of a 128x64 tile shrink from 55.3
+// to 36.9 KB -- three workgroups per CU instead of two for the N <= 64 launches (160 registers).
+constexpr int SLD = 8;
+__device__ __forceinline__ int swz(int row) { return (row >> 3) & 1; }
 
 template <int V>
 struct IC {
@@ -481,6 +487,9 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   const int kwstep = STEM ? 4 * lda4 : lda4;        // bytes between taps of a row
   const int c4 = tid & 3;   // which float4 of the 16-wide k chunk
   const int r0 = tid >> 2;  // row within a 64-row slab
+  // LDS column (dwords) of this lane's staging write / fragment read inside a 32-byte row (see SLD: swizzled halves)
+  const int wcol = ((c4 >> 1) ^ swz(r0)) * 4 + (c4 & 1) * 2;
+  const int rcol = (lh ^ swz(li)) * 4;
   const int klim = p.K - c4 * 4;  // this lane's float4 of a K-step starting at k0 is inside K iff k0 < klim
   constexpr int DEAD = (int)0x80000000;  // k0 < DEAD never holds
   unsigned a_off[RA];   // byte offset of this lane's float4 at tap (0, 0), channel chunk 0
@@ -546,7 +555,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
       const int n = n0 + row;
       b_cur[j] = (unsigned)((((long)pl * p.N + n) * SBK + half * 8) * 2);  // (K-step 0; a K-step is 3 * N * 32 bytes)
       b_lim[j] = n < p.N ? (p.K + SBK - 1) / SBK * SBK : DEAD;  // (rows past N: zeros; the planes are zero padded to 16 k)
-      b_lds[j] = (pl * BN + row) * SLD + half * 4;
+      b_lds[j] = (pl * BN + row) * SLD + (half ^ swz(row)) * 4;
     } else {
       const int n = n0 + r0 + 64 * j;
       b_cur[j] = (unsigned)((n * p.ldb + c4 * 4) * 4);
@@ -619,8 +628,8 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     lt_cin += SBK;
   };
   auto store_tile = [&](int buf, const float4(&ra)[RA], const float4(&rb)[RB]) {
-    unsigned* as = As + buf * 3 * BM * SLD + r0 * SLD + c4 * 2;
-    unsigned* bs = Bs + buf * 3 * BN * SLD + r0 * SLD + c4 * 2;
+    unsigned* as = As + buf * 3 * BM * SLD + r0 * SLD + wcol;
+    unsigned* bs = Bs + buf * 3 * BN * SLD + r0 * SLD + wcol;
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
       uint2 h, m, l;
@@ -665,8 +674,8 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
 
   u32x4 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];  // fragments as raw dwords (8 bf16 each)
   auto read_frags = [&](int buf, u32x4(&fa)[3][TM], u32x4(&fb)[3][TN]) {
-    const unsigned* as = As + buf * 3 * BM * SLD + (wm * (BM / 2) + li) * SLD + lh * 4;
-    const unsigned* bs = Bs + buf * 3 * BN * SLD + (wn * (BN / 2) + li) * SLD + lh * 4;
+    const unsigned* as = As + buf * 3 * BM * SLD + (wm * (BM / 2) + li) * SLD + rcol;
+    const unsigned* bs = Bs + buf * 3 * BN * SLD + (wn * (BN / 2) + li) * SLD + rcol;
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
@@ -702,10 +711,10 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   auto k_step = [&](int t, const u32x4(&fa)[3][TM], const u32x4(&fb)[3][TN], u32x4(&na)[3][TM], u32x4(&nb)[3][TN],
                     const float4(&cv_a)[RA], const float4(&cv_b)[RB], float4(&ld_a)[RA], float4(&ld_b)[RB]) {
     const int bw_ = t & 1, br_ = bw_ ^ 1;
-    const unsigned* as = As + br_ * 3 * BM * SLD + (wm * (BM / 2) + li) * SLD + lh * 4;
-    const unsigned* bs = Bs + br_ * 3 * BN * SLD + (wn * (BN / 2) + li) * SLD + lh * 4;
-    unsigned* aw = As + bw_ * 3 * BM * SLD + r0 * SLD + c4 * 2;
-    unsigned* bw = Bs + bw_ * 3 * BN * SLD + r0 * SLD + c4 * 2;
+    const unsigned* as = As + br_ * 3 * BM * SLD + (wm * (BM / 2) + li) * SLD + rcol;
+    const unsigned* bs = Bs + br_ * 3 * BN * SLD + (wn * (BN / 2) + li) * SLD + rcol;
+    unsigned* aw = As + bw_ * 3 * BM * SLD + r0 * SLD + wcol;
+    unsigned* bw = Bs + bw_ * 3 * BN * SLD + r0 * SLD + wcol;
     constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
     constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
     unsigned hb[NF][4], mb[NF][4], lb[NF][4];
@@ -1119,8 +1128,23 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
     // a narrow last column tile (N = 147: 128 + 19) wastes most of a 128-wide tile: 64-wide ones pad less
     if (mode == 1 && p.N <= 256 && p.N % 128 != 0 && p.N % 128 <= 32) return launch_split<64, 64>(p, batch, s);
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-    // (re-measured with the round-3 K-step: tools/tile_sweep.py -- 150 tiles now prefer 128x128 by ~5 %, 76 tiles tie)
-    if (mode == 1 && t128 < 100) return launch_split<64, 64>(p, batch, s);
+    // Tile choice, re-measured with the round-3 kernel (unpadded LDS: a 128x64 tile runs three workgroups per CU, a 64x64
+    // tile four; tools/tile_sweep.py). Launch by launch, ALONE on the chip, smaller tiles win more often now: fewer than
+    // ~230 128x128 tiles -> 64x64 (layer3's reduce convs, the Q / K projections: -5 %), a short K walk with one to two
+    // rounds of tiles or a residual epilogue behind K <= 256 -> 128x64 (layer2 / layer3 expand convs -7 %); that rule set
+    // (DANA_TILE_RULE=2) is worth -1 % of the summed launch durations (roofline 0.4175 -> 0.4215) -- and COSTS 3 % of the
+    // step's wall clock (639-643 -> 619-621 query-images/s, same box): the step runs two kernel streams, and many small
+    // workgroups of one kernel crowd out the other stream's blocks that would have filled its tail. The default keeps
+    // 128x128 wherever the grid can give ~100 CUs one tile.
+    if (mode == 1) {
+      static const int rule = getenv("DANA_TILE_RULE") ? atoi(getenv("DANA_TILE_RULE")) : 0;
+      if (rule == 2) {
+        if (t128 < 230) return launch_split<64, 64>(p, batch, s);
+        if ((p.K <= 512 && t128 < 400) || (p.residual && p.K <= 256 && p.K >= 128)) return launch_split<128, 64>(p, batch, s);
+      } else if (t128 < 100) {
+        return launch_split<64, 64>(p, batch, s);
+      }
+    }
     return launch_split<128, 128>(p, batch, s);
   }
   static const int force = getenv("DANA_IGEMM_TILE") ? atoi(getenv("DANA_IGEMM_TILE")) : 0;
