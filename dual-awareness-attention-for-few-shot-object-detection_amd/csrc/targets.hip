@@ -644,9 +644,62 @@ rcnn_loss_c_kernel(int n, int blocks, RcnnLossWs ws, float* __restrict__ losses,
   }
 }
 
+// Plain classification + box-regression losses of the sibling detectors (faster_rcnn.py:93-98): F.cross_entropy over all n
+// rois (mean) and _smooth_l1_loss(sigma) (net_utils.py:71-85: sum over the 4 coordinates, mean over rois), with their
+// gradient seeds. ONE workgroup: n is a few hundred rows; the sums go through LDS in a fixed order (deterministic).
+__global__ void __launch_bounds__(256)
+plain_rcnn_loss_kernel(const float* __restrict__ scores, const long long* __restrict__ labels, const float* __restrict__ bbox,
+                       const float* __restrict__ tgt, const float* __restrict__ win, const float* __restrict__ wout, int n,
+                       int C, float sigma, float* __restrict__ losses2, float* __restrict__ gscores, float* __restrict__ gbbox) {
+  __shared__ float part[2][256];
+  const float s2 = sigma * sigma, inv_n = 1.f / (float)n;
+  float lc = 0.f, lb = 0.f;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const float* sr = scores + (long)r * C;
+    float m = sr[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, sr[c]);
+    float z = 0.f;
+    for (int c = 0; c < C; ++c) z += expf(sr[c] - m);
+    const int y = (int)labels[r];
+    lc += -(sr[y] - m - logf(z));
+    if (gscores)
+      for (int c = 0; c < C; ++c) gscores[(long)r * C + c] = (expf(sr[c] - m) / z - (c == y ? 1.f : 0.f)) * inv_n;
+    float row = 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const long i = (long)r * 4 + q;
+      const float d = win[i] * (bbox[i] - tgt[i]);
+      const float a = fabsf(d);
+      const bool near = a < 1.f / s2;
+      row += wout[i] * (near ? d * d * (s2 * 0.5f) : a - 0.5f / s2);
+      if (gbbox) gbbox[i] = wout[i] * win[i] * (near ? s2 * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f))) * inv_n;
+    }
+    lb += row;
+  }
+  part[0][threadIdx.x] = lc;
+  part[1][threadIdx.x] = lb;
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int i = 0; i < 256; ++i) t += part[threadIdx.x][i];
+    losses2[threadIdx.x] = t * inv_n;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dana_plain_rcnn_loss(const float* scores, const long long* labels, const float* bbox_pred, const float* bbox_targets,
+                         const float* inside_weights, const float* outside_weights, int n, int n_classes, float sigma,
+                         float* losses2, float* grad_scores, float* grad_bbox, dana_stream_t stream) {
+  DANA_CHECK_ARG(n > 0 && n_classes > 0, "dana_plain_rcnn_loss: bad shape");
+  DANA_CHECK_ARG(scores && labels && bbox_pred && bbox_targets && inside_weights && outside_weights && losses2,
+                 "dana_plain_rcnn_loss: null pointer");
+  plain_rcnn_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(scores, labels, bbox_pred, bbox_targets, inside_weights,
+                                                             outside_weights, n, n_classes, sigma, losses2, grad_scores, grad_bbox);
+  DANA_CHECK_LAUNCH("dana_plain_rcnn_loss");
+  return DANA_OK;
+}
 
 size_t dana_rcnn_loss_workspace_bytes(int n) {
   if (n <= 0) return 0;

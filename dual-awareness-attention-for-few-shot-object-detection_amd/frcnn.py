@@ -159,14 +159,11 @@ class FasterRCNN(DAnARCNN):
                 RCNN_loss_bbox = T._smooth_l1_loss(bbox_pred, st["rois_target"], st["rois_inside_ws"],
                                                    st["rois_outside_ws"])
             else:
-                # the two tiny loss tails ([n_roi][2], [n_roi][4]) give their own gradient seeds through torch
-                cs, bp_ = cls_score.detach().requires_grad_(True), bbox_pred.detach().requires_grad_(True)
-                with torch.enable_grad():
-                    lc = F.cross_entropy(cs, st["rois_label"])
-                    lb = T._smooth_l1_loss(bp_, st["rois_target"], st["rois_inside_ws"], st["rois_outside_ws"])
-                    d_cls, d_bbox = torch.autograd.grad(lc + lb, [cs, bp_])
-                RCNN_loss_cls, RCNN_loss_bbox = lc.detach(), lb.detach()
-                ctx.update(loss_seeds=(d_cls.contiguous(), d_bbox.contiguous()))
+                # the two loss tails ([n_roi][2], [n_roi][4]) and their gradient seeds: one HIP launch (dana_plain_rcnn_loss)
+                l2, (d_cls, d_bbox) = ops.plain_rcnn_losses(cls_score, st["rois_label"], bbox_pred, st["rois_target"],
+                                                           st["rois_inside_ws"], st["rois_outside_ws"], with_grad=True)
+                RCNN_loss_cls, RCNN_loss_bbox = l2[0], l2[1]
+                ctx.update(loss_seeds=(d_cls, d_bbox))
                 self._ctx = ctx
                 if bridge:  # loss.backward() (train.py:141-143) runs backward.frcnn_backward on the HIP kernels
                     dev = im_data.device

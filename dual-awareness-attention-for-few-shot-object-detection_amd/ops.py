@@ -565,6 +565,24 @@ def rcnn_losses(score_pos, score_neg, labels, bbox_pred, bbox_targets, inside_ws
     return out, seeds
 
 
+def plain_rcnn_losses(scores, labels, bbox_pred, bbox_targets, inside_ws, outside_ws, sigma=1.0, with_grad=False):
+    """F.cross_entropy(scores, labels) and _smooth_l1_loss(bbox_pred, ...) of faster_rcnn.py:93-98 in one launch ->
+    (float32[2] tensor, (d cls / d scores, d box / d bbox_pred) or None)"""
+    n, c = scores.shape
+    dev = scores.device
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
+    seeds = (torch.empty((n, c), dtype=torch.float32, device=dev), torch.empty((n, 4), dtype=torch.float32, device=dev)) \
+        if with_grad else None
+    labels = labels.contiguous()
+    if labels.dtype != torch.int64:
+        raise TypeError("plain_rcnn_losses: labels must be int64")
+    lib().call("dana_plain_rcnn_loss", _p(_chk(scores, "scores")), _p(labels), _p(_chk(bbox_pred.contiguous(), "bbox_pred")),
+               _p(_chk(bbox_targets.contiguous(), "bbox_targets")), _p(_chk(inside_ws.contiguous(), "inside_ws")),
+               _p(_chk(outside_ws.contiguous(), "outside_ws")), n, c, float(sigma), _p(out),
+               _p(seeds[0]) if seeds else None, _p(seeds[1]) if seeds else None, _stream())
+    return out, seeds
+
+
 # ------------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------------

@@ -352,6 +352,12 @@ int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, c
  * half; dana.py:204-215), losses3[1] = _smooth_l1_loss(bbox_pred, targets, in, out) (net_utils.py:71-85, sigma,
  * mean over rois), losses3[2] = number of rows kept. Optional gradient seeds (may be NULL): d losses3[0] / d scores
  * and d losses3[1] / d bbox_pred. No host sync (the reference's nonzero / sort / index chain has three). */
+/* the plain losses of the sibling detectors (faster_rcnn.py:93-98): losses2[0] = F.cross_entropy(scores [n][n_classes],
+ * labels int64 [n]) (mean), losses2[1] = _smooth_l1_loss(sigma) (net_utils.py:71-85); optional gradient seeds
+ * d losses2[0] / d scores [n][n_classes] and d losses2[1] / d bbox_pred [n][4]. One launch, no host sync. */
+int dana_plain_rcnn_loss(const float* scores, const long long* labels, const float* bbox_pred, const float* bbox_targets,
+                         const float* inside_weights, const float* outside_weights, int n, int n_classes, float sigma,
+                         float* losses2, float* grad_scores, float* grad_bbox, dana_stream_t stream);
 size_t dana_rcnn_loss_workspace_bytes(int n);
 int dana_rcnn_loss(const float* score_pos, const float* score_neg, const float* labels, const float* bbox_pred,
                    const float* bbox_targets, const float* inside_weights, const float* outside_weights, int n,
