@@ -667,6 +667,32 @@ def main():
                              "frac": round(f0 / t0s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                              "kernel_ms_per_step": round(t0s * 1e3 / k0, 3)},
             }
+    if (rank == 0 and world == 1 and args.mode == "train" and not args.no_secondary and args.model == "DAnA"
+            and not args.device_rng and not args.single_stream):
+        # secondary object: the same forward with the training targets sampled by the device Philox RNG -- no host round
+        # trip, so the whole forward is ONE hipGraph. Same distributions as the reference's np.random draws, another random
+        # stream (which is why it is not the headline: the parity tests pin the host-RNG path). The one-graph replay has no
+        # host-issue gaps and no graph-to-graph hand-over (0.6 ms in the three-graph host-RNG replay: tools/r3_sync_gap.py).
+        from dana_amd.graphs import GraphedDAnA
+        model.device_rng = True
+        try:
+            rung = GraphedDAnA(model, *inputs)
+            for _ in range(5):
+                rung(*rung.inputs)
+            torch.cuda.synchronize()
+            kd = max(10, args.steps // 2)
+            t0 = time.perf_counter()
+            for _ in range(kd):
+                rung(*rung.inputs)
+            torch.cuda.synchronize()
+            dtd = time.perf_counter() - t0
+            result["device_rng_one_graph"] = {
+                "what": "train-mode forward, targets sampled by the device Philox RNG (opt-in: DAnARCNN.device_rng), replayed "
+                        "as one hipGraph", "value": round(args.batch * kd / dtd, 3), "unit": "query-images/sec",
+                "ms_per_step": round(1e3 * dtd / kd, 3), "steps": kd}
+            del rung
+        finally:
+            model.device_rng = False
     if rank == 0 and world == 1 and args.mode == "train" and args.ba and not args.no_secondary and args.model == "DAnA":
         # secondary object: BASELINE configs[1] (CISA only, use_BA_block=False) on the same episodes
         m1 = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=args.way, shot=args.shot, classes=["fg", "bg"])

@@ -627,7 +627,7 @@ class DAnARCNN(nn.Module):
                 req = next(gen)
         except StopIteration as done:
             return done.value
-        drawn = ops.upload_draws(ops.draw_targets_host(req), im_data.device)
+        drawn = ops.draw_and_upload(req, im_data.device)
         try:
             gen.send(drawn)
         except StopIteration as done:

@@ -100,7 +100,7 @@ class GraphedDAnA:
         self.g1.replay()
         if self.g2 is not None:
             # anchor counts: behind the side stream only -> the anchor draws overlap the trunk (graph 1) on the GPU
-            ops.upload_draws(ops.draw_targets_host(self.req), self.drawn.device, static=self.drawn)
+            ops.draw_and_upload(self.req, self.drawn.device, static=self.drawn)
             cur.wait_stream(self.side)
             self.g2.replay()
         return self.outputs
@@ -279,7 +279,7 @@ class GraphedTrainer:
                 self.g_anchor.replay()
         for k, (g, buckets) in enumerate(self.graphs):
             if k == 1 and self.req is not None:
-                ops.upload_draws(ops.draw_targets_host(self.req), self.drawn.device, static=self.drawn)
+                ops.draw_and_upload(self.req, self.drawn.device, static=self.drawn)
                 cur.wait_stream(self.side)
             if k == last and self.collective:
                 for w in works:  # the SGD graph runs behind every bucket's sum

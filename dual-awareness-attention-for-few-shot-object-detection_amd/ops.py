@@ -57,6 +57,7 @@ def _p(t):
 
 
 _PINNED = {"ring": [], "next": 0}
+GAP_EVENTS = None  # debug: list that receives (event in front of, event behind) the training forward's host round trip
 
 
 def _h2d_int32(arr, device):
@@ -425,60 +426,93 @@ def anchor_target_subsample_device(h, rpn_batchsize, num_fg, seed, offset, count
 #   then (which, pos) pairs, 8-byte aligned. Every consumer reads it through device pointers, so the launches after
 #   the draw have step-independent parameters (a captured hipGraph replays them with each step's draws).
 def draw_layout(B, R, total):
-    pairs_off = (2 + B * R + B + 1) // 2 * 2
+    """word offsets of the draw buffer: [picks B*R | fg_taken B | (pad) | header: n pairs, 1/num_examples | pairs 2 x n]. The
+    proposal part (a few hundred words) and the anchor part (header + up to 2 * B * total words) are two contiguous
+    regions: they are uploaded separately, the big one EARLY (draw_and_upload)."""
+    hdr = (B * R + B + 1) // 2 * 2
     cap = 2 * B * total  # every fg and every bg anchor of every image could be disabled
-    return dict(picks=2, taken=2 + B * R, pairs=pairs_off, cap=cap, words=pairs_off + 2 * cap)
+    return dict(picks=0, taken=B * R, hdr=hdr, pairs=hdr + 2, cap=cap, words=hdr + 2 + 2 * cap)
 
 
-def draw_targets_host(req):
-    """req: the forward's draw request (anchor / proposal counts [B,2] on the device, the stream the anchor half ran on,
-    B, R, fg_per, rpn_batchsize, num_fg, total) -> int32 numpy array in draw_layout order, truncated after the last used
-    pair. The anchor counts are final long before the proposals are: they are read behind THEIR stream only, and the
-    anchor layer's draws (the expensive ones: permutations over every bg anchor) run while the GPU still works on the
-    trunk; the proposal counts are the one read that waits for the caller's stream."""
-    import numpy as np
-    B, R = req["B"], req["R"]
-    lay = draw_layout(B, R, req["total"])
-    t0 = _time.perf_counter()
-    with torch.cuda.stream(req["anchor_stream"]):
-        cnt_a = req["anchor_counts"].cpu().numpy()
-    HOST_WAIT[0] += _time.perf_counter() - t0  # (time the host spent BLOCKED on the GPU, for host-enqueue accounting)
-    pairs, num_examples = anchor_target_draw(cnt_a, B, req["rpn_batchsize"], req["num_fg"])
-    t0 = _time.perf_counter()
-    cnt_p = req["proposal_counts"].cpu().numpy()  # host sync: np.random needs the counts
-    HOST_WAIT[0] += _time.perf_counter() - t0
-    picks, taken = proposal_target_draw(cnt_p, B, R, req["fg_per"])
-    n = int(pairs.shape[0])
-    out = np.zeros((lay["pairs"] + 2 * n,), dtype=np.int32)
-    out[0] = n
-    out[1:2] = np.array([1.0 / num_examples], dtype=np.float32).view(np.int32)
-    out[lay["picks"]:lay["picks"] + B * R] = picks.reshape(-1)
-    out[lay["taken"]:lay["taken"] + B] = taken
-    out[lay["pairs"]:] = pairs.reshape(-1)
-    return out
-
-
-def upload_draws(arr, device, static=None):
-    """pinned staging -> device. static: a preallocated int32 device buffer of draw_layout()['words'] words (hipGraph
-    mode: the consumers' pointers are baked into the graph); None: a fresh tensor"""
-    if static is None:
-        return _h2d_int32(arr, device)
+def _pinned_upload(arr, dst, stream=None):
+    """numpy int32 -> dst (device int32 view) through the ring of reusable PINNED staging buffers: a true asynchronous
+    DMA on `stream` (default: the current one)"""
     n = int(arr.size)
     ring = _PINNED["ring"]
-    if len(ring) < 4:
+    if len(ring) < 6:
         ring.append([torch.empty((max(n, 1 << 16),), dtype=torch.int32, pin_memory=True), None])
     i = _PINNED["next"] % len(ring)
     _PINNED["next"] += 1
     buf, ev = ring[i]
     if ev is not None:
-        ev.synchronize()
+        ev.synchronize()  # the copy that last used this buffer (several uploads ago) has long finished
     if buf.numel() < n:
         buf = ring[i][0] = torch.empty((n * 2,), dtype=torch.int32, pin_memory=True)
     buf[:n].numpy()[...] = arr.reshape(-1)
-    static[:n].copy_(buf[:n], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
+    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+        dst[:n].copy_(buf[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
     ring[i][1] = ev
+    return ev
+
+
+def draw_and_upload(req, device, static=None):
+    """The training forward's one host round trip: counts -> the reference's np.random draws -> device buffer in
+    draw_layout order (`static`: a preallocated int32 device buffer of draw_layout()['words'] words -- hipGraph mode, the
+    consumers' pointers are baked into the graph; None: a fresh tensor).
+
+    req: anchor / proposal counts [B,2] on the device, the stream the anchor half ran on, B, R, fg_per, rpn_batchsize,
+    num_fg, total. The anchor counts are final long before the proposals are: they are read behind THEIR stream only, the
+    anchor layer's draws (permutations over every bg anchor, ~1 ms of host time) and the staging + upload of their result
+    -- the list of anchors to disable, ~3 MB at 600 x 1000 -- run while the GPU still works on the trunk, on a copy stream
+    of their own. The proposal counts are the one read that waits for the caller's stream; behind it only the proposal
+    draws (~20-50 us) and a 2 KB upload stand between the GPU and the rest of the step (round 2 assembled and uploaded
+    everything as ONE array after the second read). Measured (tools/r3_sync_gap.py): the GPU idles 0.10 ms at this round
+    trip in the eager forward -- and 0.63 ms when the two halves are hipGraphs (the runtime's end-of-graph hand-over, not
+    host work: the host spends 70 us there; polling instead of a blocking read changes nothing), which is why the
+    three-graph replay of the host-RNG forward loses to eager issue while the one-graph replay of the device-RNG forward
+    wins (bench.py: device_rng_one_graph)."""
+    import numpy as np
+    B, R = req["B"], req["R"]
+    lay = draw_layout(B, R, req["total"])
+    gap = GAP_EVENTS
+    if gap is not None:  # (tools/r3_sync_gap.py: GPU time between the last kernel in front of the round trip and the first behind it)
+        e_in = torch.cuda.Event(enable_timing=True)
+        e_in.record()
+    t0 = _time.perf_counter()
+    with torch.cuda.stream(req["anchor_stream"]):
+        cnt_a = req["anchor_counts"].cpu().numpy()
+    HOST_WAIT[0] += _time.perf_counter() - t0  # (time the host spent BLOCKED on the GPU, for host-enqueue accounting)
+    pairs, num_examples = anchor_target_draw(cnt_a, B, req["rpn_batchsize"], req["num_fg"])
+    n = int(pairs.shape[0])
+    part_a = np.empty((2 + 2 * n,), dtype=np.int32)
+    part_a[0] = n
+    part_a[1:2] = np.array([1.0 / num_examples], dtype=np.float32).view(np.int32)
+    part_a[2:] = pairs.reshape(-1)
+    if static is None:
+        static = torch.empty((lay["pairs"] + 2 * n,), dtype=torch.int32, device=device)
+    cs = _PINNED.get("copy_stream")
+    if cs is None or cs.device != static.device:
+        cs = _PINNED["copy_stream"] = torch.cuda.Stream(device=static.device)
+    cur = torch.cuda.current_stream()
+    # (the buffer's previous consumers are long done: a fresh tensor, or a static one whose last reader -- the previous
+    # iteration's graph -- finished before this iteration's counts could be read)
+    ev_a = _pinned_upload(part_a, static[lay["hdr"]:], stream=cs)
+    static.record_stream(cs)
+    t0 = _time.perf_counter()
+    cnt_p = req["proposal_counts"].cpu().numpy()  # host sync: np.random needs the counts
+    HOST_WAIT[0] += _time.perf_counter() - t0
+    picks, taken = proposal_target_draw(cnt_p, B, R, req["fg_per"])
+    part_p = np.empty((B * R + B,), dtype=np.int32)
+    part_p[:B * R] = picks.reshape(-1)
+    part_p[B * R:] = taken
+    _pinned_upload(part_p, static)
+    cur.wait_event(ev_a)
+    if gap is not None:
+        e_out = torch.cuda.Event(enable_timing=True)
+        e_out.record()
+        gap.append((e_in, e_out))
     return static
 
 
@@ -486,9 +520,9 @@ def anchor_target_apply_draws(h, drawn, lay):
     """labels[list[pos]] = -1 for the drawn (which, pos) pairs; 1/num_examples stays in device memory (drawn[1])"""
     ibuf = h["ibuf"]
     base = drawn.data_ptr()
-    lib().call("dana_anchor_target_disable_dev", _p(h["labels"]), _p(ibuf[1]), _p(ibuf[2]), base,
+    lib().call("dana_anchor_target_disable_dev", _p(h["labels"]), _p(ibuf[1]), _p(ibuf[2]), base + 4 * lay["hdr"],
                base + 4 * lay["pairs"], lay["cap"], h["total"], _stream())
-    h["inv_ne_dev"] = drawn[1:2].view(torch.float32)
+    h["inv_ne_dev"] = drawn[lay["hdr"] + 1:lay["hdr"] + 2].view(torch.float32)
     h["_drawn"] = drawn  # keeps the buffer alive as long as the handle
     return h
 
