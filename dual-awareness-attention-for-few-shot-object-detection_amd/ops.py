@@ -38,7 +38,16 @@ def _prof_end(e0, tag, flops, nbytes=0.0, executed=None):
         PROFILE.append((tag[0] % tag[1], flops, e0, e1, nbytes, flops if executed is None else executed))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """the caller's current HIP stream as a raw handle. torch.cuda.current_stream() builds a Stream object through
+    several layers of Python (device index resolution, environment look-ups): 7.8 us per call, 1.4 ms of the eager
+    step's ~3 ms of host time (tools/r3_hostprof.py); the two C entry points below take 0.3 us."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 

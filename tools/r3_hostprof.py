@@ -1,0 +1,24 @@
+"""cProfile of the eager train-mode forward's HOST side (where do the ~3 ms of Python per step go?)"""
+import cProfile, os, pstats, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dana_amd
+from dana_amd import synthetic as S
+dev = torch.device("cuda:0")
+m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=2, shot=3, classes=["fg", "bg"])
+m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=11, profile="test"))
+m.to(dev).train()
+inputs = [t.to(dev) for t in S.episode_inputs(4, 2, 3, 600, 1000, seed=1996)]
+np.random.seed(0)
+with torch.no_grad():
+    for _ in range(5):
+        m(*inputs)
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(20):
+        m(*inputs)
+    pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(22)
