@@ -384,6 +384,104 @@ roi_align_bwd_nhwc_bins(const float* __restrict__ gout, const float* __restrict_
   }
 }
 
+// NHWC backward as a GATHER (round 3): one workgroup per 2 x 2 tile of feature cells, each wave owns 256 channels
+// (float4 per lane). The wave tests 64 rois at a time against the tile (lane = roi, one ballot), and for every roi that
+// can touch it computes -- one lane per entry -- the row / column weights its bins' sample lattices put on the tile's two
+// rows and two columns (the separable weights of the kernels above: at most 8 bins per axis), parks them in LDS, and
+// adds w_y w_x / count times the bin's gradient row to the four cells' accumulators: every gradient row is read once
+// per tile it touches, the feature gradient is WRITTEN ONCE, no atomics, no memset, and the sum runs in a fixed
+// (roi, bin) order -- bit-reproducible, which the scatter of ROIAlign_cuda.cu:233-250 is not.
+constexpr int GB_MAXP = 8;  // pooled height / width the gather kernel supports (else: the atomic kernel)
+__global__ void __launch_bounds__(256)
+roi_align_bwd_gather_nhwc(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin, int R,
+                          int C, int H, int W, int PH, int PW, float scale, int sr, int tiles_y, int tiles_x) {
+  __shared__ float wsm[4][4 * GB_MAXP];  // per wave: wy(row 0), wy(row 1), wx(col 0), wx(col 1) for up to 8 bins each
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = tiles_y * tiles_x;
+  const int b = blockIdx.x / per, t = blockIdx.x - b * per;
+  const int y0 = (t / tiles_x) * 2, x0 = (t % tiles_x) * 2;
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);  // (a tile at the map's edge repeats its last row / column)
+  const bool has_y1 = y0 + 1 < H, has_x1 = x0 + 1 < W;
+  float* wv = wsm[wave];
+  const int P2 = PH * PW;
+  for (int c0 = wave * 256; c0 < C; c0 += 1024) {
+    const int c = c0 + lane * 4;
+    const bool c_ok = c < C;
+    float4 a00 = make_float4(0.f, 0.f, 0.f, 0.f), a01 = a00, a10 = a00, a11 = a00;
+    for (int rb = 0; rb < R; rb += 64) {
+      const int r = rb + lane;
+      bool hit = false;
+      if (r < R) {
+        const float* roi = rois + (long)r * 5;
+        if ((int)roi[0] == b) {
+          // conservative cell box of the roi: samples lie in [start, start + max(size, 1)], each touches floor and floor + 1
+          const float sw = roi[1] * scale, sh = roi[2] * scale;
+          const float ew = sw + fmaxf(roi[3] * scale - sw, 1.f), eh = sh + fmaxf(roi[4] * scale - sh, 1.f);
+          hit = (float)(y0 - 1) <= eh && (float)(y1 + 1) >= sh && (float)(x0 - 1) <= ew && (float)(x1 + 1) >= sw;
+        }
+      }
+      unsigned long long mask = __ballot(hit);
+      while (mask) {
+        const int bit = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int rr = rb + bit;
+        const RoiGeom g = roi_geom(rois + (long)rr * 5, scale, PH, PW, sr);
+        // bins whose lattice can reach the tile's rows / columns (a sample at v touches cells floor(v), floor(v) + 1;
+        // v < 0 clamps to 0, v > size - 1 to size - 1)
+        int ph_lo = (int)floorf(((float)(y0 - 1) - g.start_h) / g.bin_h), ph_hi = (int)floorf(((float)(y1 + 1) - g.start_h) / g.bin_h);
+        int pw_lo = (int)floorf(((float)(x0 - 1) - g.start_w) / g.bin_w), pw_hi = (int)floorf(((float)(x1 + 1) - g.start_w) / g.bin_w);
+        if (y0 == 0) ph_lo = 0;
+        if (y1 == H - 1) ph_hi = PH - 1;
+        if (x0 == 0) pw_lo = 0;
+        if (x1 == W - 1) pw_hi = PW - 1;
+        ph_lo = max(ph_lo, 0); ph_hi = min(ph_hi, PH - 1);
+        pw_lo = max(pw_lo, 0); pw_hi = min(pw_hi, PW - 1);
+        if (ph_lo > ph_hi || pw_lo > pw_hi) continue;
+        const int nph = ph_hi - ph_lo + 1, npw = pw_hi - pw_lo + 1;
+        {  // lanes 0..31: one weight each
+          const int which = lane >> 3, k = lane & 7;  // 0: wy row y0, 1: wy row y1, 2: wx col x0, 3: wx col x1
+          float w = 0.f;
+          if (lane < 32) {
+            if (which < 2) {
+              if (k < nph && (which == 0 || has_y1)) w = axis_weight(which ? y1 : y0, g.grid_h, g.start_h, g.bin_h, ph_lo + k, H);
+            } else {
+              if (k < npw && (which == 2 || has_x1)) w = axis_weight(which == 3 ? x1 : x0, g.grid_w, g.start_w, g.bin_w, pw_lo + k, W);
+            }
+            wv[lane] = w;
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are done (one wave: no barrier)
+        __builtin_amdgcn_wave_barrier();
+        const float inv = 1.f / g.count;
+        for (int i = 0; i < nph; ++i) {
+          const float wy0 = wv[i] * inv, wy1 = wv[GB_MAXP + i] * inv;
+          if (wy0 == 0.f && wy1 == 0.f) continue;
+          for (int j = 0; j < npw; ++j) {
+            const float wx0 = wv[2 * GB_MAXP + j], wx1 = wv[3 * GB_MAXP + j];
+            if (wx0 == 0.f && wx1 == 0.f) continue;
+            if (c_ok) {
+              const float4 gv = *(const float4*)(gout + ((long)rr * P2 + (ph_lo + i) * PW + pw_lo + j) * C + c);
+              const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+              a00.x += w00 * gv.x; a00.y += w00 * gv.y; a00.z += w00 * gv.z; a00.w += w00 * gv.w;
+              a01.x += w01 * gv.x; a01.y += w01 * gv.y; a01.z += w01 * gv.z; a01.w += w01 * gv.w;
+              a10.x += w10 * gv.x; a10.y += w10 * gv.y; a10.z += w10 * gv.z; a10.w += w10 * gv.w;
+              a11.x += w11 * gv.x; a11.y += w11 * gv.y; a11.z += w11 * gv.z; a11.w += w11 * gv.w;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // (the next roi's weights overwrite wv)
+      }
+    }
+    if (c_ok) {
+      float* img = gin + (long)b * H * W * C + c;
+      *(float4*)(img + ((long)y0 * W + x0) * C) = a00;
+      if (has_x1) *(float4*)(img + ((long)y0 * W + x1) * C) = a01;
+      if (has_y1) *(float4*)(img + ((long)y1 * W + x0) * C) = a10;
+      if (has_y1 && has_x1) *(float4*)(img + ((long)y1 * W + x1) * C) = a11;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // RoIPool (NCHW): ROIPool_cuda.cu:16-77 forward (max + int32 argmax), :79-108 backward.
 __global__ void __launch_bounds__(256)
@@ -504,6 +602,17 @@ int dana_roi_align_backward(const float* grad_out, const float* rois, float* gra
   DANA_CHECK_ARG(batch >= 0 && channels > 0 && height > 0 && width > 0 && num_rois >= 0,
                  "dana_roi_align_backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
+  static const bool gather = !getenv("DANA_ROI_BWD_GATHER") || atoi(getenv("DANA_ROI_BWD_GATHER")) != 0;
+  if (gather && layout == DANA_LAYOUT_NHWC && num_rois > 0 && batch > 0 && channels % 4 == 0 && pooled_h <= GB_MAXP &&
+      pooled_w <= GB_MAXP && ((uintptr_t)grad_out & 15) == 0 && ((uintptr_t)grad_in & 15) == 0) {
+    // gather form: writes every cell once (no memset), deterministic
+    DANA_CHECK_ARG(grad_out && rois && grad_in, "dana_roi_align_backward: null pointer");
+    const int ty = (height + 1) / 2, tx = (width + 1) / 2;
+    roi_align_bwd_gather_nhwc<<<batch * ty * tx, 256, 0, s>>>(grad_out, rois, grad_in, num_rois, channels, height, width,
+                                                              pooled_h, pooled_w, spatial_scale, sampling_ratio, ty, tx);
+    DANA_CHECK_LAUNCH("dana_roi_align_backward(gather)");
+    return DANA_OK;
+  }
   size_t bytes = (size_t)batch * channels * height * width * sizeof(float);
   if (bytes) {
     DANA_CHECK_ARG(grad_in, "dana_roi_align_backward: null grad_in");

@@ -141,9 +141,14 @@ def test_roi_align_backward_vs_oracle_scatter(dev):
                                      H, W, sr).cpu().numpy()
         assert np.abs(got - ref).max() <= tol
         g_nhwc = torch.from_numpy(g).to(dev).permute(0, 2, 3, 1).contiguous()  # [R,7,7,C]
-        got2 = ops.roi_align_backward(g_nhwc, torch.from_numpy(rois).to(dev), 1 / 16., 7, 7, B, C, H, W, sr,
-                                      layout=ops.NHWC).permute(0, 3, 1, 2).cpu().numpy()
+        got2_t = ops.roi_align_backward(g_nhwc, torch.from_numpy(rois).to(dev), 1 / 16., 7, 7, B, C, H, W, sr,
+                                        layout=ops.NHWC)
+        got2 = got2_t.permute(0, 3, 1, 2).cpu().numpy()
         assert np.abs(got2 - ref).max() <= tol
+        # the NHWC path is a GATHER over the feature cells (fixed summation order, no atomics, every cell written once --
+        # no zero fill): the same call again returns the same bits, also into a buffer that held garbage
+        again = ops.roi_align_backward(g_nhwc, torch.from_numpy(rois).to(dev), 1 / 16., 7, 7, B, C, H, W, sr, layout=ops.NHWC)
+        assert torch.equal(got2_t, again)
 
 
 def test_roi_layers_autograd_wrappers(dev):
