@@ -598,6 +598,15 @@ def main():
                 a[2] += row[2].elapsed_time(row[3]) * 1e-3
                 a[3] += 1
             ft, xt, tt = sum(a[0] for a in fam.values()), sum(a[1] for a in fam.values()), sum(a[2] for a in fam.values())
+            if args.dump_launches:  # the iteration's per-launch table beside the forward's
+                per, nl = {}, len(tprof) // kts
+                for i, row in enumerate(tprof):
+                    a = per.setdefault((i % nl, row[0]), [row[1], 0.0, row[5]])
+                    a[1] += row[2].elapsed_time(row[3]) / kts
+                with open(os.path.splitext(args.dump_launches)[0] + "_train_step.txt", "w") as fh:
+                    for (i, tag), (f, t, x) in sorted(per.items()):
+                        fh.write("%3d %-44s %9.2f GF %9.1f us %7.2f TF/s (executed %7.2f)\n" % (
+                            i, tag, f / 1e9, t * 1e3, f / t / 1e9, x / t / 1e9))
             result["train_step"]["roofline"] = {
                 "bound": "mfma", "achieved": round(ft / tt / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ft / tt / 1e12 / peak, 4),

@@ -73,6 +73,13 @@ struct IgemmParams {
   int lda2, IH2, IW2, stride2, K1;
   int IH21, IW21, pix21;  // A2's geometry for rows of the second geometry segment (image size, first pixel)
   int bpre;               // Bw holds pre-split bf16 planes [ldb / 16][3][N][16] (dana_split_weight), ldb = K rounded up to 16
+  // fused bottleneck tail (FUSE kernels only): the BM x 64 tile of this conv goes through LDS into a SECOND contraction,
+  // a 1x1 conv 64 -> N2 with pre-split weights Bw2 [4][3][N2][16]; scale / shift / relu belong to the first conv,
+  // scale2 / shift2 / residual / relu2 / C / ldc to the second
+  const void* Bw2;
+  const float* scale2;
+  const float* shift2;
+  int N2, relu2;
   unsigned a2_bytes;
   unsigned long long* trace;  // debug (dana_set_igemm_trace): per block {start, first MFMA, loop end, end} in 100 MHz ticks + HW id
 };
@@ -444,7 +451,7 @@ inline constexpr StepSched<NM, NL, NR, NCVF, NBW> kStepSched = make_step_sched<N
 // BPRE: the B operand is a WEIGHT that was split once per weight version (dana_split_weight: three bf16 planes per
 // K-step, [Kp / 16][3][N][16], Kp = K rounded up to 16, zero padded): its chunks of 8 bf16 go from HBM to the LDS planes as loaded, and
 // the K loop splits the activation rows only -- half the VALU work of the step.
-template <int BM, int BN, int STEM, int BPRE = 0>
+template <int BM, int BN, int STEM, int BPRE = 0, int FUSE = 0>
 __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_split_kernel(IgemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
   constexpr int RA = BM / 64;                // float4 loads of A per thread per K-step (64 rows per pass)
@@ -829,6 +836,109 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
   __syncthreads();  // (the last steps' staging writes / fragment reads vs the epilogue's use of the same LDS)
   const unsigned long long t_loop_end = p.trace ? __builtin_readcyclecounter() : 0ull;
 
+  if constexpr (FUSE) {
+    // ---- fused bottleneck tail (resnet.py:92-100): o2 = relu(bn2(conv2(x))) never leaves the CU. The tile's 128 x 64
+    // values are split into the three bf16 planes exactly as the K loop of a separate 1x1 launch would split them, laid
+    // out in LDS as that launch's four K-steps of A (rows of 32 B, halves swizzled: SLD), and contracted against the
+    // pre-split 1x1 weights N2 / 64 column chunks at a time -- B fragments straight from L2 (a lane's 16 bytes are k
+    // 8*lh.. of filter row n in the [K/16][3][N][16] layout: 1 KB contiguous per wave and plane), same K-step and product
+    // order as igemm_split_kernel's loop, so the result is bit-identical to the two-launch form. The second conv's
+    // epilogue (bn3, + residual, ReLU) works on the accumulator layout directly: 32 lanes = 128 contiguous bytes of a row.
+    static_assert(BM == 128 && BN == 64 && !STEM && BPRE, "fused tail: 128 x 64 tile over pre-split weights");
+    unsigned short* A2 = (unsigned short*)smem;  // [4 K-steps][3 planes][BM rows][16] bf16
+    {
+      const int nn = wn * 32 + li;  // this lane's column of the 64 (N == BN)
+      const float sc1 = p.scale ? p.scale[nn] : 1.f, sh1 = p.shift ? p.shift[nn] : 0.f;
+      const int ks = nn >> 4, kk = nn & 15;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[i][0][r] * sc1 + sh1;
+          if (p.relu) v = fmaxf(v, 0.f);
+          const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+          const float r1 = v - __uint_as_float(hb);
+          const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+          const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb));
+          unsigned short* w = A2 + ((ks * 3) * BM + row) * 16 + (((kk >> 3) ^ swz(row)) * 8 + (kk & 7));
+          w[0 * BM * 16] = (unsigned short)(hb >> 16);
+          w[1 * BM * 16] = (unsigned short)(mb >> 16);
+          w[2 * BM * 16] = (unsigned short)(lb >> 16);
+        }
+    }
+    __syncthreads();
+    const int N2 = p.N2, nch = N2 / 64;
+    const unsigned* a_rd = (const unsigned*)smem + (wm * (BM / 2) + li) * SLD + rcol;
+    // every global access of this phase is a buffer access = descriptor (uniform) + lane offset (one VGPR) + uniform
+    // offset (SGPR): no 64-bit address per accumulator element; rows past M fall outside the descriptors' ranges (their
+    // loads return zeros, their stores are dropped)
+    const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
+    const __amdgpu_buffer_rsrc_t rc_dst =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Cb + (long)m0 * p.ldc), 0, (int)(rows_valid * p.ldc * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc_res = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.residual ? p.residual + (long)m0 * p.ldr : p.A), 0, p.residual ? (int)(rows_valid * p.ldr * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc_b2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bw2, 0, 12 * N2 * 32, 0x00020000);
+    const int ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4;
+    const int lrow = wm * (BM / 2) + 4 * lh, lcol4 = (wn * 32 + li) * 4;
+    const int vo_c = lrow * ldc4 + lcol4, vo_r = lrow * ldr4 + lcol4;
+    const int vo_b = (wn * 32 + li) * 32 + lh * 16;
+    u32x4 bfr[4][3];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rc_b2, vo_b, (ks * 3 + pl) * N2 * 32, 0);
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
+    constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
+    for (int c = 0; c < nch; ++c) {
+      const int nn = c * 64 + wn * 32 + li;
+      const float sc2 = p.scale2 ? p.scale2[nn] : 1.f, sh2 = p.shift2 ? p.shift2[nn] : 0.f;
+      float res[TM][16];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          res[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                    rc_res, vo_r, (i * 32 + (r & 3) + 8 * (r >> 2)) * ldr4 + c * 256, 0));
+      f32x16 acc2[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4 afr[3][TM];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) afr[pc][i] = *(const u32x4*)(a_rd + ((ks * 3 + pc) * BM + i * 32) * SLD);
+#pragma unroll
+        for (int pq = 0; pq < 6; ++pq)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[PA[pq]][i]),
+                                                              __builtin_bit_cast(bf16x8, bfr[ks][PB[pq]]), acc2[i], 0, 0, 0);
+        // the next chunk's filter fragments of this K-step: their registers are free now (past the last chunk the
+        // offsets fall outside the descriptor: zeros, unused)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rc_b2, vo_b, ((ks * 3 + pl) * N2 + (c + 1) * 64) * 32, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc2[i][r] * sc2 + sh2;
+          v += res[i][r];
+          if (p.relu2) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc_dst, vo_c,
+                                                (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4 + c * 256, 0);
+        }
+    }
+    return;
+  }
+
   // ---- epilogue through LDS (same C/D map as the f32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
   // The residual (and ReLU-adjoint mask) rows of the whole tile are requested BEFORE the accumulators go through LDS:
   // the 1x1 expand convs (K = 64..512) are HBM-bound on exactly these reads and the output writes, and a load issued
@@ -1075,23 +1185,26 @@ int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   return 0;
 }
 
-template <int BM, int BN, int STEM = 0, int BPRE = 0>
+template <int BM, int BN, int STEM = 0, int BPRE = 0, int FUSE = 0>
 int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
-  if (BPRE == 0 && p0.bpre) return launch_split<BM, BN, STEM, 1>(p0, batch, s);
+  if constexpr (BPRE == 0 && FUSE == 0) {
+    if (p0.bpre) return launch_split<BM, BN, STEM, 1>(p0, batch, s);
+  }
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   size_t lds = (size_t)2 * 3 * (BM + BN) * SLD * sizeof(unsigned);
   const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
-  if (lds_c > lds) lds = lds_c;
+  if (lds_c > lds && !FUSE) lds = lds_c;
+  if (FUSE && lds < (size_t)4 * 3 * BM * 16 * 2) lds = (size_t)4 * 3 * BM * 16 * 2;  // the tile as four K-steps of A
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+    (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE, FUSE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-  igemm_split_kernel<BM, BN, STEM, BPRE><<<grid, 256, lds, s>>>(p);
+  igemm_split_kernel<BM, BN, STEM, BPRE, FUSE><<<grid, 256, lds, s>>>(p);
   return 0;
 }
 
@@ -1298,6 +1411,66 @@ int dana_conv2d_nhwc_masked(const float* input, const float* weight, float* outp
   return conv2d_impl("dana_conv2d_nhwc_masked", input, weight, output, nullptr, scale, shift, residual, nullptr, batch,
                      in_h, in_w, 0, 0, 0, cin, cout, kh, kw, stride, pad, in_pix_stride, out_pix_stride, 0,
                      res_pix_stride, 0, flags, stream, mask_act, mask_pix_stride);
+}
+
+int dana_bottleneck_tail_nhwc(const float* input, const float* w2_split, const float* scale2, const float* shift2,
+                              const float* w3_split, const float* scale3, const float* shift3, const float* residual,
+                              float* output, int batch, int h, int w, int cin, int cmid, int cout, long in_pix_stride,
+                              long out_pix_stride, long res_pix_stride, int flags, dana_stream_t stream) {
+  const char* who = "dana_bottleneck_tail_nhwc";
+  DANA_CHECK_ARG(batch >= 0 && h > 0 && w > 0, "%s: bad shape", who);
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(input && w2_split && w3_split && output, "%s: null pointer", who);
+  DANA_CHECK_ARG(cmid == 64 && cin % SBK == 0 && cin > 0 && cout % 64 == 0 && cout > 0,
+                 "%s: needs 64 middle channels, cin %% 16 == 0, cout %% 64 == 0", who);
+  DANA_CHECK_ARG(dana_get_mfma_mode() != 0, "%s: split kernel only (dana_set_mfma_mode != 0)", who);
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = input;
+  p.Bw = w2_split;
+  p.C = output;
+  p.scale = scale2;
+  p.shift = shift2;
+  p.residual = residual;
+  p.IH = p.IH1 = h;
+  p.IW = p.IW1 = w;
+  p.OH = p.OH1 = h;
+  p.OW = p.OW1 = w;
+  p.M = p.M0 = batch * h * w;
+  p.N = cmid;
+  p.KH = p.KW = 3;
+  p.stride = 1;
+  p.pad = 1;
+  p.Cin = cin;
+  p.K = 9 * cin;
+  p.alpha = 1.f;
+  p.relu = 1;
+  p.relu2 = (flags & DANA_EPI_RELU) ? 1 : 0;
+  p.bpre = 1;
+  p.Bw2 = w3_split;
+  p.scale2 = scale3;
+  p.shift2 = shift3;
+  p.N2 = cout;
+  const long lda = in_pix_stride > 0 ? in_pix_stride : cin;
+  DANA_CHECK_ARG(lda % 4 == 0 && lda >= cin, "%s: bad in_pix_stride", who);
+  const long a_bytes = (long)batch * h * w * lda * 4, b_bytes = (long)3 * cmid * p.K * 2;
+  DANA_CHECK_ARG(a_bytes < (long)OOB, "%s: input span >= 2 GiB; split the batch", who);
+  p.lda = (int)lda;
+  p.ldb = p.K;
+  p.a_bytes = (unsigned)a_bytes;
+  p.b_bytes = (unsigned)b_bytes;
+  p.ldc = out_pix_stride > 0 ? out_pix_stride : cout;
+  p.ldr = res_pix_stride > 0 ? res_pix_stride : cout;
+  p.C1 = p.C;
+  p.ldc1 = p.ldc;
+  p.residual1 = p.residual;
+  p.ldr1 = p.ldr;
+  DANA_CHECK_ARG(((uintptr_t)input & 15) == 0 && ((uintptr_t)w2_split & 15) == 0 && ((uintptr_t)w3_split & 15) == 0,
+                 "%s: input / weights must be 16-byte aligned", who);
+  p.trace = nullptr;
+  launch_split<128, 64, 0, 1, 1>(p, 1, (hipStream_t)stream);
+  DANA_CHECK_LAUNCH(who);
+  return DANA_OK;
 }
 
 int dana_conv2d_nhwc_dual(const float* input, const float* weight, float* out0, float* out1, const float* scale,

@@ -170,6 +170,7 @@ class DAnARCNN(nn.Module):
                                                                  128 if self.winograd_tile == 4 else 256))
         self.fuse_downsample = __import__('os').environ.get('DANA_FUSE_DS', '1') != '0'  # first block of a layer: expand + downsample 1x1 convs as one contraction
         self.query_streams = int(__import__('os').environ.get('DANA_QUERY_STREAMS', 1))
+        self.fuse_tail = __import__('os').environ.get('DANA_FUSE_TAIL', '1') != '0'  # conv2 + conv3 of layer1's identity blocks as one launch
         self.query_sequential = False  # chunks of the query batch one after the other on the main stream
         # False (measured faster): support trunk on its own stream, concurrent with the query trunk;
         # True: query + support batches share every trunk launch (dana_conv2d_nhwc_dual)
@@ -421,6 +422,13 @@ class DAnARCNN(nn.Module):
     def _bottleneck(self, x, n, h, w, bp, out=None, out_stride=0, in_stride=0, save=None, key=None):
         """save: optional list; receives dict(x, o1, o2, o3, h1, w1, ...) for backward.bottleneck_backward"""
         o1, h1, w1 = self._conv(x, n, h, w, bp["c1"], True, in_stride=in_stride)
+        c2, c3 = bp["c2"], bp["c3"]
+        if (getattr(self, "fuse_tail", True) and save is None and bp["ds"] is None and c2["cout"] == 64 and c2["k"] == 3 and c2["stride"] == 1
+                and c2.get("u") is None and c2.get("ws") is not None and c3.get("ws") is not None):
+            # conv2 -> conv3 in one launch (layer1's identity blocks; nothing of a frozen layer is saved for the backward)
+            return ops.bottleneck_tail(o1, n, h1, w1, c2["cin"], c2["ws"], c2["scale"], c2["shift"], c3["ws"], c3["scale"],
+                                       c3["shift"], c3["cout"], residual=x, res_stride=in_stride, out=out,
+                                       out_stride=out_stride)
         o2, _, _ = self._conv(o1, n, h1, w1, bp["c2"], True)
         if bp.get("cat") is not None and getattr(self, "fuse_downsample", True) and ops.get_mfma_mode() != 0:
             c3, ds = bp["c3"], bp["ds"]
@@ -577,6 +585,20 @@ class DAnARCNN(nn.Module):
             for bi, bp in enumerate(layer):
                 last = (li == nl - 1) and (bi == len(layer) - 1)
                 o1, h0, h1 = conv(x, g0, g1, bp["c1"], True)
+                c2, c3 = bp["c2"], bp["c3"]
+                if (two[0] and li == 0 and getattr(self, "fuse_tail", True) and bp["ds"] is None and c2["cout"] == 64
+                        and c2["k"] == 3 and c2["stride"] == 1 and c2.get("u") is None and c2.get("ws") is not None
+                        and c3.get("ws") is not None):
+                    # layer1's identity blocks (frozen: nothing saved): conv2 -> conv3 as one launch per batch
+                    m0o, mi = n0 * h0[0] * h0[1], n0 * g0[0] * g0[1]
+                    o3 = buf(m0o + n1 * h1[0] * h1[1], c3["cout"])
+                    for grp, (r0_, ri_, n_, hh) in enumerate(((0, 0, n0, h0), (m0o, mi, n1, h1))):
+                        with (on_sup() if grp else torch.cuda.stream(main)):
+                            ops.bottleneck_tail(o1[r0_:], n_, hh[0], hh[1], c2["cin"], c2["ws"], c2["scale"], c2["shift"], c3["ws"],
+                                                c3["scale"], c3["shift"], c3["cout"], residual=x[ri_:], out=o3[r0_:],
+                                                out_stride=c3["cout"], res_stride=c3["cout"])
+                    x, g0, g1 = o3, h0, h1
+                    continue
                 o2, _, _ = conv(o1, h0, h1, bp["c2"], True)
                 m0o, mi = n0 * h0[0] * h0[1], n0 * g0[0] * g0[1]
                 out0 = out1 = None

@@ -651,6 +651,26 @@ def conv2d_nhwc(x, batch, in_h, in_w, cin, weight, cout, kh, kw, stride, pad, sc
     return out, oh, ow
 
 
+def bottleneck_tail(x, batch, h, w, cin, w2, scale2, shift2, w3, scale3, shift3, cout, residual=None, relu=True, in_stride=0,
+                    out=None, out_stride=0, res_stride=0):
+    """conv2 (3x3 / 1 / pad 1, cin -> 64) + bn2 + ReLU + conv3 (1x1, 64 -> cout) + bn3 + residual + ReLU of a Bottleneck
+    (resnet.py:92-100) as ONE launch; w2 / w3 are W3 split planes. Returns (out, h, w)."""
+    _chk(x, "x")
+    if not (isinstance(w2, W3) and isinstance(w3, W3)):
+        raise TypeError("bottleneck_tail: both weights must be split planes (ops.split_weight)")
+    if out is None:
+        out = torch.empty((batch * h * w, cout), dtype=torch.float32, device=x.device)
+        out_stride = cout
+    e0 = _prof_begin()
+    lib().call("dana_bottleneck_tail_nhwc", _p(x), _p(w2.t), _p(scale2), _p(shift2), _p(w3.t), _p(scale3), _p(shift3),
+               _p(residual), _p(out), batch, h, w, cin, 64, cout, in_stride, out_stride, res_stride, EPI_RELU if relu else 0,
+               _stream())
+    m = batch * h * w
+    _prof_end(e0, ("conv3x3+1x1 M=%d N=%d K=%d+64 s1", (m, cout, 9 * cin)), 2.0 * m * 64 * (9 * cin + cout),
+              4.0 * (m * cin + 64 * 9 * cin + 64 * cout + m * cout * (2 if residual is not None else 1)))
+    return out, h, w
+
+
 def conv2d_nhwc_dual(x, n0, h0, w0, n1, h1, w1, cin, weight, cout, kh, kw, stride, pad, scale=None, shift=None,
                      res0=None, res1=None, relu=False, in_stride=0, out0=None, out1=None, out0_stride=0,
                      out1_stride=0, res0_stride=0, res1_stride=0, stem=False):

@@ -159,6 +159,17 @@ int dana_conv2d_nhwc_masked(const float* input, const float* weight, float* outp
                             int in_w, int cin, int cout, int kh, int kw, int stride, int pad, long in_pix_stride,
                             long out_pix_stride, long res_pix_stride, long mask_pix_stride, int flags,
                             dana_stream_t stream);
+/* The tail of a Bottleneck in ONE launch (resnet.py:92-100): out = relu?( bn3(conv3(relu(bn2(conv2(x))))) + residual ),
+ * conv2 3x3 / stride 1 / pad 1 with cmid = 64 output channels, conv3 1x1 cmid -> cout. Both weights are dana_split_weight
+ * planes (of the packed [cmid][3][3][cin] rows and of the [cout][cmid] rows); scale2 / shift2 and scale3 / shift3 are the
+ * folded frozen BatchNorms. conv2's output tile stays in LDS as conv3's A operand -- the [M][64] map is never written --
+ * and the result is bit-identical to dana_conv2d_nhwc (3x3, DANA_EPI_RELU) followed by dana_conv2d_nhwc (1x1, residual).
+ * flags: DANA_EPI_RELU = the final ReLU. Split kernel only (dana_set_mfma_mode != 0). */
+int dana_bottleneck_tail_nhwc(const float* input, const float* w2_split, const float* scale2, const float* shift2,
+                              const float* w3_split, const float* scale3, const float* shift3, const float* residual,
+                              float* output, int batch, int h, int w, int cin, int cmid, int cout, long in_pix_stride,
+                              long out_pix_stride, long res_pix_stride, int flags, dana_stream_t stream);
+
 /* The same conv over TWO image groups in one launch: input rows = batch0 images of h0 x w0 followed by
  * batch1 images of h1 x w1 (same channels / pixel stride); outputs go to out0 / out1 with their own row
  * strides. RCNN_base is applied to the query batch and to the support batch (dana.py:98,100): sharing

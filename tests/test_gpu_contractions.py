@@ -334,6 +334,34 @@ def test_split_k_gemm_matches_single_chain_and_fp64(dev, m, n, k):
     assert float((got - one).abs().max()) <= 2e-6 * scale * (k ** 0.5)
 
 
+def test_fused_bottleneck_tail_equals_the_two_launches(dev, mfma_mode):
+    """dana_bottleneck_tail_nhwc (resnet.py:92-100: conv2 3x3 -> bn2 -> ReLU -> conv3 1x1 -> bn3 -> + residual -> ReLU in one
+    launch, conv2's tile handed over through LDS) returns the SAME BITS as the two conv launches, incl. a ragged last row
+    tile, strided input / residual / output rows, no residual, no final ReLU."""
+    ops = _ops()
+    if mfma_mode == 0:
+        return  # split kernel only
+    g = torch.Generator().manual_seed(91)
+    for (n, h, w, ci, co, ldx, ldo, res, relu) in [(2, 19, 23, 64, 256, 64, 256, True, True), (1, 37, 41, 64, 256, 96, 320, True, True),
+                                                    (3, 16, 8, 128, 128, 128, 128, False, True), (1, 9, 15, 64, 64, 64, 64, True, False),
+                                                    (4, 75, 125, 64, 256, 64, 256, True, True)]:
+        m = n * h * w
+        x = torch.randn(m, ldx, generator=g).to(dev)
+        w2 = (torch.randn(64, 9 * ci, generator=g) / np.sqrt(9 * ci)).to(dev)
+        w3 = (torch.randn(co, 64, generator=g) / 8).to(dev)
+        s2, b2 = (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)
+        s3, b3 = (torch.rand(co, generator=g) + 0.5).to(dev), torch.randn(co, generator=g).to(dev)
+        r = torch.randn(m, ldo, generator=g).to(dev) if res else None
+        o2, _, _ = ops.conv2d_nhwc(x, n, h, w, ci, w2, 64, 3, 3, 1, 1, scale=s2, shift=b2, relu=True, in_stride=ldx)
+        ref = torch.zeros(m, ldo, device=dev)
+        ops.conv2d_nhwc(o2, n, h, w, 64, w3, co, 1, 1, 1, 0, scale=s3, shift=b3, residual=r, relu=relu, out=ref, out_stride=ldo,
+                        res_stride=ldo if res else 0)
+        got = torch.zeros(m, ldo, device=dev)
+        ops.bottleneck_tail(x, n, h, w, ci, ops.split_weight(w2, 64, 9 * ci), s2, b2, ops.split_weight(w3, co, 64), s3, b3, co,
+                            residual=r, relu=relu, in_stride=ldx, out=got, out_stride=ldo, res_stride=ldo if res else 0)
+        assert torch.equal(ref, got), (n, h, w, ci, co, float((ref - got).abs().max()))
+
+
 def test_presplit_weights_are_bit_identical_to_fp32_weights(dev, mfma_mode):
     """DANA_W_SPLIT3 (ops.split_weight): the B operand split into its three bf16 planes once per weight version feeds the
     same six products as the in-loop split -> every entry point returns the SAME BITS as with fp32 weight rows. Also the

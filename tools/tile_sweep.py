@@ -22,7 +22,13 @@ GEMM = [  # (name, m, n, k, batch)
     ("q-proj", 9576, 256, 1024, 1), ("k-proj", 4800, 256, 1024, 1), ("QK^T", 2394, 1200, 256, 4), ("A.S", 2394, 1024, 1200, 4),
     ("rpn heads", 9576, 72, 512, 1), ("roi q-proj", 25088, 256, 1024, 1), ("roi transform", 25088, 64, 1024, 1),
     ("roi QK^T", 6272, 147, 256, 4), ("roi A.S", 6272, 1024, 160, 4), ("ffn1", 512, 1024, 3136, 1), ("k2-proj", 1176, 256, 1024, 1),
+    # the 36 plane GEMMs of the Winograd F(4x4) convs: [4x4 tiles][cin] x [cout][cin]
+    ("wino rpn", 640, 512, 2048, 36), ("wino l4", 512, 512, 512, 36), ("wino l3", 640, 256, 256, 36), ("wino l2", 2432, 128, 128, 36),
+    ("wino sup l3", 600, 256, 256, 36), ("wino sup l2", 2400, 128, 128, 36),
 ]
+if os.environ.get("SWEEP_ONLY"):
+    CONV = []
+    GEMM = [g for g in GEMM if g[0].startswith(os.environ["SWEEP_ONLY"])]
 MODES = [(1, "auto"), (4, "128x128"), (2, "128x64"), (5, "64x128"), (3, "64x64")]
 
 
