@@ -259,20 +259,18 @@ def _attention_backward(d_dense, ld_dd, a, unary, q, k_, s_mat, Bn, rows_b, nseg
     dA = torch.zeros((Bn, rows_b, Kp), dtype=torch.float32, device=dev)
     ops.gemm_nt(d_dense, s_mat, rows_b, K, 1024, lda=ld_dd, out=dA, ldc=Kp, batch=Bn, batch_a=rows_b * ld_dd,
                 batch_b=s_batch, batch_c=rows_b * Kp)
-    dflat = d_dense.view(-1)
-    for b in range(Bn):  # d s[b] += a[b]^T . d_dense[b]
-        t = ops.conv2d_wgrad(a[b], dflat[b * rows_b * ld_dd:], 1, 1, rows_b, 1024, Kp, 1, 1, 1, 0, in_stride=ld_dd,
-                             grad_stride=Kp)
-        ops.axpy_rows_(d_s_out.view(-1)[b * s_batch:], t, K, 1024)
+    # d s[b] += a[b]^T . d_dense[b], every image in one launch (a's zero-padded columns K..Kp-1 are computed, not stored)
+    ops.gemm_tn_batched(a, d_dense, Bn, rows_b, Kp, 1024, d_s_out, ldy=Kp, ldx=ld_dd, batch_y=rows_b * Kp,
+                        batch_x=rows_b * ld_dd, batch_out=s_batch, n_valid=K)
+    for b in range(Bn):
         ops.colsum(dA[b], rows_b, K, ld=Kp, alpha=ugamma / nseg, out=d_u_out.view(-1)[b * u_batch:])
     ops.attn_softmax_unary_backward_(dA, a, unary, Bn * rows_b, rows_b, nseg, L, Kp, Kp, ugamma, 1.0 / nseg,
                                      1.0 / math.sqrt(dq), unary_batch_stride=u_batch)
     kt = ops.transpose_batched(k_, Bn, K, dq, ldi=dq, ldo=Kp, in_batch=k_batch)  # [Bn][dq][Kp], zero padded
     d_q = ops.gemm_nt(dA, kt, rows_b, dq, Kp, lda=Kp, ldb=Kp, batch=Bn, batch_a=rows_b * Kp, batch_b=dq * Kp)
-    qf = q.view(-1)
-    for b in range(Bn):  # d k[b] += dS0[b]^T . q[b]
-        t = ops.conv2d_wgrad(dA[b], qf[b * rows_b * dq:], 1, 1, rows_b, dq, Kp, 1, 1, 1, 0, grad_stride=Kp)
-        ops.axpy_rows_(d_k_out.view(-1)[b * k_batch:], t, K, dq)
+    # d k[b] += dS0[b]^T . q[b]
+    ops.gemm_tn_batched(dA, q, Bn, rows_b, Kp, dq, d_k_out, ldy=Kp, ldx=dq, batch_y=rows_b * Kp, batch_x=rows_b * dq,
+                        batch_out=k_batch, n_valid=K)
     return d_q.view(Bn * rows_b, dq)
 
 

@@ -870,9 +870,10 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     __syncthreads();
     const int N2 = p.N2, nch = N2 / 64;
     const unsigned* a_rd = (const unsigned*)smem + (wm * (BM / 2) + li) * SLD + rcol;
-    // every global access of this phase is a buffer access = descriptor (uniform) + lane offset (one VGPR) + uniform
-    // offset (SGPR): no 64-bit address per accumulator element; rows past M fall outside the descriptors' ranges (their
-    // loads return zeros, their stores are dropped)
+    // every global access of this phase is a buffer access = descriptor (uniform) + 32-bit lane offset (the lane's own
+    // part plus a uniform term: one v_add with an SGPR operand): no 64-bit address per accumulator element. Rows past M
+    // fall outside the descriptors' ranges -- their loads return zeros, their stores are dropped. (The whole offset is
+    // in the VGPR operand: the instruction's SGPR offset is NOT part of the hardware's range check.)
     const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
     const __amdgpu_buffer_rsrc_t rc_dst =
         __builtin_amdgcn_make_buffer_rsrc((void*)(Cb + (long)m0 * p.ldc), 0, (int)(rows_valid * p.ldc * 4), 0x00020000);
@@ -887,19 +888,21 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rc_b2, vo_b, (ks * 3 + pl) * N2 * 32, 0);
+      for (int pl = 0; pl < 3; ++pl) bfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rc_b2, vo_b + (ks * 3 + pl) * N2 * 32, 0, 0);
     constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
     constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
     for (int c = 0; c < nch; ++c) {
       const int nn = c * 64 + wn * 32 + li;
       const float sc2 = p.scale2 ? p.scale2[nn] : 1.f, sh2 = p.shift2 ? p.shift2[nn] : 0.f;
       float res[TM][16];
+      int vr = vo_r + c * 256, vc = vo_c + c * 256;  // (opaque per chunk: 64 loop-invariant row addresses would otherwise
+      asm volatile("" : "+v"(vr), "+v"(vc));         //  be kept in registers across the loop -- one workgroup less per CU)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           res[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                    rc_res, vo_r, (i * 32 + (r & 3) + 8 * (r >> 2)) * ldr4 + c * 256, 0));
+                                                    rc_res, vr + (i * 32 + (r & 3) + 8 * (r >> 2)) * ldr4, 0, 0));
       f32x16 acc2[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -922,7 +925,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
         // offsets fall outside the descriptor: zeros, unused)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          bfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rc_b2, vo_b, ((ks * 3 + pl) * N2 + (c + 1) * 64) * 32, 0);
+          bfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rc_b2, vo_b + ((ks * 3 + pl) * N2 + (c + 1) * 64) * 32, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -932,8 +935,8 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
           float v = acc2[i][r] * sc2 + sh2;
           v += res[i][r];
           if (p.relu2) v = fmaxf(v, 0.f);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc_dst, vo_c,
-                                                (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4 + c * 256, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc_dst,
+                                                vc + (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4, 0, 0);
         }
     }
     return;

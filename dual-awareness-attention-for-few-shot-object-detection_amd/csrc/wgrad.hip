@@ -633,17 +633,19 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_128p_kernel(WgradParams p)
 // through LDS): 4x the blocks and S/4 dependent loads per thread -- the 1-lane version was latency-bound (~19 us).
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW, const float* __restrict__ row_scale,
-                    long n4, int K4, int S, int accumulate) {
+                    long n4, int K4, int S, int accumulate, long out_plane4 = -1, long n4_valid = -1) {
   __shared__ float4 part[4][64];
   const int ol = threadIdx.x & 63, q = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + ol;
   partial += (long)blockIdx.y * S * n4;  // plane of a batched launch
-  dW += (long)blockIdx.y * n4;
+  dW += (long)blockIdx.y * (out_plane4 >= 0 ? out_plane4 : n4);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long n4s = n4;  // (slice stride of the partial sums)
+  if (n4_valid >= 0) n4 = n4_valid;  // only the first rows of a plane are results (zero-padded operand rows behind them)
   if (i < n4) {
 #pragma unroll 4
     for (int s = q; s < S; s += 4) {
-      const float4 v = partial[(long)s * n4 + i];
+      const float4 v = partial[(long)s * n4s + i];
       a.x += v.x;
       a.y += v.y;
       a.z += v.z;
@@ -850,6 +852,75 @@ int dana_wgrad_tn_batched(const float* dY, const float* X, float* out, int plane
 }
 
 extern "C" {
+
+/* out[z][n][k] (+)= sum_m y[z][m][n] * x[z][m][k] for n < n_valid: a batch of "TN" GEMMs (the adjoints of torch.bmm
+ * w.r.t. its right operand, dana.py:140-150 / 270-283, one plane per image). N rows are computed (y may carry zero
+ * padded columns behind n_valid); k % 64 == 0, n % 4 == 0. Deterministic split-M reduction through the workspace. */
+size_t dana_gemm_tn_batched_workspace_bytes(int planes, int m, int n, int k) {
+  if (planes <= 0 || m <= 0 || n <= 0 || k <= 0) return 0;
+  return (size_t)planes * wgrad_shape(n, k, m, planes).S * n * k * sizeof(float);
+}
+
+int dana_gemm_tn_batched(const float* y, const float* x, float* out, int planes, int m, int n, int k, long ldy, long ldx,
+                         long batch_y, long batch_x, long batch_out, int n_valid, int accumulate, void* workspace,
+                         size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(planes >= 0 && m > 0 && n > 0 && k > 0 && k % 64 == 0 && n % 4 == 0 && n_valid >= 0 && n_valid <= n,
+                 "dana_gemm_tn_batched: bad shape (k %% 64 == 0, n %% 4 == 0)");
+  if (planes == 0 || n_valid == 0) return DANA_OK;
+  DANA_CHECK_ARG(y && x && out, "dana_gemm_tn_batched: null pointer");
+  if (ldy <= 0) ldy = n;
+  if (ldx <= 0) ldx = k;
+  DANA_CHECK_ARG(ldy % 4 == 0 && ldx % 4 == 0 && ldy >= n && ldx >= k && batch_y % 4 == 0 && batch_x % 4 == 0 &&
+                     batch_out % 4 == 0 && (((uintptr_t)y | (uintptr_t)x | (uintptr_t)out) & 15) == 0,
+                 "dana_gemm_tn_batched: strides / pointers must be 16-byte aligned");
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.dY = y;
+  p.X = x;
+  p.IH = 1;
+  p.IW = m;
+  p.OH = 1;
+  p.OW = m;
+  p.M = m;
+  p.N = n;
+  p.K = k;
+  p.Cin = k;
+  p.KH = p.KW = 1;
+  p.stride = 1;
+  p.pad = 0;
+  p.ldx = (int)ldx;
+  p.ldy = (int)ldy;
+  p.batch_y = batch_y;
+  p.batch_x = batch_x;
+  const long xb = (long)m * ldx * 4, yb = (long)m * ldy * 4;
+  DANA_CHECK_ARG(xb < (long)OOB && yb < (long)OOB, "dana_gemm_tn_batched: plane >= 2 GiB");
+  p.x_bytes = (unsigned)xb;
+  p.y_bytes = (unsigned)yb;
+  const WgradShape ws = wgrad_shape(n, k, m, planes);
+  const int S = ws.S;
+  p.m_chunk = ((m + S - 1) / S + 31) / 32 * 32;
+  p.nsplit = S;
+  const size_t need = (size_t)planes * S * n * k * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("dana_gemm_tn_batched: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  p.partial = (float*)workspace;
+  DANA_CHECK_ARG((long)planes * S <= 65535, "dana_gemm_tn_batched: too many slices");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(ws.tn, ws.tk, planes * S);
+  if (ws.tile == 128)
+    launch_wgrad_128(p, grid, s);
+  else
+    wgrad_f32_kernel<<<grid, 256, 0, s>>>(p);
+  DANA_CHECK_LAUNCH("dana_gemm_tn_batched");
+  const long n4 = (long)n * k / 4, n4v = (long)n_valid * k / 4;
+  dim3 rgrid(dana_ceil_div(n4v, 64), planes);
+  wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>((const float4*)workspace, (float4*)out, nullptr, n4, k / 4, S, accumulate,
+                                            batch_out > 0 ? batch_out / 4 : n4v, n4v);
+  DANA_CHECK_LAUNCH("dana_gemm_tn_batched(reduce)");
+  return DANA_OK;
+}
 
 size_t dana_conv2d_wgrad_workspace_bytes(int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride,
                                          int pad) {

@@ -499,10 +499,20 @@ class DAnARCNN(nn.Module):
         two = [merge_from > 0]  # currently issuing the two batches as two launches (on two streams)
 
         def buf(rows, cols):
+            """a buffer both streams write (their own row ranges). It comes from the CALLER's stream pool: the block may
+            have been released a moment ago by an op of that stream whose kernel is still queued (a workspace, an op's own
+            output), which is safe for later work of that stream only -- so the support stream waits for the caller's
+            stream to reach this point before it touches the buffer (it may not run ahead of the allocation)"""
             t = torch.empty((rows, cols), dtype=torch.float32, device=dev)
             if sup_stream is not main:
                 t.record_stream(sup_stream)
+                if fence:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    sup_stream.wait_event(ev)
             return t
+
+        fence = __import__('os').environ.get('DANA_DUAL_FENCE', '1') != '0'
 
         def on_sup():
             return torch.cuda.stream(sup_stream)
@@ -579,11 +589,14 @@ class DAnARCNN(nn.Module):
 
         corr = sup = None
         nl = len(plan["layers"])
+        stall = getattr(self, "_debug_stall", None)  # tests: (layer, spin cycles) -- hold the caller's stream back there
         for li, layer in enumerate(plan["layers"]):
             if li >= merge_from:
                 join()
             for bi, bp in enumerate(layer):
                 last = (li == nl - 1) and (bi == len(layer) - 1)
+                if stall is not None and two[0] and li == stall[0]:
+                    torch.cuda._sleep(int(stall[1]))
                 o1, h0, h1 = conv(x, g0, g1, bp["c1"], True)
                 c2, c3 = bp["c2"], bp["c3"]
                 if (two[0] and li == 0 and getattr(self, "fuse_tail", True) and bp["ds"] is None and c2["cout"] == 64

@@ -499,16 +499,23 @@ def draw_and_upload(req, device, static=None):
     part_a[0] = n
     part_a[1:2] = np.array([1.0 / num_examples], dtype=np.float32).view(np.int32)
     part_a[2:] = pairs.reshape(-1)
-    if static is None:
-        static = torch.empty((lay["pairs"] + 2 * n,), dtype=torch.int32, device=device)
     cs = _PINNED.get("copy_stream")
-    if cs is None or cs.device != static.device:
-        cs = _PINNED["copy_stream"] = torch.cuda.Stream(device=static.device)
+    if cs is None or cs.device != torch.device(device):
+        cs = _PINNED["copy_stream"] = torch.cuda.Stream(device=device)
     cur = torch.cuda.current_stream()
-    # (the buffer's previous consumers are long done: a fresh tensor, or a static one whose last reader -- the previous
-    # iteration's graph -- finished before this iteration's counts could be read)
+    if static is None:
+        # a fresh buffer FROM THE COPY STREAM'S POOL: the upload below starts at once, and a block of the caller's pool
+        # may still be in use by a kernel that is queued on the caller's stream (released in stream order only) when
+        # that stream lags behind the host -- two processes on one GPU, a long kernel in front (regression:
+        # tests/test_gpu_backward.py::test_two_stream_trunk_..._recycled_blocks)
+        with torch.cuda.stream(cs):
+            static = torch.empty((lay["pairs"] + 2 * n,), dtype=torch.int32, device=device)
+        static.record_stream(cur)
+    else:
+        # (a static buffer's last reader -- the previous iteration's graph -- finished before this iteration's counts
+        # could be read)
+        static.record_stream(cs)
     ev_a = _pinned_upload(part_a, static[lay["hdr"]:], stream=cs)
-    static.record_stream(cs)
     t0 = _time.perf_counter()
     cnt_p = req["proposal_counts"].cpu().numpy()  # host sync: np.random needs the counts
     HOST_WAIT[0] += _time.perf_counter() - t0
@@ -1132,6 +1139,21 @@ def conv2d_wgrad(grad_out, x, batch, in_h, in_w, cin, cout, kh, kw, stride, pad,
     m = batch * ((in_h + 2 * pad - kh) // stride + 1) * ((in_w + 2 * pad - kw) // stride + 1)
     _prof_end(e0, ("wgrad%dx%d M=%d N=%d K=%d s%d", (kh, kw, m, cout, kh * kw * cin, stride)),
               2.0 * m * cout * kh * kw * cin)
+    return out
+
+
+def gemm_tn_batched(y, x, planes, m, n, k, out, ldy=0, ldx=0, batch_y=0, batch_x=0, batch_out=0, n_valid=None, accumulate=True):
+    """out[z][r][k] (+)= sum_m y[z][m][r] * x[z][m][k] for r < n_valid, all planes z in one launch (the adjoints of torch.bmm
+    w.r.t. its right operand: d value / d key of the attention, dana.py:140-150)"""
+    _chk(y, "y")
+    _chk(x, "x")
+    _chk(out, "out")
+    n_valid = n if n_valid is None else n_valid
+    ws = _ws(lib().query("dana_gemm_tn_batched_workspace_bytes", planes, m, n, k), x.device)
+    e0 = _prof_begin()
+    lib().call("dana_gemm_tn_batched", _p(y), _p(x), _p(out), planes, m, n, k, ldy, ldx, batch_y or m * (ldy or n),
+               batch_x or m * (ldx or k), batch_out or n_valid * k, n_valid, int(accumulate), _p(ws), ws.numel(), _stream())
+    _prof_end(e0, ("wgrad1x1 M=%d N=%d K=%d b%d", (m, n_valid, k, planes)), 2.0 * planes * m * n_valid * k)
     return out
 
 

@@ -396,6 +396,14 @@ int dana_conv2d_wgrad_nhwc(const float* grad_out, const float* input, float* gra
                            int in_w, int cin, int cout, int kh, int kw, int stride, int pad, long in_pix_stride,
                            long grad_pix_stride, const float* row_scale, int accumulate, void* workspace, size_t workspace_bytes,
                            dana_stream_t stream);
+/* A batch of "TN" GEMMs, out[z][n][k] (+)= sum_m y[z][m][n] * x[z][m][k] for n < n_valid -- the adjoints of torch.bmm
+ * w.r.t. its right operand (dana.py:140-150, 270-283: d value / d key of the dual-awareness attention), one plane z per
+ * image in ONE launch. y rows have ldy >= n floats (columns n_valid..n-1 may be zero padding), x rows ldx >= k; planes
+ * are batch_y / batch_x / batch_out floats apart. k % 64 == 0, n % 4 == 0; deterministic split-M reduction. */
+size_t dana_gemm_tn_batched_workspace_bytes(int planes, int m, int n, int k);
+int dana_gemm_tn_batched(const float* y, const float* x, float* out, int planes, int m, int n, int k, long ldy, long ldx,
+                         long batch_y, long batch_x, long batch_out, int n_valid, int accumulate, void* workspace,
+                         size_t workspace_bytes, dana_stream_t stream);
 /* weights for the data gradient of a stride-1 conv: out[cin][kh][kw][cout] = w[cout][KH-1-kh][KW-1-kw][cin]*scale[cout];
  * grad_input = dana_conv2d_nhwc(grad_out, out, cin <-> cout swapped, same kernel size / pad) */
 int dana_conv2d_dgrad_weight(const float* w_packed, const float* scale, float* out, int cout, int cin, int kh, int kw,

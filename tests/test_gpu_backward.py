@@ -531,3 +531,40 @@ def test_merged_trunk_modes_equal_the_two_stream_trunk(dev, mfma_mode, merge_fro
             assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-12, k
         else:
             assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-12, k
+
+
+def test_two_stream_trunk_in_shared_buffers_does_not_race_on_recycled_blocks(dev):
+    """The Trainer's forward (merge_trunk, merge_from 3) runs the query and the support batch on two streams over the row
+    ranges of shared buffers that come from the caller's stream pool. A block that pool hands out may still be in use by a
+    queued kernel of the caller's stream (an op's workspace, released in stream order): the support stream must not
+    touch it before the caller's stream got there (`buf()` in `_rcnn_base_dual`). Regression: two processes sharing one
+    GPU produced wrong losses. Here the caller's stream is held back inside the trunk -- a spin kernel in front of every
+    block of one layer -- so that the support stream WOULD run ahead of it."""
+    import dana_amd
+    from dana_amd import synthetic as S
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=2, shot=2, classes=["fg", "bg"])
+    m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=5, profile="test"))
+    m.to(dev).train()
+    inputs = [t.to(dev) for t in S.episode_inputs(2, 2, 2, 256, 320, seed=9)]
+
+    def run():
+        np.random.seed(3)
+        with torch.no_grad():
+            out = m(*inputs)
+        torch.cuda.synchronize()
+        return [t.clone() if torch.is_tensor(t) else t for t in out]
+
+    ref = run()
+    m.merge_trunk, m.merge_from = True, 3
+    base = run()
+    for a, b in zip(base, ref):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b)
+    for layer in (0, 1, 2):
+        m._debug_stall = (layer, 2_000_000)
+        for _ in range(2):
+            got = run()
+            for a, b in zip(got, base):
+                if torch.is_tensor(a):
+                    assert torch.equal(a, b), layer
+    m._debug_stall = None

@@ -356,10 +356,12 @@ def test_fused_bottleneck_tail_equals_the_two_launches(dev, mfma_mode):
         ref = torch.zeros(m, ldo, device=dev)
         ops.conv2d_nhwc(o2, n, h, w, 64, w3, co, 1, 1, 1, 0, scale=s3, shift=b3, residual=r, relu=relu, out=ref, out_stride=ldo,
                         res_stride=ldo if res else 0)
-        got = torch.zeros(m, ldo, device=dev)
+        got = torch.full((m + 136, ldo), -7.0, device=dev)  # guard rows behind the last (ragged) row tile
+        got[:m].zero_()
         ops.bottleneck_tail(x, n, h, w, ci, ops.split_weight(w2, 64, 9 * ci), s2, b2, ops.split_weight(w3, co, 64), s3, b3, co,
                             residual=r, relu=relu, in_stride=ldx, out=got, out_stride=ldo, res_stride=ldo if res else 0)
-        assert torch.equal(ref, got), (n, h, w, ci, co, float((ref - got).abs().max()))
+        assert torch.equal(ref, got[:m]), (n, h, w, ci, co, float((ref - got[:m]).abs().max()))
+        assert bool((got[m:] == -7.0).all()), "rows past M were written"
 
 
 def test_presplit_weights_are_bit_identical_to_fp32_weights(dev, mfma_mode):
