@@ -523,7 +523,7 @@ def main():
         direct = [r for r in prof if not r[0].startswith("wino")]
         fw, xw, tw = family(wino) if wino else (0.0, 0.0, 1e-9)
         fd, xd, td = family(direct)
-        traffic_kernel = "igemm_split_kernel<128, 128, 0>" if split else "igemm_f32_kernel<64, 64, 0>"
+        traffic_kernel = "igemm_split_kernel_128<0" if split else "igemm_f32_kernel<64, 64, 0>"  # (the 128 x 128 tile; prefix match: the BPRE argument follows)
         result["roofline"] = {
             "bound": "mfma",
             "kernel": ("igemm_split_kernel (fp32 operands split exactly into 3 bf16 each, 6 x v_mfma_f32_32x32x16_bf16 per "
@@ -582,7 +582,7 @@ def main():
                 result["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ms_) /
                                                       sum(v["launches"] for v in ms_))
                 result["roofline"]["traffic_source"] = "profiles/r3_pmc_traffic.json (committed PMC run, not this run)"
-            except (OSError, KeyError, ValueError):
+            except (OSError, KeyError, ValueError, ZeroDivisionError):
                 pass
         if tprof is not None:
             kts = tprof_steps

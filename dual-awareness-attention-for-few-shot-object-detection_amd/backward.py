@@ -262,8 +262,7 @@ def _attention_backward(d_dense, ld_dd, a, unary, q, k_, s_mat, Bn, rows_b, nseg
     # d s[b] += a[b]^T . d_dense[b], every image in one launch (a's zero-padded columns K..Kp-1 are computed, not stored)
     ops.gemm_tn_batched(a, d_dense, Bn, rows_b, Kp, 1024, d_s_out, ldy=Kp, ldx=ld_dd, batch_y=rows_b * Kp,
                         batch_x=rows_b * ld_dd, batch_out=s_batch, n_valid=K)
-    for b in range(Bn):
-        ops.colsum(dA[b], rows_b, K, ld=Kp, alpha=ugamma / nseg, out=d_u_out.view(-1)[b * u_batch:])
+    ops.colsum_batched(dA, Bn, rows_b, K, d_u_out, ld=Kp, x_batch=rows_b * Kp, out_batch=u_batch, alpha=ugamma / nseg)
     ops.attn_softmax_unary_backward_(dA, a, unary, Bn * rows_b, rows_b, nseg, L, Kp, Kp, ugamma, 1.0 / nseg,
                                      1.0 / math.sqrt(dq), unary_batch_stride=u_batch)
     kt = ops.transpose_batched(k_, Bn, K, dq, ldi=dq, ldo=Kp, in_batch=k_batch)  # [Bn][dq][Kp], zero padded

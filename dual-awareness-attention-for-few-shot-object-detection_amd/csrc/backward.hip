@@ -69,8 +69,10 @@ unpack_weight_kernel(const float* __restrict__ packed, float* __restrict__ w, in
 // out[c] (+)= sum_r x[r][c]  -- two-stage deterministic: grid (C/64, chunks), then a tiny finisher
 constexpr int CS_ROWS = 256;
 __global__ void __launch_bounds__(256)
-colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, long rows, int C, long ld) {
+colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, long rows, int C, long ld, long x_batch = 0) {
   __shared__ float part[4][64];
+  x += (long)blockIdx.z * x_batch;  // (batched: one matrix per blockIdx.z, its partial sums behind the previous one's)
+  partial += (long)blockIdx.z * gridDim.y * C;
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
@@ -119,9 +121,11 @@ scale_shift_relu_kernel(float4* __restrict__ x, const float4* __restrict__ scale
 
 __global__ void __launch_bounds__(256)
 colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int chunks, int C, float alpha,
-                    int accumulate) {
+                    int accumulate, long out_batch = 0) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  partial += (long)blockIdx.y * chunks * C;
+  out += (long)blockIdx.y * out_batch;
   float s = 0.f;
   for (int k = 0; k < chunks; ++k) s += partial[(long)k * C + c];
   out[c] = (accumulate ? out[c] : 0.f) + alpha * s;
@@ -284,6 +288,29 @@ int dana_colsum(const float* x, float* out, long rows, int channels, long ld, fl
   colsum_final_kernel<<<dana_ceil_div(channels, 256), 256, 0, (hipStream_t)stream>>>((const float*)workspace, out, chunks,
                                                                                       channels, alpha, accumulate);
   DANA_CHECK_LAUNCH("dana_colsum(final)");
+  return DANA_OK;
+}
+
+int dana_colsum_batched(const float* x, float* out, int batch, long rows, int channels, long ld, long x_batch, long out_batch,
+                        float alpha, int accumulate, void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && rows > 0 && channels > 0, "dana_colsum_batched: bad args");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(x && out && batch <= 65535, "dana_colsum_batched: bad args");
+  if (ld <= 0) ld = channels;
+  const size_t need = (size_t)batch * dana_colsum_workspace_bytes(rows, channels);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("dana_colsum_batched: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  const int chunks = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+  DANA_CHECK_ARG(chunks <= 65535, "dana_colsum_batched: too many rows");
+  dim3 grid(dana_ceil_div(channels, 64), chunks, batch);
+  colsum_partial_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (float*)workspace, rows, channels, ld, x_batch);
+  DANA_CHECK_LAUNCH("dana_colsum_batched(partial)");
+  dim3 fgrid(dana_ceil_div(channels, 256), batch);
+  colsum_final_kernel<<<fgrid, 256, 0, (hipStream_t)stream>>>((const float*)workspace, out, chunks, channels, alpha,
+                                                               accumulate, out_batch);
+  DANA_CHECK_LAUNCH("dana_colsum_batched(final)");
   return DANA_OK;
 }
 

@@ -452,7 +452,7 @@ inline constexpr StepSched<NM, NL, NR, NCVF, NBW> kStepSched = make_step_sched<N
 // K-step, [Kp / 16][3][N][16], Kp = K rounded up to 16, zero padded): its chunks of 8 bf16 go from HBM to the LDS planes as loaded, and
 // the K loop splits the activation rows only -- half the VALU work of the step.
 template <int BM, int BN, int STEM, int BPRE = 0, int FUSE = 0>
-__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_split_kernel(IgemmParams p) {
+__device__ __forceinline__ void igemm_split_body(const IgemmParams& p) {
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
   constexpr int RA = BM / 64;                // float4 loads of A per thread per K-step (64 rows per pass)
   // B: fp32 rows like A (64 rows per pass), or 16-byte chunks of the pre-split planes (3 planes x BN rows x 2 halves)
@@ -980,11 +980,22 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
       }
     }
   }
-  // The common tile -- all BM rows and BN columns inside the problem, one geometry segment, vector I/O, no ReLU-adjoint
-  // mask -- takes a straight-line epilogue (uniform choice): two float4 loads for scale / shift, every pass's LDS read
+  // The common tile -- all BM rows and BN columns inside the problem, one geometry segment, vector I/O
+  // -- takes a straight-line epilogue (uniform choice): two float4 loads for scale / shift, every pass's LDS read
   // issued before the first is used, no per-pass bounds / flag branches. (The general form below loads the eight scale /
   // shift values one by one, each behind its own wait, and serialises the passes behind their LDS reads.)
-  const bool fast_epi = p.vec_io && p.vec_ss && one_seg && !p.mask && m0 + BM <= p.M && n0 + BN <= p.N;
+  const bool fast_epi = p.vec_io && p.vec_ss && one_seg && m0 + BM <= p.M && n0 + BN <= p.N;
+  // The ReLU-adjoint mask rows of a data-gradient launch (activation rows: only their signs matter) are requested ahead
+  // like the residual rows -- a load per pass inside the store loop cannot be hoisted over the stores (possible alias)
+  // and costs an HBM round trip per pass --, but in halves of at most 8 passes: the first half here, the second when the
+  // first has been turned into sign bits, so that a 128 x 128 tile stays inside its two-blocks-per-CU register budget.
+  constexpr int EH = NP > 8 ? 2 : 1, NH = NP / EH;
+  float4 rmask[NH];
+  const float* const k_base = p.mask ? p.mask + (long)(m0 + er) * p.ldm + n : nullptr;
+  if (p.mask && fast_epi) {
+#pragma unroll
+    for (int q = 0; q < NH; ++q) rmask[q] = *(const float4*)(k_base + (long)(q * RPP) * p.ldm);
+  }
   float sc[4], sh[4];  // (requested with the residual rows: in flight while the accumulators go through LDS)
   if (fast_epi) {
     const float4 s4 = p.scale ? *(const float4*)(p.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -1012,33 +1023,63 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
 #pragma unroll
   for (int q = 0; q < 4; ++q) sc[q] *= p.alpha;
   if (fast_epi) {
-    float4 a4[NP];
+    auto emit = [&](auto res_c, auto relu_c, auto mask_c) {
+      constexpr bool RES = decltype(res_c)::value != 0, RELU = decltype(relu_c)::value != 0, MASK = decltype(mask_c)::value != 0;
 #pragma unroll
-    for (int q = 0; q < NP; ++q) a4[q] = *(const float4*)(Cs + (er + q * RPP) * CLD + ec);
-    auto emit = [&](auto res_c, auto relu_c) {
-      constexpr bool RES = decltype(res_c)::value != 0, RELU = decltype(relu_c)::value != 0;
+      for (int h = 0; h < EH; ++h) {
+        float4 a4[NH];  // (every pass's LDS read of the half issued before the first is used)
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        float v[4] = {a4[q].x * sc[0] + sh[0], a4[q].y * sc[1] + sh[1], a4[q].z * sc[2] + sh[2], a4[q].w * sc[3] + sh[3]};
-        if (RES) {
-          v[0] += rres[q].x;
-          v[1] += rres[q].y;
-          v[2] += rres[q].z;
-          v[3] += rres[q].w;
+        for (int q = 0; q < NH; ++q) a4[q] = *(const float4*)(Cs + (er + (h * NH + q) * RPP) * CLD + ec);
+        unsigned mb = 0;
+        if (MASK) {
+#pragma unroll
+          for (int q = 0; q < NH; ++q)
+            mb |= ((rmask[q].x > 0.f ? 1u : 0u) | (rmask[q].y > 0.f ? 2u : 0u) | (rmask[q].z > 0.f ? 4u : 0u) |
+                   (rmask[q].w > 0.f ? 8u : 0u)) << (4 * q);
+          if (h + 1 < EH) {  // (the next half's rows: they land while this half is stored)
+#pragma unroll
+            for (int q = 0; q < NH; ++q) rmask[q] = *(const float4*)(k_base + (long)(((h + 1) * NH + q) * RPP) * p.ldm);
+          }
         }
-        if (RELU) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        for (int q = 0; q < NH; ++q) {
+          const int qq = h * NH + q;
+          float v[4] = {a4[q].x * sc[0] + sh[0], a4[q].y * sc[1] + sh[1], a4[q].z * sc[2] + sh[2], a4[q].w * sc[3] + sh[3]};
+          if (RES) {
+            v[0] += rres[qq].x;
+            v[1] += rres[qq].y;
+            v[2] += rres[qq].z;
+            v[3] += rres[qq].w;
+          }
+          if (RELU) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+          }
+          if (MASK) {
+            const unsigned nb = mb >> (4 * q);
+            v[0] = (nb & 1u) ? v[0] : 0.f;
+            v[1] = (nb & 2u) ? v[1] : 0.f;
+            v[2] = (nb & 4u) ? v[2] : 0.f;
+            v[3] = (nb & 8u) ? v[3] : 0.f;
+          }
+          *(float4*)(c_base + (long)(qq * RPP) * ld_c) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *(float4*)(c_base + (long)(q * RPP) * ld_c) = make_float4(v[0], v[1], v[2], v[3]);
       }
     };
-    if (p.residual) {
-      if (p.relu) emit(IC<1>{}, IC<1>{});
-      else emit(IC<1>{}, IC<0>{});
+    if (p.mask) {  // (data gradients)
+      if (p.residual) {
+        if (p.relu) emit(IC<1>{}, IC<1>{}, IC<1>{});
+        else emit(IC<1>{}, IC<0>{}, IC<1>{});
+      } else {
+        if (p.relu) emit(IC<0>{}, IC<1>{}, IC<1>{});
+        else emit(IC<0>{}, IC<0>{}, IC<1>{});
+      }
+    } else if (p.residual) {
+      if (p.relu) emit(IC<1>{}, IC<1>{}, IC<0>{});
+      else emit(IC<1>{}, IC<0>{}, IC<0>{});
     } else {
-      if (p.relu) emit(IC<0>{}, IC<1>{});
-      else emit(IC<0>{}, IC<0>{});
+      if (p.relu) emit(IC<0>{}, IC<1>{}, IC<0>{});
+      else emit(IC<0>{}, IC<0>{}, IC<0>{});
     }
   } else if (full4) {
 #pragma unroll
@@ -1102,6 +1143,18 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) igemm_spl
     tr[6] = w_start;
     tr[7] = 0;
   }
+}
+
+// The kernels proper. The 128 x 128 tile is compiled for TWO workgroups per CU: 192 arch VGPRs beside its 64 accumulator
+// registers (the compiler, left alone with the one-block bound, spends 200+ on the epilogue's prefetches and halves the
+// occupancy of the whole K loop).
+template <int BM, int BN, int STEM, int BPRE = 0, int FUSE = 0>
+__global__ void __launch_bounds__(256, 2) igemm_split_kernel(IgemmParams p) {
+  igemm_split_body<BM, BN, STEM, BPRE, FUSE>(p);
+}
+template <int STEM, int BPRE>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) igemm_split_kernel_128(IgemmParams p) {
+  igemm_split_body<128, 128, STEM, BPRE, 0>(p);
 }
 
 // ---- skinny GEMM (N <= 8): one wave per output row, lanes split K (RCNN_bbox_pred 2048->4,
@@ -1200,14 +1253,23 @@ int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
   const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds_c > lds && !FUSE) lds = lds_c;
   if (FUSE && lds < (size_t)4 * 3 * BM * 16 * 2) lds = (size_t)4 * 3 * BM * 16 * 2;  // the tile as four K-steps of A
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE, FUSE>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-  igemm_split_kernel<BM, BN, STEM, BPRE, FUSE><<<grid, 256, lds, s>>>(p);
+  static bool attr_set = false;
+  if constexpr (BM * BN >= 128 * 128) {
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)igemm_split_kernel_128<STEM, BPRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      attr_set = true;
+    }
+    igemm_split_kernel_128<STEM, BPRE><<<grid, 256, lds, s>>>(p);
+  } else {
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE, FUSE>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    igemm_split_kernel<BM, BN, STEM, BPRE, FUSE><<<grid, 256, lds, s>>>(p);
+  }
   return 0;
 }
 

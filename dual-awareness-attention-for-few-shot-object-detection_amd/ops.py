@@ -1248,6 +1248,15 @@ def colsum(x, rows, channels, ld=0, out=None, alpha=1.0):
     return out
 
 
+def colsum_batched(x, batch, rows, channels, out, ld=0, x_batch=0, out_batch=0, alpha=1.0, accumulate=True):
+    """out[z*out_batch + c] (+)= alpha * sum_r x[z*x_batch + r*ld + c], every z in one launch pair"""
+    _chk(x, "x")
+    ws = _ws(batch * lib().query("dana_colsum_workspace_bytes", rows, channels), x.device)
+    lib().call("dana_colsum_batched", _p(x), _p(out), batch, rows, channels, ld, x_batch or rows * (ld or channels),
+               out_batch or channels, float(alpha), int(accumulate), _p(ws), ws.numel(), _stream())
+    return out
+
+
 def avgpool_backward(grad_out, B, H, W, C, k, stride):
     _chk(grad_out, "grad_out")
     gin = torch.empty((B, H * W, C), dtype=torch.float32, device=grad_out.device)

@@ -426,6 +426,10 @@ int dana_colsum(const float* x, float* out, long rows, int channels, long ld, fl
                 void* workspace, size_t workspace_bytes, dana_stream_t stream);   /* bias gradients, deterministic */
 int dana_avgpool_backward_nhwc(const float* grad_out, float* grad_in, int batch, int height, int width, int channels,
                                int k, int stride, dana_stream_t stream);
+/* dana_colsum over `batch` matrices in one launch pair: matrix z at x + z * x_batch, its sums at out + z * out_batch
+ * (the unary-term adjoint of the attention, one matrix per image: dana.py:132-137); workspace = batch x the single one */
+int dana_colsum_batched(const float* x, float* out, int batch, long rows, int channels, long ld, long x_batch, long out_batch,
+                        float alpha, int accumulate, void* workspace, size_t workspace_bytes, dana_stream_t stream);
 int dana_softmax_rows_backward(float* grad, const float* prob, long rows, int length, long ld_grad, long ld_prob,
                                dana_stream_t stream);            /* grad <- p * (grad - <p, grad>) */
 int dana_gemm_small(const float* a, long a_stride_m, long a_stride_k, const float* b, long b_stride_k, long b_stride_n,
