@@ -17,6 +17,7 @@ from .config import cfg
 
 
 USE_WINOGRAD_WGRAD = __import__("os").environ.get("DANA_WINO_WGRAD", "1") != "0"
+GATHER_STRIDED_WGRAD = __import__("os").environ.get("DANA_WGRAD_GATHER", "1") != "0"
 
 
 class WeightGrads:
@@ -34,6 +35,7 @@ class WeightGrads:
         # of the backward from the caller's): every side stream forks from and joins into exactly one parent, and the
         # two families of launches no longer queue behind each other.
         self.side = {}    # caller stream handle -> [side stream, operands kept alive while its launches are in flight]
+        self.compact = {}  # gathered input rows of strided 1x1 convs (shared by a block's conv1 and downsample conv)
 
     def _side_for_current(self):
         cur = torch.cuda.current_stream()
@@ -75,6 +77,15 @@ class WeightGrads:
 
     def _launch(self, key, g, x, n, h, w, c, in_stride, grad_stride):
         view = self._direct_view(key)
+        if c["k"] == 1 and c["stride"] > 1 and c["pad"] == 0 and GATHER_STRIDED_WGRAD:
+            # a strided 1x1 conv (first block of layer2-4: conv1 and the downsample conv read the same pixels): gather those
+            # pixels once into plain rows -- both weight gradients then run on the software-pipelined plain-row kernel
+            ck = (x.data_ptr(), n, h, w, c["cin"], c["stride"], in_stride, torch.cuda.current_stream().cuda_stream)
+            ent = self.compact.get(ck)
+            if ent is None:
+                ent = self.compact[ck] = (ops.downsample_gather(x, n, h, w, c["cin"], c["stride"], in_stride), x)
+            (x, h, w), in_stride = ent[0], 0
+            c = dict(c, stride=1)
         u = c.get("u")
         if u is not None and u.size(0) == 36 and c["cin"] % 64 == 0 and USE_WINOGRAD_WGRAD:
             # the conv ran in the F(4x4,3x3) domain forward: so does its weight gradient (4x fewer multiplies)
@@ -100,6 +111,7 @@ class WeightGrads:
     def join(self):
         """the caller's stream waits for every weight-gradient launch issued so far"""
         if self.stream is None:
+            self.compact.clear()
             return
         cur = torch.cuda.current_stream()
         for st, keep in self.side.values():
@@ -108,6 +120,7 @@ class WeightGrads:
                 done.record(st)
                 cur.wait_event(done)
                 del keep[:]
+        self.compact.clear()
 
     def finish_conv(self, key, c, param):
         """apply the frozen-BN scale to the rows and add into param.grad (OIHW)"""

@@ -724,6 +724,19 @@ upsample_scatter_kernel(const float4* __restrict__ compact, float4* __restrict__
   out[o] = v;
 }
 
+// the input pixels a strided 1x1 conv reads, as plain rows: compact[b][oh][ow][:] = x[b][oh*s][ow*s][:]
+__global__ void __launch_bounds__(256)
+downsample_gather_kernel(const float* __restrict__ x, float4* __restrict__ compact, int OH, int OW, int IH, int IW, int C4,
+                         int stride, long ldx, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C4);
+  const int ow = (int)((i / C4) % OW);
+  const int oh = (int)((i / C4 / OW) % OH);
+  const long b = i / C4 / OW / OH;
+  compact[i] = *(const float4*)(x + ((b * IH + (long)oh * stride) * IW + (long)ow * stride) * ldx + c * 4);
+}
+
 // tile edge (64 or 128) and pixel split of one weight-gradient launch
 struct WgradShape {
   int tile, tn, tk, S;
@@ -1024,6 +1037,26 @@ int dana_upsample_scatter_nhwc(const float* compact, float* out, const float* ma
                                                                     (const float4*)mask_act, oh, ow, ih, iw,
                                                                     channels / 4, stride, total);
   DANA_CHECK_LAUNCH("dana_upsample_scatter_nhwc");
+  return DANA_OK;
+}
+
+/* compact[b][oh][ow][channels] = x[b][oh*stride][ow*stride][0..channels) (x pixel stride in_pix_stride, 0 = channels): the
+ * rows a strided 1x1 conv reads (resnet.py:71, the first block of layer2-4), so that its weight gradient is a plain-row
+ * contraction (the software-pipelined kernel) and the block's two strided convs share one copy. */
+int dana_downsample_gather_nhwc(const float* x, float* compact, int batch, int ih, int iw, int channels, int stride,
+                                long in_pix_stride, dana_stream_t stream) {
+  DANA_CHECK_ARG(batch >= 0 && ih > 0 && iw > 0 && channels > 0 && channels % 4 == 0 && stride > 0,
+                 "dana_downsample_gather_nhwc: bad shape");
+  if (batch == 0) return DANA_OK;
+  DANA_CHECK_ARG(x && compact, "dana_downsample_gather_nhwc: null pointer");
+  const long ldx = in_pix_stride > 0 ? in_pix_stride : channels;
+  DANA_CHECK_ARG(ldx % 4 == 0 && ldx >= channels && (((uintptr_t)x | (uintptr_t)compact) & 15) == 0,
+                 "dana_downsample_gather_nhwc: rows must be 16-byte aligned");
+  const int oh = (ih - 1) / stride + 1, ow = (iw - 1) / stride + 1;
+  const long total = (long)batch * oh * ow * (channels / 4);
+  downsample_gather_kernel<<<dana_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(x, (float4*)compact, oh, ow, ih, iw,
+                                                                                        channels / 4, stride, ldx, total);
+  DANA_CHECK_LAUNCH("dana_downsample_gather_nhwc");
   return DANA_OK;
 }
 

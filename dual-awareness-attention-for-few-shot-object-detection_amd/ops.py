@@ -1157,6 +1157,15 @@ def gemm_tn_batched(y, x, planes, m, n, k, out, ldy=0, ldx=0, batch_y=0, batch_x
     return out
 
 
+def downsample_gather(x, batch, ih, iw, channels, stride, in_stride=0):
+    """[batch*oh*ow][channels] rows of the pixels a strided 1x1 conv reads"""
+    _chk(x, "x")
+    oh, ow = (ih - 1) // stride + 1, (iw - 1) // stride + 1
+    out = torch.empty((batch * oh * ow, channels), dtype=torch.float32, device=x.device)
+    lib().call("dana_downsample_gather_nhwc", _p(x), _p(out), batch, ih, iw, channels, stride, in_stride, _stream())
+    return out, oh, ow
+
+
 def conv3x3_wgrad_winograd(grad_out, x, batch, h, w, cin, cout, in_stride=0, grad_stride=0, out=None, row_scale=None):
     """conv2d_wgrad of a stride-1 pad-1 3x3 conv through the F(4x4,3x3) domain (4x fewer multiplies)"""
     _chk(grad_out, "grad_out")

@@ -413,6 +413,11 @@ int dana_conv2d_dgrad_weight(const float* w_packed, const float* scale, float* o
 int dana_upsample_scatter_nhwc(const float* compact, float* out, const float* mask_act, int batch, int oh, int ow,
                                int ih, int iw, int channels, int stride, dana_stream_t stream);
 
+/* the rows a strided 1x1 conv reads (resnet.py:71), compacted: compact[b][oh][ow][:] = x[b][oh*stride][ow*stride][:];
+ * its weight gradient is then dana_conv2d_wgrad_nhwc with stride 1 over [batch][oh][ow] */
+int dana_downsample_gather_nhwc(const float* x, float* compact, int batch, int ih, int iw, int channels, int stride,
+                                long in_pix_stride, dana_stream_t stream);
+
 /* element-wise / reduction glue of the backward pass */
 int dana_relu_mask(float* grad, const float* act, long rows, int channels, long ld_grad, long ld_act,
                    dana_stream_t stream);                       /* grad *= (saved output > 0) */
