@@ -568,3 +568,44 @@ def test_two_stream_trunk_in_shared_buffers_does_not_race_on_recycled_blocks(dev
                 if torch.is_tensor(a):
                     assert torch.equal(a, b), layer
     m._debug_stall = None
+
+
+def test_batched_tn_gemm_and_column_sums_vs_torch(dev):
+    """dana_gemm_tn_batched (the attention's d value / d key adjoints, one plane per image: out[z][r][k] += sum_m
+    y[z][m][r] x[z][m][k] for r < n_valid, strided rows, zero-padded y columns computed but not stored) and
+    dana_colsum_batched against fp64 torch; dana_downsample_gather_nhwc + the plain-row weight gradient against the strided
+    weight-gradient kernel."""
+    from dana_amd import ops
+    g = torch.Generator().manual_seed(123)
+    for (planes, m, n, nv, k, ldy, ldx, gap) in [(4, 2394, 1200, 1200, 256, 1200, 256, 0), (3, 700, 160, 147, 1024, 160, 2048, 512),
+                                                 (2, 130, 64, 61, 64, 72, 64, 64)]:
+        y = torch.randn(planes, m, ldy, generator=g).to(dev)
+        y[:, :, nv:] = 0
+        x = torch.randn(planes, m, ldx, generator=g).to(dev)
+        bo = nv * k + gap
+        out = torch.randn(planes * bo + 8, generator=g).to(dev)
+        ref = out.double().clone()
+        for z in range(planes):
+            ref[z * bo:z * bo + nv * k] += (y[z, :, :nv].double().t() @ x[z, :, :k].double()).reshape(-1)
+        ops.gemm_tn_batched(y, x, planes, m, n, k, out, ldy=ldy, ldx=ldx, batch_y=m * ldy, batch_x=m * ldx, batch_out=bo, n_valid=nv)
+        err = float((out.double() - ref).abs().max())
+        assert err <= 2e-5 * float(ref.abs().max()) * (m ** 0.5) / 30 + 1e-4, (planes, m, n, k, err)
+        # (the gaps between the planes' results and the tail stay untouched)
+        for z in range(planes):
+            assert torch.equal(out[z * bo + nv * k:(z + 1) * bo].double(), ref[z * bo + nv * k:(z + 1) * bo])
+    xs = torch.randn(5, 300, 168, generator=g).to(dev)
+    o = torch.ones(5 * 200, device=dev)
+    ops.colsum_batched(xs, 5, 300, 147, o, ld=168, x_batch=300 * 168, out_batch=200, alpha=0.25)
+    want = torch.ones(5, 200, dtype=torch.double)
+    want[:, :147] += 0.25 * xs[:, :, :147].double().sum(1).cpu()
+    assert float((o.view(5, 200).cpu().double() - want).abs().max()) <= 1e-4
+    # strided 1x1 weight gradient: gathered rows + plain kernel == the strided kernel
+    n_, h, w, ci, co, ld = 2, 19, 23, 256, 128, 320
+    x = torch.randn(n_ * h * w, ld, generator=g).to(dev)
+    xc, oh, ow = ops.downsample_gather(x, n_, h, w, ci, 2, in_stride=ld)
+    want = x.view(n_, h, w, ld)[:, ::2, ::2, :ci].reshape(-1, ci)
+    assert (oh, ow) == (10, 12) and torch.equal(xc, want)
+    gy = torch.randn(n_ * oh * ow, co, generator=g).to(dev)
+    a = ops.conv2d_wgrad(gy, x, n_, h, w, ci, co, 1, 1, 2, 0, in_stride=ld)
+    b = ops.conv2d_wgrad(gy, xc, n_, oh, ow, ci, co, 1, 1, 1, 0)
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
