@@ -17,6 +17,7 @@ from .config import cfg
 
 
 USE_WINOGRAD_WGRAD = __import__("os").environ.get("DANA_WINO_WGRAD", "1") != "0"
+SAVED_WINOGRAD_V = __import__("os").environ.get("DANA_WGRAD_SAVED_V", "1") != "0"  # weight gradients reuse the forward's V planes
 GATHER_STRIDED_WGRAD = __import__("os").environ.get("DANA_WGRAD_GATHER", "1") != "0"
 
 
@@ -62,20 +63,21 @@ class WeightGrads:
         self.direct[key] = v
         return v
 
-    def add_conv(self, key, g, x, n, h, w, c, in_stride=0, grad_stride=0):
+    def add_conv(self, key, g, x, n, h, w, c, in_stride=0, grad_stride=0, v=None):
+        """v: the forward launch's kept Winograd workspace (V planes of x), if that conv ran in the F(4x4,3x3) domain"""
         self.convs[key] = c
         if self.stream is None:
-            self._launch(key, g, x, n, h, w, c, in_stride, grad_stride)
+            self._launch(key, g, x, n, h, w, c, in_stride, grad_stride, v)
             return
         st, keep = self._side_for_current()
         ready = torch.cuda.Event()
         ready.record()
         st.wait_event(ready)
-        keep.append((g, x))
+        keep.append((g, x, v))
         with torch.cuda.stream(st):
-            self._launch(key, g, x, n, h, w, c, in_stride, grad_stride)
+            self._launch(key, g, x, n, h, w, c, in_stride, grad_stride, v)
 
-    def _launch(self, key, g, x, n, h, w, c, in_stride, grad_stride):
+    def _launch(self, key, g, x, n, h, w, c, in_stride, grad_stride, v=None):
         view = self._direct_view(key)
         if c["k"] == 1 and c["stride"] > 1 and c["pad"] == 0 and GATHER_STRIDED_WGRAD:
             # a strided 1x1 conv (first block of layer2-4: conv1 and the downsample conv read the same pixels): gather those
@@ -92,7 +94,8 @@ class WeightGrads:
             out = view if view is not None else self.packed.get(key)
             res = ops.conv3x3_wgrad_winograd(g, x, n, h, w, c["cin"], c["cout"], in_stride=in_stride,
                                              grad_stride=grad_stride, out=out,
-                                             row_scale=c.get("scale") if view is not None else None)
+                                             row_scale=c.get("scale") if view is not None else None,
+                                             v=v if SAVED_WINOGRAD_V else None)
             if out is None:
                 self.packed[key] = res
             return
@@ -178,7 +181,7 @@ def bottleneck_backward(g, saved, n, h, w, bp, grads, key, need_dx=True, mask_dx
     x = saved["x"]
     grads.add_conv(key + ".conv3", g, saved["o2"], n, h1, w1, bp["c3"])
     g2 = conv_dgrad(g, n, h1, w1, bp["c3"], mask=saved["o2"])
-    grads.add_conv(key + ".conv2", g2, saved["o1"], n, h1, w1, bp["c2"])
+    grads.add_conv(key + ".conv2", g2, saved["o1"], n, h1, w1, bp["c2"], v=saved.get("v2"))
     g1 = conv_dgrad(g2, n, h1, w1, bp["c2"], mask=saved["o1"])
     grads.add_conv(key + ".conv1", g1, x, n, h, w, bp["c1"])
     if bp["ds"] is not None:
@@ -209,7 +212,7 @@ def bottleneck_backward_merged(g, sq, ss, sm, bp, grads, key):
     g2 = conv_dgrad(g, 1, mt, 1, c3, mask=sm["o2"])
     g1 = torch.empty((mt, c2["cin"]), dtype=torch.float32, device=g.device)
     for part, s_ in ((slice(0, mq), sq), (slice(mq, mt), ss)):
-        grads.add_conv(key + ".conv2", g2[part], sm["o1"][part], s_["n"], s_["h1"], s_["w1"], c2)
+        grads.add_conv(key + ".conv2", g2[part], sm["o1"][part], s_["n"], s_["h1"], s_["w1"], c2, v=s_.get("v2"))
         conv_dgrad(g2[part], s_["n"], s_["h1"], s_["w1"], c2, mask=sm["o1"][part], out=g1[part])
     grads.add_conv(key + ".conv1", g1, sm["x"], 1, mt, 1, c1)
     return conv_dgrad(g1, 1, mt, 1, c1, residual=g, mask=sm["x"])
@@ -460,7 +463,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     _acc(rpn.RPN_bbox_pred.bias, dbh[ns:])
     ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
     c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None, u=plan["rpn_conv_u"])
-    grads.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn)
+    grads.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn, v=ctx.get("rpn_v"))
     _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
     d_corr = conv_dgrad(d_x, B, fh, fw, c_rpn)  # [B*hw][2048]
 

@@ -478,13 +478,38 @@ size_t dana_conv3x3_wgrad_winograd4_workspace_bytes(int batch, int h, int w, int
   return p.total + du + dana_align_up(dana_wgrad_tn_batched_workspace(36, (int)p.tiles, cout, cin), 256);
 }
 
+static int wgrad_winograd4_impl(const float* grad_out, const float* input, const float* v_saved, float* grad_weight,
+                                int batch, int h, int w, int cin, int cout, long in_pix_stride, long grad_pix_stride,
+                                const float* row_scale, int accumulate, void* workspace, size_t workspace_bytes,
+                                dana_stream_t stream);
+
 int dana_conv3x3_wgrad_winograd4(const float* grad_out, const float* input, float* grad_weight, int batch, int h, int w,
                                  int cin, int cout, long in_pix_stride, long grad_pix_stride, const float* row_scale,
                                  int accumulate, void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(input || batch == 0, "dana_conv3x3_wgrad_winograd4: null pointer");
+  return wgrad_winograd4_impl(grad_out, input, nullptr, grad_weight, batch, h, w, cin, cout, in_pix_stride, grad_pix_stride,
+                              row_scale, accumulate, workspace, workspace_bytes, stream);
+}
+
+/* the same with the input's transform handed in: v = the V planes [36][tiles][cin] the forward's
+ * dana_conv3x3_winograd4_nhwc left at the start of ITS workspace (kept by the caller) -- no second input transform */
+int dana_conv3x3_wgrad_winograd4_v(const float* grad_out, const float* v, float* grad_weight, int batch, int h, int w,
+                                   int cin, int cout, long grad_pix_stride, const float* row_scale, int accumulate,
+                                   void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(v || batch == 0, "dana_conv3x3_wgrad_winograd4_v: null pointer");
+  DANA_CHECK_ARG(((uintptr_t)v & 15) == 0, "dana_conv3x3_wgrad_winograd4_v: v must be 16-byte aligned");
+  return wgrad_winograd4_impl(grad_out, nullptr, v, grad_weight, batch, h, w, cin, cout, 0, grad_pix_stride, row_scale,
+                              accumulate, workspace, workspace_bytes, stream);
+}
+
+static int wgrad_winograd4_impl(const float* grad_out, const float* input, const float* v_saved, float* grad_weight,
+                                int batch, int h, int w, int cin, int cout, long in_pix_stride, long grad_pix_stride,
+                                const float* row_scale, int accumulate, void* workspace, size_t workspace_bytes,
+                                dana_stream_t stream) {
   DANA_CHECK_ARG(batch >= 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 64 == 0 && cout % 4 == 0,
                  "dana_conv3x3_wgrad_winograd4: bad shape (cin %% 64, cout %% 4)");
   if (batch == 0) return DANA_OK;
-  DANA_CHECK_ARG(grad_out && input && grad_weight, "dana_conv3x3_wgrad_winograd4: null pointer");
+  DANA_CHECK_ARG(grad_out && (input || v_saved) && grad_weight, "dana_conv3x3_wgrad_winograd4: null pointer");
   const long lda = in_pix_stride > 0 ? in_pix_stride : cin;
   const long ldy = grad_pix_stride > 0 ? grad_pix_stride : cout;
   DANA_CHECK_ARG(lda % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)input & 15) == 0 && ((uintptr_t)grad_out & 15) == 0,
@@ -498,16 +523,18 @@ int dana_conv3x3_wgrad_winograd4(const float* grad_out, const float* input, floa
   }
   const WinoPlan p = wino_plan(batch, h, w, cin, cout, 4);
   hipStream_t s = (hipStream_t)stream;
-  float* V = (float*)workspace;                            // [36][tiles][cin]
+  const float* V = v_saved ? v_saved : (const float*)workspace;  // [36][tiles][cin]
   float* dM = (float*)((char*)workspace + p.v_bytes);      // [36][tiles][cout]
   float* dU = (float*)((char*)workspace + p.total);        // [36][cout][cin]
   const size_t du = dana_align_up((size_t)36 * cout * cin * 4, 256);
   void* gws = (char*)workspace + p.total + du;
   const int C4 = cin / 4, N4 = cout / 4;
   DANA_CHECK_ARG(p.tiles * (long)(C4 > N4 ? C4 : N4) < (1L << 31), "dana_conv3x3_wgrad_winograd4: too many tiles x channels");
-  wino4_input_kernel<<<dana_ceil_div(p.tiles * C4, 256), 256, 0, s>>>(input, V, h, w, C4, p.th, p.tw, p.tiles, (int)lda,
-                                                                     (unsigned)in_bytes);
-  DANA_CHECK_LAUNCH("dana_conv3x3_wgrad_winograd4(input transform)");
+  if (!v_saved) {
+    wino4_input_kernel<<<dana_ceil_div(p.tiles * C4, 256), 256, 0, s>>>(input, (float*)workspace, h, w, C4, p.th, p.tw, p.tiles,
+                                                                       (int)lda, (unsigned)in_bytes);
+    DANA_CHECK_LAUNCH("dana_conv3x3_wgrad_winograd4(input transform)");
+  }
   wino4_outgrad_kernel<<<dana_ceil_div(p.tiles * N4, 256), 256, 0, s>>>(grad_out, dM, h, w, N4, p.th, p.tw, p.tiles, ldy);
   DANA_CHECK_LAUNCH("dana_conv3x3_wgrad_winograd4(output-gradient transform)");
   int rc = dana_wgrad_tn_batched(dM, V, dU, 36, (int)p.tiles, cout, cin, p.tiles * cout, p.tiles * cin, gws,

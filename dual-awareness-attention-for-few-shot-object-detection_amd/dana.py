@@ -411,10 +411,11 @@ class DAnARCNN(nn.Module):
 
     # ---- trunk -----------------------------------------------------------------------------------
     @staticmethod
-    def _conv(x, n, h, w, c, relu, residual=None, res_stride=0, out=None, out_stride=0, in_stride=0):
+    def _conv(x, n, h, w, c, relu, residual=None, res_stride=0, out=None, out_stride=0, in_stride=0, keep_v=None):
         if c.get("u") is not None and residual is None:
             return ops.conv3x3_winograd(x, n, h, w, c["cin"], c.get("us") or c["u"], c["cout"], scale=c["scale"],
-                                        shift=c["shift"], relu=relu, in_stride=in_stride, out=out, out_stride=out_stride)
+                                        shift=c["shift"], relu=relu, in_stride=in_stride, out=out, out_stride=out_stride,
+                                        keep_v=keep_v)
         return ops.conv2d_nhwc(x, n, h, w, c["cin"], c.get("ws") or c["w"], c["cout"], c["k"], c["k"], c["stride"], c["pad"],
                                scale=c["scale"], shift=c["shift"], residual=residual, relu=relu,
                                in_stride=in_stride, out=out, out_stride=out_stride, res_stride=res_stride)
@@ -429,14 +430,16 @@ class DAnARCNN(nn.Module):
             return ops.bottleneck_tail(o1, n, h1, w1, c2["cin"], c2["ws"], c2["scale"], c2["shift"], c3["ws"], c3["scale"],
                                        c3["shift"], c3["cout"], residual=x, res_stride=in_stride, out=out,
                                        out_stride=out_stride)
-        o2, _, _ = self._conv(o1, n, h1, w1, bp["c2"], True)
+        kv = [] if save is not None else None  # conv2's Winograd-domain input (V planes) for its weight gradient
+        o2, _, _ = self._conv(o1, n, h1, w1, bp["c2"], True, keep_v=kv)
+        v2 = kv[0] if kv else None
         if bp.get("cat") is not None and getattr(self, "fuse_downsample", True) and ops.get_mfma_mode() != 0:
             c3, ds = bp["c3"], bp["ds"]
             o3, _, _ = ops.conv1x1_cat2(o2, c3["cin"], x, ds["cin"], n, h, w, ds["stride"], bp["cat"].get("ws") or bp["cat"]["w"],
                                         bp["cat"]["shift"], c3["cout"], relu=True, a1_stride=in_stride, out=out,
                                         out_stride=out_stride)
             if save is not None:
-                save.append(dict(x=x, o1=o1, o2=o2, o3=o3, h1=h1, w1=w1, n=n, h=h, w=w, bp=bp, key=key, o3_ld=out_stride))
+                save.append(dict(x=x, o1=o1, o2=o2, o3=o3, h1=h1, w1=w1, n=n, h=h, w=w, bp=bp, key=key, o3_ld=out_stride, v2=v2))
             return o3, h1, w1
         if bp["ds"] is not None:
             res, _, _ = self._conv(x, n, h, w, bp["ds"], False, in_stride=in_stride)
@@ -446,7 +449,7 @@ class DAnARCNN(nn.Module):
         o3, _, _ = self._conv(o2, n, h1, w1, bp["c3"], True, residual=res, res_stride=rs, out=out,
                               out_stride=out_stride)
         if save is not None:
-            save.append(dict(x=x, o1=o1, o2=o2, o3=o3, h1=h1, w1=w1, n=n, h=h, w=w, bp=bp, key=key, o3_ld=out_stride))
+            save.append(dict(x=x, o1=o1, o2=o2, o3=o3, h1=h1, w1=w1, n=n, h=h, w=w, bp=bp, key=key, o3_ld=out_stride, v2=v2))
         return o3, h1, w1
 
     def _rcnn_base(self, im, plan, out_stride=0, out_buf=None, save=None):
@@ -555,7 +558,7 @@ class DAnARCNN(nn.Module):
         split = ops.get_mfma_mode() != 0
         fuse_ds = getattr(self, "fuse_downsample", True) and split
 
-        def conv(xin, gi0, gi1, c, relu, res=None, out0=None, out1=None, s0=0, s1=0):
+        def conv(xin, gi0, gi1, c, relu, res=None, out0=None, out1=None, s0=0, s1=0, keep=None):
             """one conv over both batches -> (merged output or out0, (oh0, ow0), (oh1, ow1))"""
             st_, k_, pd = c["stride"], c["k"], c["pad"]
             h0 = ((gi0[0] + 2 * pd - k_) // st_ + 1, (gi0[1] + 2 * pd - k_) // st_ + 1)
@@ -573,7 +576,8 @@ class DAnARCNN(nn.Module):
                     with (on_sup() if grp else torch.cuda.stream(main)):
                         if wino:
                             ops.conv3x3_winograd(xi, n_, gi[0], gi[1], c["cin"], c.get("us") or c["u"], c["cout"],
-                                                 scale=c["scale"], shift=c["shift"], relu=relu, out=oo, out_stride=so)
+                                                 scale=c["scale"], shift=c["shift"], relu=relu, out=oo, out_stride=so,
+                                                 keep_v=keep[grp] if keep is not None else None)
                         else:
                             ops.conv2d_nhwc(xi, n_, gi[0], gi[1], c["cin"], c.get("ws") or c["w"], c["cout"], k_, k_, st_, pd,
                                             scale=c["scale"], shift=c["shift"], residual=rr, relu=relu, out=oo, out_stride=so)
@@ -612,7 +616,8 @@ class DAnARCNN(nn.Module):
                                                 out_stride=c3["cout"], res_stride=c3["cout"])
                     x, g0, g1 = o3, h0, h1
                     continue
-                o2, _, _ = conv(o1, h0, h1, bp["c2"], True)
+                kv = ([], []) if (li > 0 and save_q is not None) else None  # conv2's V planes, per batch, for its weight gradient
+                o2, _, _ = conv(o1, h0, h1, bp["c2"], True, keep=kv)
                 m0o, mi = n0 * h0[0] * h0[1], n0 * g0[0] * g0[1]
                 out0 = out1 = None
                 s0 = s1 = 0
@@ -640,9 +645,11 @@ class DAnARCNN(nn.Module):
                 if li > 0 and save_q is not None:  # (layer1 is frozen: nothing to differentiate there)
                     key = "RCNN_base.%d.%d" % (4 + li, bi)
                     save_q.append(dict(x=x[:mi], o1=o1[:m0o], o2=o2[:m0o], o3=corr if last else o3[:m0o], h1=h0[0], w1=h0[1],
-                                       n=n0, h=g0[0], w=g0[1], bp=bp, key=key, o3_ld=s0))
+                                       n=n0, h=g0[0], w=g0[1], bp=bp, key=key, o3_ld=s0,
+                                       v2=kv[0][0] if kv and kv[0] else None))
                     save_s.append(dict(x=x[mi:], o1=o1[m0o:], o2=o2[m0o:], o3=sup if last else o3[m0o:], h1=h1[0], w1=h1[1],
-                                       n=n1, h=g1[0], w=g1[1], bp=bp, key=key, o3_ld=s1 if last else 0))
+                                       n=n1, h=g1[0], w=g1[1], bp=bp, key=key, o3_ld=s1 if last else 0,
+                                       v2=kv[1][0] if kv and kv[1] else None))
                     if save_m is not None:  # the [query | support] buffers themselves: backward.bottleneck_backward_merged
                         save_m.append(dict(x=x, o1=o1, o2=o2, o3=None if last else o3, mq_in=mi, mq_out=m0o,
                                            m_in=x.size(0), m_out=o1.size(0)))
@@ -861,8 +868,11 @@ class DAnARCNN(nn.Module):
         # -- RPN head + proposals (rpn.py:58-78, proposal_layer.py:49-190) --
         rpn = self.RCNN_rpn
         if plan["rpn_conv_u"] is not None:
+            kv = [] if ctx is not None else None
             x, _, _ = ops.conv3x3_winograd(corr, B, fh, fw, 2048, plan["rpn_conv_b3"] or plan["rpn_conv_u"], 512,
-                                           shift=plan["rpn_conv_b"], relu=True)
+                                           shift=plan["rpn_conv_b"], relu=True, keep_v=kv)
+            if kv:
+                ctx["rpn_v"] = kv[0]  # the input's Winograd transform: the weight gradient does not repeat it
         else:
             x, _, _ = ops.conv2d_nhwc(corr, B, fh, fw, 2048, plan["rpn_conv_b3"] or plan["rpn_conv_w"], 512, 3, 3, 1, 1,
                                       shift=plan["rpn_conv_b"], relu=True)

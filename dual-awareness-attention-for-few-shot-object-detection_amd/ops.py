@@ -786,8 +786,10 @@ def winograd_filter_transform(w_packed, cout, cin, tile=2):
 
 
 def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=False, in_stride=0, out=None,
-                     out_stride=0, mask=None, mask_stride=0):
-    """stride-1 pad-1 3x3 conv through Winograd F(2x2,3x3) or F(4x4,3x3), chosen by u (winograd_filter_transform)."""
+                     out_stride=0, mask=None, mask_stride=0, keep_v=None):
+    """stride-1 pad-1 3x3 conv through Winograd F(2x2,3x3) or F(4x4,3x3), chosen by u (winograd_filter_transform).
+    keep_v: a list that receives the launch's workspace (F(4x4) only): its first 36*tiles*cin floats are the input's
+    transform V, which conv3x3_wgrad_winograd(v=...) takes instead of transforming the input again."""
     _chk(x, "x")
     up, wfl = _wf(u)
     if out is None:
@@ -802,6 +804,8 @@ def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=
     lib().call("dana_conv3x3_winograd%s_nhwc_masked" % sfx, _p(x), up, _p(out), _p(scale), _p(shift), _p(mask), batch,
                h, w, cin, cout, in_stride, out_stride, mask_stride, (EPI_RELU if relu else 0) | wfl, _p(ws), ws.numel(),
                _stream())
+    if keep_v is not None and m == 4:
+        keep_v.append(ws)
     _prof_end(e0, ("wino3x3 M=%d N=%d K=%d s1", (batch * h * w, cout, 9 * cin)), 2.0 * batch * h * w * cout * 9 * cin,
               # bytes of the batched GEMM launch itself: V[planes][tiles][cin], U[planes][cout][cin], M[planes][tiles][cout]
               4.0 * (m + 2) * (m + 2) * (batch * ((h + m - 1) // m) * ((w + m - 1) // m) * (cin + cout) + cout * cin),
@@ -1166,8 +1170,9 @@ def downsample_gather(x, batch, ih, iw, channels, stride, in_stride=0):
     return out, oh, ow
 
 
-def conv3x3_wgrad_winograd(grad_out, x, batch, h, w, cin, cout, in_stride=0, grad_stride=0, out=None, row_scale=None):
-    """conv2d_wgrad of a stride-1 pad-1 3x3 conv through the F(4x4,3x3) domain (4x fewer multiplies)"""
+def conv3x3_wgrad_winograd(grad_out, x, batch, h, w, cin, cout, in_stride=0, grad_stride=0, out=None, row_scale=None, v=None):
+    """conv2d_wgrad of a stride-1 pad-1 3x3 conv through the F(4x4,3x3) domain (4x fewer multiplies). v: the forward
+    launch's kept workspace (conv3x3_winograd(keep_v=...)): its V planes replace the input transform of x."""
     _chk(grad_out, "grad_out")
     _chk(x, "x")
     accumulate = out is not None
@@ -1175,8 +1180,12 @@ def conv3x3_wgrad_winograd(grad_out, x, batch, h, w, cin, cout, in_stride=0, gra
         out = torch.empty((cout, 9 * cin), dtype=torch.float32, device=x.device)
     ws = _ws(lib().query("dana_conv3x3_wgrad_winograd4_workspace_bytes", batch, h, w, cin, cout), x.device)
     e0 = _prof_begin()
-    lib().call("dana_conv3x3_wgrad_winograd4", _p(grad_out), _p(x), _p(out), batch, h, w, cin, cout, in_stride,
-               grad_stride, _p(row_scale), int(accumulate), _p(ws), ws.numel(), _stream())
+    if v is not None:
+        lib().call("dana_conv3x3_wgrad_winograd4_v", _p(grad_out), _p(v), _p(out), batch, h, w, cin, cout, grad_stride,
+                   _p(row_scale), int(accumulate), _p(ws), ws.numel(), _stream())
+    else:
+        lib().call("dana_conv3x3_wgrad_winograd4", _p(grad_out), _p(x), _p(out), batch, h, w, cin, cout, in_stride,
+                   grad_stride, _p(row_scale), int(accumulate), _p(ws), ws.numel(), _stream())
     _prof_end(e0, ("wgradwino M=%d N=%d K=%d", (batch * h * w, cout, 9 * cin)), 2.0 * batch * h * w * cout * 9 * cin)
     return out
 

@@ -220,6 +220,13 @@ size_t dana_conv3x3_wgrad_winograd4_workspace_bytes(int batch, int h, int w, int
 int dana_conv3x3_wgrad_winograd4(const float* grad_out, const float* input, float* grad_weight, int batch, int h, int w,
                                  int cin, int cout, long in_pix_stride, long grad_pix_stride, const float* row_scale,
                                  int accumulate, void* workspace, size_t workspace_bytes, dana_stream_t stream);
+/* ... with the input's transform handed in: v = the V planes [36][tiles][cin] that the forward's
+ * dana_conv3x3_winograd4_nhwc(_masked) call over the same input left in the FIRST 36*tiles*cin floats of its workspace
+ * (the caller keeps that buffer until the backward) -- the weight gradient skips its own input transform. Same workspace
+ * size as dana_conv3x3_wgrad_winograd4. */
+int dana_conv3x3_wgrad_winograd4_v(const float* grad_out, const float* v, float* grad_weight, int batch, int h, int w,
+                                   int cin, int cout, long grad_pix_stride, const float* row_scale, int accumulate,
+                                   void* workspace, size_t workspace_bytes, dana_stream_t stream);
 
 /* nn.Linear / torch.bmm (dana.py:124,140,142,147,266-290): c[z][m][n] = epi(alpha * sum_k a[z][m][k]*b[z][n][k]).
  * Both operands K-contiguous ("NT"); nn.Linear weights [out][in] are used as stored. k % 4 == 0. */
