@@ -225,12 +225,15 @@ def _block_convs(prefix, bp):
     return names
 
 
-def grad_stages(model):
+def grad_stages(model, plan=None):
     """[(stage, [parameter names])] in the order model_backward FINISHES the gradients: the trainer lays its flat
-    gradient buffer out in this order so that all-reduce buckets can leave while the rest of the backward runs."""
+    gradient buffer out in this order so that all-reduce buckets can leave while the rest of the backward runs.
+    plan: the forward's plan (the backward passes the one its context saved: asking the model for a plan INSIDE the
+    backward -- autograd runs it with gradients disabled, i.e. not `_live()` -- re-derived and pre-split every trainable
+    weight once per iteration for nothing: ~100 small launches at the head of the backward)."""
     if type(model).__name__ in ("FasterRCNN", "MetaRCNN", "FGN", "FSOD"):
-        return frcnn_grad_stages(model)
-    plan = model._get_plan()
+        return frcnn_grad_stages(model, plan)
+    plan = plan if plan is not None else model._get_plan()
     lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
     st = [("box branch", lin("RCNN_bbox_pred") + [n for bi in (2, 1, 0)
                                                  for n in _block_convs("RCNN_top.0.%d" % bi, plan["layer4"][bi])])]
@@ -364,7 +367,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         else model._stream("layer4", dev)
     seeds_ready = torch.cuda.Event()
     seeds_ready.record()
-    stages = grad_stages(model)
+    stages = grad_stages(model, plan)
     with torch.cuda.stream(l4_stream):
         l4_stream.wait_event(seeds_ready)
         wb = model.RCNN_bbox_pred.weight.detach()
@@ -550,8 +553,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
 
 
 # ---- sibling model `frcnn` (lib/model/framework/faster_rcnn.py): the same adjoints without the attention ----------------
-def frcnn_grad_stages(model):
-    plan = model._get_plan()
+def frcnn_grad_stages(model, plan=None):
+    plan = plan if plan is not None else model._get_plan()
     lin = lambda n: [n + ".weight", n + ".bias"]  # noqa: E731
     cls = "RCNN_cls_score.0" if type(model).__name__ == "MetaRCNN" else "RCNN_cls_score"  # meta.py:199-201: a Sequential
     extra = []
@@ -603,7 +606,7 @@ def frcnn_backward(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     fc7 = ctx["fc7"]
     dev = fc7.device
     grads = WeightGrads(None if getattr(model, "_single_stream", False) else model._stream("wgrad", dev), model)
-    stages = frcnn_grad_stages(model)
+    stages = frcnn_grad_stages(model, plan)
     gs = None
     if meta:
         d_pos, d_neg, d_bbox = ctx["loss_seeds"]  # written by the fused mined-loss kernel (dana_rcnn_loss)
