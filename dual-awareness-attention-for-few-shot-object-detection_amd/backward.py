@@ -18,6 +18,7 @@ from .config import cfg
 
 USE_WINOGRAD_WGRAD = __import__("os").environ.get("DANA_WINO_WGRAD", "1") != "0"
 SAVED_WINOGRAD_V = __import__("os").environ.get("DANA_WGRAD_SAVED_V", "1") != "0"  # weight gradients reuse the forward's V planes
+PREFETCH_DGRAD_W = __import__("os").environ.get("DANA_PREFETCH_DGRAD_W", "1") != "0"  # trunk dgrad weights derived on a side stream
 GATHER_STRIDED_WGRAD = __import__("os").environ.get("DANA_WGRAD_GATHER", "1") != "0"
 
 
@@ -349,6 +350,39 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     grads = WeightGrads(None if getattr(model, "_single_stream", False) else model._stream("wgrad", dev), model)
     ug = model.unary_gamma
 
+    # -- the trunk's data-gradient weights (flipped / transposed / BN-scaled copies, Winograd-domain filters: ~45 small
+    #    launches that depend on the weights only) are derived NOW on a stream of their own, under the heads' backward,
+    #    instead of one by one in front of the trunk's data-gradient launches that need them (the chain every other
+    #    launch of the trunk's backward waits for); joined into the caller's stream before the pause below --
+    rpn = model.RCNN_rpn
+    c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None, u=plan["rpn_conv_u"])
+    dgw_ready = l4w_ready = rpnw_ready = None
+    if PREFETCH_DGRAD_W and not getattr(model, "_single_stream", False):
+        prep = model._stream("dgradw", dev)
+        ev0 = torch.cuda.Event()
+        ev0.record()
+        prep.wait_event(ev0)
+        with torch.cuda.stream(prep):
+            seen = set()
+
+            def derive(saved):
+                for sv in reversed(saved):
+                    for name in ("c3", "c2", "c1", "ds"):
+                        c = sv["bp"].get(name)
+                        if c is not None and id(c) not in seen:
+                            seen.add(id(c))
+                            _dgrad_weights(c)
+
+            derive(ctx["l4_saved"])  # (in the order the backward needs them: box branch, RPN conv, trunk)
+            l4w_ready = torch.cuda.Event()
+            l4w_ready.record()
+            _dgrad_weights(c_rpn)
+            rpnw_ready = torch.cuda.Event()
+            rpnw_ready.record()
+            derive(ctx["q_saved"])
+            dgw_ready = torch.cuda.Event()
+            dgw_ready.record()
+
     # -- seeds: d RCNN losses / d (scores, bbox_pred) were written by the fused loss kernel (dana_rcnn_loss);
     #    the upstream scalars g3 / g4 ride as alpha on the first launches that consume them --
     d_score_pos, d_score_neg, d_bbox = ctx["loss_seeds"]
@@ -370,6 +404,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     stages = grad_stages(model, plan)
     with torch.cuda.stream(l4_stream):
         l4_stream.wait_event(seeds_ready)
+        if l4w_ready is not None:
+            l4_stream.wait_event(l4w_ready)
         wb = model.RCNN_bbox_pred.weight.detach()
         _acc(model.RCNN_bbox_pred.weight,
              ops.gemm_small(d_bbox, (1, 4), ctx["fc7"], (2048, 1), 4, 2048, n_roi, alpha=g4))
@@ -465,7 +501,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     _acc(rpn.RPN_bbox_pred.weight, dwh[ns:])
     _acc(rpn.RPN_bbox_pred.bias, dbh[ns:])
     ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
-    c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None, u=plan["rpn_conv_u"])
+    if rpnw_ready is not None:
+        torch.cuda.current_stream().wait_event(rpnw_ready)
     grads.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn, v=ctx.get("rpn_v"))
     _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
     d_corr = conv_dgrad(d_x, B, fh, fw, c_rpn)  # [B*hw][2048]
@@ -511,6 +548,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         ops.axpy_rows_(d_sup.view(-1)[b * way * shot * L * 1024:], d_s_pe[b], K1, 1024)
     grads.finish_all(model, "RCNN_rpn")
     _ready(model, stages[2][1])
+    if dgw_ready is not None:
+        torch.cuda.current_stream().wait_event(dgw_ready)
     yield "heads, RPN and attention done; trunk next"
 
     # -- trunk: query (RoIAlign + RPN paths meet in base_feat) and supports; layer3, layer2 (layer1 is frozen) --
