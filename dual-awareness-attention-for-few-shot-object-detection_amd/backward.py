@@ -19,6 +19,7 @@ from .config import cfg
 USE_WINOGRAD_WGRAD = __import__("os").environ.get("DANA_WINO_WGRAD", "1") != "0"
 SAVED_WINOGRAD_V = __import__("os").environ.get("DANA_WGRAD_SAVED_V", "1") != "0"  # weight gradients reuse the forward's V planes
 PREFETCH_DGRAD_W = __import__("os").environ.get("DANA_PREFETCH_DGRAD_W", "1") != "0"  # trunk dgrad weights derived on a side stream
+LINEAR_WGRAD_ON_SIDE = __import__("os").environ.get("DANA_LINEAR_WGRAD_SIDE", "1") != "0"  # Linear dW / db off the dgrad chain
 GATHER_STRIDED_WGRAD = __import__("os").environ.get("DANA_WGRAD_GATHER", "1") != "0"
 
 
@@ -77,6 +78,28 @@ class WeightGrads:
         keep.append((g, x, v))
         with torch.cuda.stream(st):
             self._launch(key, g, x, n, h, w, c, in_stride, grad_stride, v)
+
+    def side_run(self, fn, *keep):
+        """fn() on the weight-gradient stream of the caller's stream, behind everything queued so far; `keep` stays
+        alive until join(). For work that consumes the chain's gradients and feeds nothing back into it (a Linear's
+        dW / db and their accumulation): off the data-gradient chain, joined with the conv weight gradients."""
+        if self.stream is None:
+            fn()
+            return
+        st, kept = self._side_for_current()
+        ready = torch.cuda.Event()
+        ready.record()
+        st.wait_event(ready)
+        kept.append(keep)
+        with torch.cuda.stream(st):
+            fn()
+
+    def linear(self, g, x, m, n, k, then, ldx=0, ldg=0):
+        """dW / db of a Linear (ops.linear_wgrad) on the side stream; then(dw, db) accumulates them there"""
+        if not LINEAR_WGRAD_ON_SIDE:
+            then(*ops.linear_wgrad(g, x, m, n, k, ldx=ldx, ldg=ldg))
+            return
+        self.side_run(lambda: then(*ops.linear_wgrad(g, x, m, n, k, ldx=ldx, ldg=ldg)), g, x)
 
     def _launch(self, key, g, x, n, h, w, c, in_stride, grad_stride, v=None):
         view = self._direct_view(key)
@@ -447,12 +470,13 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         _acc(model.output_score_layer.linear2.bias, ops.colsum(ds, n_roi, 2, alpha=g3))
         d_hid = ops.gemm_small(ds, (2, 1), w2, (nhid, 1), n_roi, nhid, 2, alpha=g3)
         ops.relu_mask_(d_hid, hc["hid"], n_roi, nhid)
-        dw1, db1, d_tr = ops.linear_backward(d_hid, hc["tr"], w1, n_roi, nhid, P2 * rd)
-        _acc(model.output_score_layer.linear1.weight, dw1)
-        _acc(model.output_score_layer.linear1.bias, db1)
+        lin1 = model.output_score_layer.linear1
+        grads.linear(d_hid, hc["tr"], n_roi, nhid, P2 * rd, lambda dw, db: (_acc(lin1.weight, dw), _acc(lin1.bias, db)))
+        _, _, d_tr = ops.linear_backward(d_hid, hc["tr"], w1, n_roi, nhid, P2 * rd, need_dw=False)
         ops.axpy_rows_(d_trq, d_tr, n_roi * P2, rd)
-        dwt_d, _, d_dense = ops.linear_backward(d_tr, hc["dense"], wt.view(-1)[1024:], n_roi * P2, rd, 1024, ldw=2048)
-        ops.axpy_rows_(d_wt.view(-1)[1024:], dwt_d, rd, 1024, ld_y=2048)
+        grads.linear(d_tr, hc["dense"], n_roi * P2, rd, 1024,
+                     lambda dw, db: ops.axpy_rows_(d_wt.view(-1)[1024:], dw, rd, 1024, ld_y=2048))
+        _, _, d_dense = ops.linear_backward(d_tr, hc["dense"], wt.view(-1)[1024:], n_roi * P2, rd, 1024, ldw=2048, need_dw=False)
         d_qh = _attention_backward(d_dense, 1024, hc["sc2"], un2.view(-1)[off * P2:], q2, k2.view(-1)[off * P2 * dq:],
                                    sp_pe.view(-1)[off * P2 * 1024:], B, R * P2, shot, P2, K2p, dq, ug,
                                    way * shot * P2 * dq, way * shot * P2 * 1024, way * shot * P2,
@@ -463,13 +487,17 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     # -- RoI-level query side: Q projection + the q half of rcnn_transform_layer; PE is additive --
     ops.colmean_sub_(d_q2, n_roi, P2, dq)
     wq2 = model.rcnn_adapt_q_layer.weight.detach()
-    dwq2, dbq2, d_q_pe = ops.linear_backward(d_q2, q_pe, wq2, n_roi * P2, dq, 1024)
-    _acc(model.rcnn_adapt_q_layer.weight, dwq2)
-    _acc(model.rcnn_adapt_q_layer.bias, dbq2)
-    dwt_q, dbt, _ = ops.linear_backward(d_trq, q_pe, wt, n_roi * P2, rd, 1024, ldw=2048, dx_out=d_q_pe, dx_ld=1024)
-    ops.axpy_rows_(d_wt, dwt_q, rd, 1024, ld_y=2048)
-    _acc(model.rcnn_transform_layer.weight, d_wt)
-    _acc(model.rcnn_transform_layer.bias, dbt)
+    grads.linear(d_q2, q_pe, n_roi * P2, dq, 1024,
+                 lambda dw, db: (_acc(model.rcnn_adapt_q_layer.weight, dw), _acc(model.rcnn_adapt_q_layer.bias, db)))
+    _, _, d_q_pe = ops.linear_backward(d_q2, q_pe, wq2, n_roi * P2, dq, 1024, need_dw=False)
+
+    def _transform_grads(dw, db):  # (both halves of rcnn_transform_layer's weight gradient are in d_wt now)
+        ops.axpy_rows_(d_wt, dw, rd, 1024, ld_y=2048)
+        _acc(model.rcnn_transform_layer.weight, d_wt)
+        _acc(model.rcnn_transform_layer.bias, db)
+
+    grads.linear(d_trq, q_pe, n_roi * P2, rd, 1024, _transform_grads)
+    ops.linear_backward(d_trq, q_pe, wt, n_roi * P2, rd, 1024, ldw=2048, dx_out=d_q_pe, dx_ld=1024, need_dw=False)
     main.wait_event(box_done)
     ops.axpy_rows_(d_pooled, d_q_pe, n_roi * P2, 1024)
     d_bf = ops.roi_align_backward(d_pooled.view(n_roi, 7, 7, 1024), ctx["rois"].view(-1, 5), 1.0 / 16.0, 7, 7, B, 1024,
@@ -478,15 +506,16 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     # -- RoI-level support side: K projection, unary term, PE, 14x14 average pool (dana.py:105-108,271-277) --
     ops.colmean_sub_(d_k2, Ns, P2, dq)
     wk2 = model.rcnn_adapt_k_layer.weight.detach()
-    dwk2, dbk2, _ = ops.linear_backward(d_k2, sp_pe, wk2, Ns * P2, dq, 1024, dx_out=d_sp_pe, dx_ld=1024)
-    _acc(model.rcnn_adapt_k_layer.weight, dwk2)
-    _acc(model.rcnn_adapt_k_layer.bias, dbk2)
+    grads.linear(d_k2, sp_pe, Ns * P2, dq, 1024,
+                 lambda dw, db: (_acc(model.rcnn_adapt_k_layer.weight, dw), _acc(model.rcnn_adapt_k_layer.bias, db)))
+    ops.linear_backward(d_k2, sp_pe, wk2, Ns * P2, dq, 1024, dx_out=d_sp_pe, dx_ld=1024, need_dw=False)
     ops.softmax_rows_backward_(d_un2, un2, Ns, P2)
     wu2 = model.rcnn_unary_layer.weight.detach()
     _acc(model.rcnn_unary_layer.weight, ops.rowdot_backward(sp_pe, d_un2, wu2, Ns * P2, 1024, grad_x=d_sp_pe))
     _acc(model.rcnn_unary_layer.bias, ops.colsum(d_un2, Ns * P2, 1))
     (sh_, sw_), pool = ctx["sup_map"], ctx["sup_pool"]
     d_sup = ops.avgpool_backward(d_sp_pe, Ns, sh_, sw_, 1024, pool[0], pool[1])  # [Ns][L][1024]
+    grads.join()  # (the heads' Linear weight / bias gradients were accumulated on the weight-gradient stream)
     _ready(model, stages[1][1])
 
     # -- RPN: losses -> heads -> 3x3 conv (rpn.py:58-115) --
@@ -494,12 +523,11 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     nh = ctx["nh"]
     d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
                                     inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0], grad_dev=g_dev)
-    dwh, dbh, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512)
     ns = rpn.nc_score_out
-    _acc(rpn.RPN_cls_score.weight, dwh[:ns])
-    _acc(rpn.RPN_cls_score.bias, dbh[:ns])
-    _acc(rpn.RPN_bbox_pred.weight, dwh[ns:])
-    _acc(rpn.RPN_bbox_pred.bias, dbh[ns:])
+    grads.linear(d_heads, ctx["rpn_x"], B * hw, nh, 512,
+                 lambda dw, db: (_acc(rpn.RPN_cls_score.weight, dw[:ns]), _acc(rpn.RPN_cls_score.bias, db[:ns]),
+                                 _acc(rpn.RPN_bbox_pred.weight, dw[ns:]), _acc(rpn.RPN_bbox_pred.bias, db[ns:])))
+    _, _, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512, need_dw=False)
     ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
     if rpnw_ready is not None:
         torch.cuda.current_stream().wait_event(rpnw_ready)
@@ -518,13 +546,13 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     ops.colmean_sub_(d_qp, B, hw, d)
     ops.colmean_sub_(d_kp, B * shot, L, d)
     wq = model.rpn_adapt_q_layer.weight.detach()
-    dwq, dbq, _ = ops.linear_backward(d_qp, corr, wq, B * hw, d, 1024, ldx=2048, dx_out=d_corr, dx_ld=2048)
-    _acc(model.rpn_adapt_q_layer.weight, dwq)
-    _acc(model.rpn_adapt_q_layer.bias, dbq)
+    grads.linear(d_qp, corr, B * hw, d, 1024,
+                 lambda dw, db: (_acc(model.rpn_adapt_q_layer.weight, dw), _acc(model.rpn_adapt_q_layer.bias, db)), ldx=2048)
+    ops.linear_backward(d_qp, corr, wq, B * hw, d, 1024, ldx=2048, dx_out=d_corr, dx_ld=2048, need_dw=False)
     wk = model.rpn_adapt_k_layer.weight.detach()
-    dwk, dbk, _ = ops.linear_backward(d_kp, s_pe, wk, B * K1, d, 1024, dx_out=d_s_pe, dx_ld=1024)
-    _acc(model.rpn_adapt_k_layer.weight, dwk)
-    _acc(model.rpn_adapt_k_layer.bias, dbk)
+    grads.linear(d_kp, s_pe, B * K1, d, 1024,
+                 lambda dw, db: (_acc(model.rpn_adapt_k_layer.weight, dw), _acc(model.rpn_adapt_k_layer.bias, db)))
+    ops.linear_backward(d_kp, s_pe, wk, B * K1, d, 1024, dx_out=d_s_pe, dx_ld=1024, need_dw=False)
     ops.softmax_rows_backward_(d_un, unary, B * shot, L)
     wu = model.rpn_unary_layer.weight.detach()
     _acc(model.rpn_unary_layer.weight, ops.rowdot_backward(s_pe, d_un, wu, B * K1, 1024, grad_x=d_s_pe))

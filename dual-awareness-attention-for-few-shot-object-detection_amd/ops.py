@@ -1359,13 +1359,20 @@ def rpn_loss_backward(heads, head_row_stride, h, losses3, grad_cls=1.0, grad_box
     return g
 
 
-def linear_backward(g, x, w, m, n, k, ldx=0, ldg=0, ldw=0, need_dx=True, dx_out=None, dx_ld=0):
+def linear_wgrad(g, x, m, n, k, ldx=0, ldg=0):
+    """(dW [n][k], db [n]) of y = x . w^T + b from g = dL/dy: the two pieces of a Linear's backward that nothing on the
+    data-gradient chain waits for (backward.py issues them on the weight-gradient stream)"""
+    return conv2d_wgrad(g, x, 1, 1, m, k, n, 1, 1, 1, 0, in_stride=ldx, grad_stride=ldg), colsum(g, m, n, ld=ldg)
+
+
+def linear_backward(g, x, w, m, n, k, ldx=0, ldg=0, ldw=0, need_dx=True, dx_out=None, dx_ld=0, need_dw=True):
     """y[m][n] = x[m][:k] . w[n][:k]^T + b: returns (dW [n][k] dense, db [n], dx [m][k] or None).
     n % 4 == 0 and k % 64 == 0 (the split-M TN MFMA kernel); dx goes through the forward GEMM on w^T and is
     ACCUMULATED into dx_out (row stride dx_ld) when that is given."""
     ldw = ldw or k
-    dw = conv2d_wgrad(g, x, 1, 1, m, k, n, 1, 1, 1, 0, in_stride=ldx, grad_stride=ldg)
-    db = colsum(g, m, n, ld=ldg)
+    dw = db = None
+    if need_dw:
+        dw, db = linear_wgrad(g, x, m, n, k, ldx=ldx, ldg=ldg)
     dx = None
     if need_dx:
         wt = torch.empty((k, n), dtype=torch.float32, device=g.device)  # [k][n] = w^T
