@@ -90,30 +90,54 @@ def config_label(args):
     return "no BASELINE configuration (configs[2]'s model at another shape)"
 
 
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(args, sd):
-    """The oracle port (oracle/model_ref.py) on the host cores: ONE episode of the same workload."""
+    """The oracle port (oracle/model_ref.py) on the host cores: ONE episode of the same workload, timed with all cores
+    (capped at 64 threads) and, SURVEY 8d, with 8 threads."""
     from dana_amd import synthetic as S
     from oracle import model_ref as O
-    cores = min(os.cpu_count() or 1, 64)  # torch-CPU convs stop scaling (and oversubscribe) beyond ~64 threads
-    torch.set_num_threads(cores)
     way = args.way if args.mode == "train" else 1
     inputs = S.episode_inputs(1, way, args.shot, args.height, args.width, seed=1996)
-    np.random.seed(3)
 
     def one():
         with torch.no_grad():
             O.forward(sd, *inputs, args.mode == "train", way, args.shot, args.ba, nms_inclusive=False)
 
-    one()  # warm-up (thread pools, oneDNN primitive caches)
-    reps, t0 = 0, time.time()
-    while reps < 20 and (time.time() - t0) < 12.0:  # bounded sample: ~10-15 s of CPU work
-        one()
-        reps += 1
-    dt = (time.time() - t0) / reps
-    return {"value": round(1.0 / dt, 4), "unit": "query-images/sec", "cores": cores, "kind": "port",
-            "sample": "%d x 1 episode (1 query %dx%d + %d supports 320x320), %s-mode forward, oracle/model_ref.py on "
-                      "torch-CPU fp32 with %d threads, %.2f s/episode" % (reps, args.height, args.width,
-                                                                          way * args.shot, args.mode, cores, dt)}
+    def sample(threads, budget_s, max_reps):
+        torch.set_num_threads(threads)
+        np.random.seed(3)
+        one()  # warm-up (thread pools, oneDNN primitive caches)
+        reps, t0 = 0, time.time()
+        while reps < max_reps and (time.time() - t0) < budget_s:  # bounded sample
+            one()
+            reps += 1
+        return (time.time() - t0) / reps, reps
+
+    cores = min(os.cpu_count() or 1, 64)  # torch-CPU convs stop scaling (and oversubscribe) beyond ~64 threads
+    runs = []
+    for threads, budget, reps_max in ((cores, 10.0, 12),) + (((8, 8.0, 8),) if cores > 8 else ()):
+        dt, reps = sample(threads, budget, reps_max)  # together ~15-20 s of CPU work
+        runs.append({"value": round(1.0 / dt, 4), "unit": "query-images/sec", "cores": threads,
+                     "sample": "%d x 1 episode, %d threads, %.2f s/episode" % (reps, threads, dt)})
+    torch.set_num_threads(cores)
+    best = max(runs, key=lambda r: r["value"])  # (on a many-core host the 8-thread run can beat the all-cores one)
+    return {"value": best["value"], "unit": "query-images/sec", "cores": best["cores"], "kind": "port",
+            "cpu": cpu_model_name(), "host_logical_cpus": os.cpu_count(), "torch": torch.__version__,
+            "sample": "1 episode (1 query %dx%d + %d supports 320x320) per repetition, %s-mode forward, oracle/model_ref.py on "
+                      "torch-CPU fp32; value = the faster of the thread counts sampled" % (
+                          args.height, args.width, way * args.shot, args.mode),
+            "thread_counts": runs}
 
 
 def pmc_passes(args, kernel):
@@ -174,9 +198,33 @@ def pmc_passes(args, kernel):
     return res
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-execute this very command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one rank per GPU, rendezvous on 127.0.0.1, a free
+    port), hand its output through and return its exit status. The launch contract of DESIGN.md 6: `--gpus` IS the
+    number of ranks; under an external launcher WORLD_SIZE must agree with it."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # (the driver's N > 1 command passes both; a mismatch would print a line whose n_gpus is not what was asked for)
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -205,6 +253,8 @@ def main():
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
         rccl_ranks_seen = int(one.item())
+        if rccl_ranks_seen != world:
+            raise SystemExit("bench.py: the %s process group spans %d ranks, %d were launched" % (backend, rccl_ranks_seen, world))
 
     import dana_amd
     from dana_amd import ops, synthetic as S
@@ -536,6 +586,9 @@ def main():
             "algorithmic_gflop_per_step": round(flops / args.steps / 1e9, 1),
             "executed_gflop_per_step": round(executed / args.steps / 1e9, 1),
             "kernel_ms_per_step": round(ms / args.steps, 3),
+            "kernel_ms_per_step_is": "SERIAL sum of the launches' durations, each bracketed ALONE on one stream; the timed "
+                                     "step overlaps the query and support trunks on two streams, so ms_per_step can be smaller "
+                                     "-- frac is the conservative per-launch figure, whole_step_tflops the overlapped one",
             # the two sub-families, separately: launches that run the DIRECT contraction (algorithmic == executed
             # multiply-adds) and the Winograd F(4x4,3x3) launches (input transform + 36 plane GEMMs + output transform
             # in one timed bracket: 4x fewer multiply-adds than the algorithmic figure they are priced at)
@@ -726,6 +779,59 @@ def main():
         result["configs_1_cisa_only"] = {"value": round(args.batch * k1 / dt1, 3), "unit": "query-images/sec",
                                          "ms_per_step": round(1e3 * dt1 / k1, 3), "steps": k1}
         del m1
+    def secondary_workload(label, mode, batch, height, width, shot, k):
+        """another BASELINE configuration in the same line: its own model / episodes, eager and hipGraph replay timed
+        (the faster is the value), and its own per-launch contraction roofline (single-stream pass, HIP events)."""
+        train_ = mode == "train"
+        way_ = args.way if train_ else 1
+        m2 = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=args.way, shot=shot, classes=["fg", "bg"])
+        m2.load_state_dict(S.fill_state_dict(m2.state_dict(), seed=11, profile="test"))
+        m2.to(dev)
+        m2.train() if train_ else m2.eval()
+        in2 = [t.to(dev) for t in S.episode_inputs(batch, way_, shot, height, width, seed=1996)]
+        np.random.seed(1996)
+        with torch.no_grad():
+            eager2 = lambda: m2(*in2)  # noqa: E731
+            t_eager = trial(eager2, k)
+            t_graph = None
+            if use_graphs:
+                from dana_amd.graphs import GraphedDAnA
+                run2 = GraphedDAnA(m2, *in2)
+                t_graph = trial(lambda: run2(*run2.inputs), k)
+                del run2
+            ops.PROFILE = []
+            m2._single_stream = True
+            torch.cuda.synchronize()
+            for _ in range(k):
+                eager2()
+            torch.cuda.synchronize()
+            m2._single_stream = False
+            prof2, ops.PROFILE = ops.PROFILE, None
+        f2 = sum(r[1] for r in prof2)
+        x2 = sum(r[5] for r in prof2)
+        t2 = sum(r[2].elapsed_time(r[3]) for r in prof2) * 1e-3
+        best = min(t_eager, t_graph) if t_graph is not None else t_eager
+        pk = PEAK_SPLIT_TFLOPS if ops.get_mfma_mode() else PEAK_FP32_MFMA_TFLOPS
+        del m2, in2
+        torch.cuda.empty_cache()
+        return {"workload": label, "value": round(batch / best * 1e3, 3), "unit": "query-images/sec",
+                "ms_per_step": round(best, 3), "steps": k, "batch": batch,
+                "launch": "hipGraph replay" if (t_graph is not None and t_graph <= t_eager) else "eager",
+                "eager_ms_per_step": round(t_eager, 3), "graph_ms_per_step": None if t_graph is None else round(t_graph, 3),
+                "roofline": {"bound": "mfma", "achieved": round(f2 / t2 / 1e12, 2), "peak": pk, "unit": "TFLOP/s",
+                             "frac": round(f2 / t2 / 1e12 / pk, 4), "launches_per_step": len(prof2) // k,
+                             "algorithmic_gflop_per_step": round(f2 / k / 1e9, 1), "executed_gflop_per_step": round(x2 / k / 1e9, 1),
+                             "kernel_ms_per_step": round(t2 * 1e3 / k, 3)}}
+
+    default_shape = (args.height, args.width, args.shot, args.batch, args.support_size) == (600, 1000, 3, 4, 320)
+    if (rank == 0 and world == 1 and args.mode == "train" and args.ba and not args.no_secondary and args.model == "DAnA"
+            and default_shape and not args.single_stream):
+        # BASELINE configs[0] on the GPU path (eval-mode forward, ONE 600x1000 query + 3 supports: the inference.py shape and
+        # SURVEY 8d's parity-checked inference path) and configs[4]'s per-GPU shape (800x1333, shot 10, 2 of its 16 episodes)
+        result["eval_b1"] = secondary_workload("BASELINE configs[0] on the HIP path: eval-mode forward, 1 query 600x1000 + 3 "
+                                               "supports 320x320, BA+CISA", "eval", 1, 600, 1000, 3, 10)
+        result["configs_4"] = secondary_workload("BASELINE configs[4] per-GPU shape: train-mode forward, 2 episodes of 800x1333 "
+                                                 "queries + 20 supports 320x320 (way 2, shot 10), BA+CISA", "train", 2, 800, 1333, 10, 10)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.support_size == 320 and args.model == "DAnA":
         result["cpu_baseline"] = cpu_baseline(args, sd)  # (the oracle, like the reference, only runs 320x320 supports)
     if rank == 0:

@@ -139,8 +139,12 @@ class WeightGrads:
         """the caller's stream waits for every weight-gradient launch issued so far"""
         if self.stream is None:
             self.compact.clear()
+            del _FRESH_GRADS[:]
             return
         cur = torch.cuda.current_stream()
+        for t in _FRESH_GRADS:
+            t.record_stream(cur)
+        del _FRESH_GRADS[:]
         for st, keep in self.side.values():
             if keep:
                 done = torch.cuda.Event()
@@ -282,10 +286,17 @@ def _ready(model, names):
         cb(names)
 
 
+_FRESH_GRADS = []  # gradients _acc() allocated since the last WeightGrads.join() (possibly in a side stream's pool)
+
+
 def _acc(param, g):
     g = g.view_as(param)
     if param.grad is None:
+        # (the reference's optimizer.zero_grad() sets grads to None, so the bridge path comes here every iteration.)
+        # When this runs on the weight-gradient side stream, the clone's block belongs to THAT stream's pool, while the
+        # optimizer / clipping / all-reduce read it on the caller's stream: join() marks it as used there
         param.grad = g.clone()
+        _FRESH_GRADS.append(param.grad)
     else:
         param.grad.add_(g)
 

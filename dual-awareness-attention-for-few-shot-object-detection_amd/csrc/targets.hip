@@ -660,10 +660,16 @@ plain_rcnn_loss_kernel(const float* __restrict__ scores, const long long* __rest
     for (int c = 1; c < C; ++c) m = fmaxf(m, sr[c]);
     float z = 0.f;
     for (int c = 0; c < C; ++c) z += expf(sr[c] - m);
-    const int y = (int)labels[r];
-    lc += -(sr[y] - m - logf(z));
+    // a label outside 0..C-1 (class count and score width disagree) must not index the score row: the loss and that
+    // row's gradient become NaN -- loud in the very next optimizer step -- where F.cross_entropy would raise; there is
+    // no ignore_index on this path (faster_rcnn.py:94 passes every sampled roi)
+    const long long yl = labels[r];
+    const bool ok = yl >= 0 && yl < (long long)C;
+    const int y = ok ? (int)yl : 0;
+    lc += ok ? -(sr[y] - m - logf(z)) : __builtin_nanf("");
     if (gscores)
-      for (int c = 0; c < C; ++c) gscores[(long)r * C + c] = (expf(sr[c] - m) / z - (c == y ? 1.f : 0.f)) * inv_n;
+      for (int c = 0; c < C; ++c)
+        gscores[(long)r * C + c] = ok ? (expf(sr[c] - m) / z - (c == y ? 1.f : 0.f)) * inv_n : __builtin_nanf("");
     float row = 0.f;
     for (int q = 0; q < 4; ++q) {
       const long i = (long)r * 4 + q;

@@ -702,11 +702,16 @@ class DAnARCNN(nn.Module):
 
         ctx = None
         self._bridge = training and torch.is_grad_enabled()  # train.py:141-143 will call loss.backward()
+        merge_trunk, merge_from = bool(self.merge_trunk), int(self.merge_from)
         if training and (self._bridge or getattr(self, "save_for_backward", False)):
+            if getattr(self, "_train_merge", None) is not None:
+                # a Trainer's preference for forwards that SAVE for its backward only (shared [query | support] buffers,
+                # trainer.py); every other forward of this model keeps the configured path
+                merge_trunk, merge_from = self._train_merge
             # everything backward.model_backward needs. The side streams of this forward are all joined into the
             # caller's stream before it returns, and each of them starts by waiting for an event of the NEXT
             # forward's caller stream, so the saved tensors are safe for a backward that runs on that stream.
-            if self.query_streams != 1 and not self.merge_trunk:
+            if self.query_streams != 1 and not merge_trunk:
                 raise RuntimeError("save_for_backward needs query_streams=1")
             ctx = self._ctx = dict(plan=plan, B=B, shot=shot, way=way, q_saved=[], s_saved=[], m_saved=[], l4_saved=[], heads=[])
         else:
@@ -777,12 +782,12 @@ class DAnARCNN(nn.Module):
         P2 = P * P
         dq = self.rcnn_reduce_dim
         K1 = shot * L
-        if self.merge_trunk:
+        if merge_trunk:
             sup_stream.wait_event(inputs_ready)
             corr, (fh, fw), sup, (sh_, sw_) = self._rcnn_base_dual(im_data, sup_ims, plan, dev,
                                                                    save_q=ctx["q_saved"] if ctx is not None else None,
                                                                    save_s=ctx["s_saved"] if ctx is not None else None,
-                                                                   sup_stream=sup_stream, merge_from=int(self.merge_from),
+                                                                   sup_stream=sup_stream, merge_from=merge_from,
                                                                    save_m=ctx["m_saved"] if ctx is not None else None)
             trunk_done = torch.cuda.Event()
             trunk_done.record()
@@ -977,11 +982,20 @@ class DAnARCNN(nn.Module):
         n_roi = B * R
 
         # -- RoIAlign on base_feat (dana.py:181-186), emitting pooled and pooled+PE in one pass --
-        if cfg.POOLING_MODE != "align":
-            raise NotImplementedError("POOLING_MODE '%s': the DAnA recipe uses 'align' (cfgs/res50.yml:35)"
-                                      % cfg.POOLING_MODE)
-        pooled, q_pe = ops.roi_align_forward_nhwc(corr, B, fh, fw, 1024, 2048, rois.view(-1, 5), 1.0 / 16.0, P, 0,
-                                                  pe=plan["pe49"])  # pooled [n,49,1024] and pooled + PE (dana.py:259)
+        if cfg.POOLING_MODE == "align":
+            pooled, q_pe = ops.roi_align_forward_nhwc(corr, B, fh, fw, 1024, 2048, rois.view(-1, 5), 1.0 / 16.0, P, 0,
+                                                      pe=plan["pe49"])  # pooled [n,49,1024] and pooled + PE (dana.py:259)
+        elif cfg.POOLING_MODE == "pool":
+            # dana.py:183-184 (a resumed checkpoint's cfg may ask for it, train.py:100-101): the RoIPool operator of the
+            # `_C` boundary on base_feat (the first 1024 channels of the [.. | attended] buffer), forward only
+            if ctx is not None:
+                raise NotImplementedError("the HIP backward of DAnA covers POOLING_MODE 'align' (cfgs/res50.yml:35)")
+            pooled_nchw, _ = ops.roi_pool_forward(ops.nhwc_to_nchw(corr, B, 1024, fh, fw, in_stride=2048),
+                                                  rois.view(-1, 5).contiguous(), 1.0 / 16.0, P, P)
+            pooled = ops.nchw_to_nhwc(pooled_nchw).view(n_roi, P * P, 1024)
+            q_pe = ops.add_pe(pooled, plan["pe49"], n_roi * P * P, P * P, 1024).view(n_roi, P * P, 1024)
+        else:
+            raise NotImplementedError("POOLING_MODE '%s'" % cfg.POOLING_MODE)
         if inter is not None:
             inter["pooled"] = pooled
         pooled_ready = torch.cuda.Event()

@@ -98,6 +98,11 @@ class GraphedDAnA:
             with torch.cuda.stream(self.side):
                 self.g0.replay()
         self.g1.replay()
+        if self.g0 is None and self.g2 is None and getattr(self.model, "device_rng", False) and self.model.training:
+            # the replay advanced the DEVICE Philox counter by one forward; keep the host count in step, so that an eager
+            # device-RNG forward (or a later capture, which refills the device counter from it) continues the stream
+            # instead of repeating earlier draws
+            self.model._rng_calls += 1
         if self.g2 is not None:
             # anchor counts: behind the side stream only -> the anchor draws overlap the trunk (graph 1) on the GPU
             ops.draw_and_upload(self.req, self.drawn.device, static=self.drawn)
@@ -135,8 +140,9 @@ class GraphedTrainer:
         # iterations are the warm-up)
         snap = None
         if warmup > 0:
+            import numpy as _np
             snap = ([fb.params.clone() for fb, _, _ in trainer.groups], [b.clone() for b in trainer.bufs], trainer.steps,
-                    self.model._rng_calls)
+                    self.model._rng_calls, _np.random.get_state())  # (host-RNG mode draws np.random in the warm-up too)
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 trainer.step(*self.inputs)
@@ -147,6 +153,7 @@ class GraphedTrainer:
             for b, b0 in zip(trainer.bufs, snap[1]):
                 b.copy_(b0)
             trainer.steps, self.model._rng_calls = snap[2], snap[3]
+            _np.random.set_state(snap[4])
             self.model._epoch += 1
             torch.cuda.synchronize(dev)
         cur.wait_stream(self.stream)
@@ -290,6 +297,8 @@ class GraphedTrainer:
             for fb, i in buckets:
                 works.append(fb.reduce_bucket(i))
         tr.steps += 1
+        if getattr(self.model, "device_rng", False):
+            self.model._rng_calls += 1  # (the replay advanced the device Philox counter by one forward: see GraphedDAnA)
         # the fused SGD wrote the weights through raw pointers (no tensor._version bump) and the graph re-derived its OWN
         # packed / Winograd / two-segment copies at the start of the replay, i.e. before this step's update: an eager
         # forward that follows (per-epoch eval, Trainer.step) must re-derive them from the live weights

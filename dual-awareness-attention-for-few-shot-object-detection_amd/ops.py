@@ -18,6 +18,7 @@ EPI_RELU, CONV_STEM7, W_SPLIT3 = 1, 2, 256
 # bench.py sets this to a list to time every MFMA contraction launch with HIP events recorded on the
 # stream the kernel is launched on; entries are (tag, algorithmic_flops, start_event, end_event).
 PROFILE = None
+PROF_ROLE = None  # set (while profiling) around launches that play another role than their kernel's name says: "dgrad"
 
 
 def _prof_begin():
@@ -35,7 +36,10 @@ def _prof_end(e0, tag, flops, nbytes=0.0, executed=None):
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((tag[0] % tag[1], flops, e0, e1, nbytes, flops if executed is None else executed))
+        name = tag[0] % tag[1]
+        if PROF_ROLE is not None and not name.startswith(PROF_ROLE):
+            name = PROF_ROLE + ":" + name  # e.g. "dgrad:wino3x3 ...": a data gradient that runs on a forward kernel
+        PROFILE.append((name, flops, e0, e1, nbytes, flops if executed is None else executed))
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -1205,6 +1209,14 @@ def conv2d_dgrad(grad_out, w_packed, batch, in_h, in_w, cin, cout, kh, kw, strid
     whose ReLU adjoint is applied last (zero where mask <= 0). For a strided 1x1 conv residual must be COMPACT
     ([batch*oh*ow][cin], e.g. the downsample branch's compact gradient) and compact_out=True returns the compact
     result without scattering."""
+    global PROF_ROLE
+    if PROFILE is not None and PROF_ROLE is None:
+        PROF_ROLE = "dgrad"
+        try:
+            return conv2d_dgrad(grad_out, w_packed, batch, in_h, in_w, cin, cout, kh, kw, stride, pad, scale, wd, ud,
+                                residual, mask, mask_stride, compact_out, out)
+        finally:
+            PROF_ROLE = None
     _chk(grad_out, "grad_out")
     if wd is None:
         wd = conv2d_dgrad_weight(w_packed, cout, cin, kh, kw, scale)

@@ -168,11 +168,15 @@ class Trainer:
         self.bufs = [torch.zeros_like(fb.params) for fb, _, _ in self.groups]  # SGD momentum / Adam exp_avg
         self.bufs2 = [torch.zeros_like(fb.params) for fb, _, _ in self.groups] if optimizer == "adam" else None
         self.steps = 0
-        if type(model).__name__ == "DAnARCNN" and __import__("os").environ.get("DANA_TRAIN_MERGED", "1") != "0":
+        env = __import__("os").environ
+        if (type(model).__name__ == "DAnARCNN" and env.get("DANA_TRAIN_MERGED", "1") != "0"
+                and "DANA_MERGE_TRUNK" not in env and "DANA_MERGE_FROM" not in env):
             # the training iteration keeps the query and the support batch in ONE set of activation buffers (the trunk's
             # launches stay two per conv on two streams: merge_from 3), so that the backward's 1x1 weight / data gradients
-            # run once over both batches (backward.bottleneck_backward_merged)
-            model.merge_trunk, model.merge_from = True, 3
+            # run once over both batches (backward.bottleneck_backward_merged). A preference for the forwards that save
+            # for THIS trainer's backward only: the model's configured path (merge_trunk / merge_from, or an explicit
+            # DANA_MERGE_TRUNK / DANA_MERGE_FROM) stays what every eval / inference / bench forward takes.
+            model._train_merge = (True, 3)
         model._plan = None  # parameter storage moved: re-pack on the next forward
         model._grad_ready_cb = self._on_ready
         for fb, _, _ in self.groups:

@@ -374,7 +374,9 @@ int dana_anchor_target_outputs(const float* labels, const float* max_overlaps, c
  * and d losses3[1] / d bbox_pred. No host sync (the reference's nonzero / sort / index chain has three). */
 /* the plain losses of the sibling detectors (faster_rcnn.py:93-98): losses2[0] = F.cross_entropy(scores [n][n_classes],
  * labels int64 [n]) (mean), losses2[1] = _smooth_l1_loss(sigma) (net_utils.py:71-85); optional gradient seeds
- * d losses2[0] / d scores [n][n_classes] and d losses2[1] / d bbox_pred [n][4]. One launch, no host sync. */
+ * d losses2[0] / d scores [n][n_classes] and d losses2[1] / d bbox_pred [n][4]. One launch, no host sync.
+ * A label outside 0..n_classes-1 is never used as an index: losses2[0] and that row's score gradient become NaN
+ * (F.cross_entropy would raise); there is no ignore_index. */
 int dana_plain_rcnn_loss(const float* scores, const long long* labels, const float* bbox_pred, const float* bbox_targets,
                          const float* inside_weights, const float* outside_weights, int n, int n_classes, float sigma,
                          float* losses2, float* grad_scores, float* grad_bbox, dana_stream_t stream);

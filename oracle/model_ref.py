@@ -478,7 +478,7 @@ def roi_align_torch(feat, rois, scale, P):
 
 
 def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_way=2, n_shot=3, use_ba=False,
-            nms_inclusive=True, inter=None, differentiable=False, sampled=None):
+            nms_inclusive=True, inter=None, differentiable=False, sampled=None, pooling="align"):
     """sampled: optional (rois [B,R,5], labels [B,R], targets [B,R,4], w_in, w_out) used INSTEAD of this call's own
     proposal_target_layer draw (everything downstream of the sampling is then a deterministic function of it).
     differentiable=True: the state-dict tensors may require grad (RoIAlign through roi_align_torch; the proposal
@@ -529,7 +529,11 @@ def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_
         rw_out = rw_out.view(-1, 4)
     if inter is not None:
         inter["rois"] = rois
-    if differentiable:
+    if pooling == "pool":  # dana.py:183-184: cfg.POOLING_MODE == 'pool' -> RCNN_roi_pool (ROIPool.h)
+        assert not differentiable
+        pooled = torch.from_numpy(native.roi_pool_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
+                                                          1.0 / 16.0, 7, 7)[0])
+    elif differentiable:
         pooled = roi_align_torch(base_feat, rois.view(-1, 5), 1.0 / 16.0, 7)
     else:
         pooled = torch.from_numpy(native.roi_align_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),

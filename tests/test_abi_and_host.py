@@ -4,6 +4,7 @@ logic of the product package (module API, state_dict contract, config, target as
 generator) behaves like the reference / the oracle."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -13,6 +14,8 @@ import dana_amd
 from dana_amd import _lib, ops, synthetic as S, targets as T
 from dana_amd.config import cfg, cfg_from_list
 from oracle import model_ref as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -180,3 +183,13 @@ def test_C_module_installs_as_the_reference_model_C():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_bench_rejects_a_launcher_whose_world_size_is_not_gpus():
+    """bench.py's launch contract: under an external launcher WORLD_SIZE must equal --gpus; a mismatch
+    exits non-zero before any device work (it would otherwise print a line whose n_gpus is not what was asked for)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert pr.returncode != 0 and b"WORLD_SIZE=2" in pr.stderr and not pr.stdout.strip()

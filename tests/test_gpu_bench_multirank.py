@@ -47,3 +47,20 @@ def test_bench_two_ranks_prints_one_line(dev):
     # N ranks share the host: graph replay unless every rank's trial preferred eager issue
     lt = j["launch_trial"]
     assert lt is None or ("hipGraph" in j["launch"]) == (lt.get("ranks_preferring_eager") != "all")
+
+
+def test_bench_gpus_flag_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's N = 1 command with another N):
+    bench.py re-executes itself under torch.distributed.run and rank 0 prints ONE line with n_gpus 2."""
+    env = dict(os.environ, DANA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-pmc",
+           "--no-secondary", "--no-train-step", "--no-cpu-baseline"]
+    pr = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert pr.returncode == 0, pr.stderr.decode()[-3000:]
+    lines = [ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and j["config"]["global_batch"] == 8
+    assert j["value"] > 0 and _finite(j)

@@ -296,6 +296,10 @@ def _train_vs_oracle(dev, B, way, shot, H, W, ba, wseed=11, iseed=1996, nseed=5,
             i, 100 * per_image[i])
     assert sum(good) * 2 >= B, "sampled rois diverge from the oracle on most images: %s" % per_image
     matched = np.array(per_image)
+    # make a drift visible: how many images had a flip-free proposal list, and how many met the sampled-roi bar
+    # (pytest -rP / -s shows it; the caller asserts its own floor on the flip-free count)
+    print("_train_vs_oracle B=%d %dx%d shot=%d ba=%d: flip-free proposal lists %d/%d, sampled rois matched on %d/%d images %s"
+          % (B, H, W, shot, int(ba), sum(flip_free), B, sum(good), B, ["%.3f" % v for v in per_image]))
     # (d) stage-wise and unconditional: the oracle's sampled batch goes into the RoI stages
     m._inject_sampled = inter["sampled"]
     np.random.seed(nseed)
@@ -309,12 +313,44 @@ def _train_vs_oracle(dev, B, way, shot, H, W, ba, wseed=11, iseed=1996, nseed=5,
 
 def test_train_forward_full_size_vs_oracle(dev):
     """BASELINE.json configs[1] at its full batch: 600x1000, way 2, shot 3, bs 4, CISA only, train mode"""
-    _train_vs_oracle(dev, 4, 2, 3, 600, 1000, False)
+    _, flip_free = _train_vs_oracle(dev, 4, 2, 3, 600, 1000, False)
+    assert sum(flip_free) >= 2, flip_free  # (seeded: a drop below half the batch means the proposal layer drifted)
 
 
 def test_train_forward_full_size_ba_bs4_vs_oracle(dev):
     """BASELINE.json configs[2] at its full batch: 600x1000, way 2, shot 3, bs 4, BA + CISA (the bench headline)"""
-    _train_vs_oracle(dev, 4, 2, 3, 600, 1000, True, nseed=9)
+    _, flip_free = _train_vs_oracle(dev, 4, 2, 3, 600, 1000, True, nseed=9)
+    assert sum(flip_free) >= 2, flip_free
+
+
+def test_dana_roi_pool_mode_vs_oracle(dev):
+    """cfg.POOLING_MODE = 'pool' inside DAnA (dana.py:183-184; a resumed checkpoint may set it, train.py:100-101): the
+    RoIPool operator of the `_C` boundary feeds layer4 and the RoI-level attention; vs the oracle in the same mode"""
+    import dana_amd
+    from dana_amd import synthetic as S
+    from dana_amd.config import cfg
+    from oracle import model_ref as O
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=1, shot=2, classes=["fg", "bg"])
+    sd = S.fill_state_dict(m.state_dict(), seed=13, profile="test")
+    m.load_state_dict(sd)
+    m.to(dev).eval()
+    inputs = S.episode_inputs(1, 1, 2, 160, 224, seed=3)
+    old = cfg.POOLING_MODE
+    cfg.POOLING_MODE = "pool"
+    try:
+        with torch.no_grad():
+            out = m(*[t.to(dev) for t in inputs])
+            ref = O.forward(sd, *inputs, False, 1, 2, True, nms_inclusive=False, pooling="pool")
+            cfg.POOLING_MODE = "align"
+            out_align = m(*[t.to(dev) for t in inputs])
+    finally:
+        cfg.POOLING_MODE = old
+    r, rg = out[0].cpu().numpy().reshape(-1, 5), ref[0].numpy().reshape(-1, 5)
+    matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
+    assert matched.mean() >= 0.99
+    assert np.abs(out[1].cpu().numpy() - ref[1].numpy()).reshape(-1, 2)[matched].max() <= 1e-4
+    assert np.abs(out[2].cpu().numpy() - ref[2].numpy()).reshape(-1, 4)[matched].max() <= 1e-4
+    assert not torch.equal(out[1], out_align[1])  # (the two pooling modes really are different operators)
 
 
 def test_config4_stress_train_forward_vs_oracle(dev):

@@ -595,3 +595,90 @@ def test_device_rng_target_sampling_is_valid_deterministic_and_uniform(dev):
         fgb = rois_out[b, :nfg, 1:]
         assert len({tuple(r.tolist()) for r in fgb}) == nfg  # foreground picks are drawn without replacement
         assert torch.all((w_in[b] > 0).any(1) == (labels[b] == 1))
+
+
+def test_two_threads_two_streams_are_reentrant(dev):
+    """include/dana_hip.h:7-9 promises re-entrancy (nn.DataParallel drives one replica per THREAD, train.py:104-105):
+    two Python threads, each on its own stream of the one device, hammer `_C.nms`, `_C.roi_align_forward` and a
+    contraction concurrently; every result must equal the single-threaded one bit for bit."""
+    import threading
+    from dana_amd import _C, ops
+    rng = np.random.RandomState(5)
+
+    def boxes(n, seed):
+        r = np.random.RandomState(seed)
+        xy = r.rand(n, 2).astype(np.float32) * 400
+        wh = r.rand(n, 2).astype(np.float32) * 120 + 4
+        return torch.from_numpy(np.concatenate([xy, xy + wh], 1)), torch.from_numpy(r.rand(n).astype(np.float32))
+
+    work = []
+    for t in range(2):
+        d, s = boxes(3000 + 700 * t, 10 + t)
+        feat = torch.from_numpy(rng.randn(2, 64, 38, 50).astype(np.float32))
+        rois = torch.from_numpy(np.concatenate([rng.randint(0, 2, (200, 1)).astype(np.float32),
+                                                boxes(200, 20 + t)[0]], 1))
+        x = torch.from_numpy(rng.randn(2 * 30 * 40, 128).astype(np.float32))
+        w = torch.from_numpy((rng.randn(256, 128, 3, 3) * 0.05).astype(np.float32))
+        work.append([v.to(dev) for v in (d, s, feat, rois, x, w)])
+
+    def run(item):
+        d, s, feat, rois, x, w = item
+        keep = _C.nms(d, s, 0.7)
+        pooled = _C.roi_align_forward(feat, rois, 1.0 / 16.0, 7, 7, 0)
+        y, _, _ = ops.conv2d_nhwc(x, 2, 30, 40, 128, ops.pack_conv_weight(w), 256, 3, 3, 1, 1, relu=True)
+        return keep, pooled, y
+
+    expect = [run(it) for it in work]
+    torch.cuda.synchronize()
+    errors, out = [], [[None] * 6 for _ in range(2)]
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                for i in range(6):
+                    out[t][i] = run(work[t])
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    assert not errors, errors
+    for t in range(2):
+        for i in range(6):
+            for a, b in zip(out[t][i], expect[t]):
+                assert torch.equal(a, b), "thread %d round %d differs from the single-threaded result" % (t, i)
+
+
+def test_plain_rcnn_losses_vs_torch_and_out_of_range_label_is_nan(dev):
+    """dana_plain_rcnn_loss (faster_rcnn.py:93-98) vs F.cross_entropy / the smooth-L1 formulation, with its seeds vs
+    autograd; a label outside 0..C-1 never indexes the score row: loss and that row's gradient are NaN"""
+    import torch.nn.functional as F
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    n, C = 200, 2
+    sc = torch.randn(n, C, generator=g)
+    lab = torch.randint(0, C, (n,), generator=g)
+    bp, tg = torch.randn(n, 4, generator=g), torch.randn(n, 4, generator=g)
+    win = (torch.rand(n, 4, generator=g) > 0.5).float()
+    wout = win.clone()
+    scr = sc.clone().requires_grad_(True)
+    ref = F.cross_entropy(scr, lab)
+    ref.backward()
+    l2, (dc, db) = ops.plain_rcnn_losses(sc.to(dev), lab.to(dev), bp.to(dev), tg.to(dev), win.to(dev), wout.to(dev),
+                                         with_grad=True)
+    assert abs(float(l2[0]) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert (dc.cpu() - scr.grad).abs().max() <= 1e-7
+    d = win * (bp - tg)
+    sl1 = (wout * torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5)).sum(1).mean()
+    assert abs(float(l2[1]) - float(sl1)) <= 2e-6 * max(1.0, abs(float(sl1)))
+    bad = lab.clone()
+    bad[17] = C  # one past the last class
+    l2b, (dcb, _) = ops.plain_rcnn_losses(sc.to(dev), bad.to(dev), bp.to(dev), tg.to(dev), win.to(dev), wout.to(dev),
+                                          with_grad=True)
+    assert torch.isnan(l2b[0]) and torch.isnan(dcb[17]).all()
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[17] = False
+    assert torch.equal(dcb.cpu()[keep], dc.cpu()[keep]) and torch.isfinite(l2b[1])
