@@ -181,6 +181,8 @@ class DAnARCNN(nn.Module):
         # first trunk stage whose convs run as ONE launch over both batches (0: stem + layer1 .. 2: layer3 only, 3: none);
         # the stages in front of it run the two batches on two streams (_rcnn_base_dual)
         self.merge_from = int(__import__('os').environ.get('DANA_MERGE_FROM', '0'))
+        # issue the query and the support trunk alternately, block by block (two streams fed from the first launch on)
+        self.interleave_trunks = __import__('os').environ.get('DANA_INTERLEAVE', '1') != '0'
         self.nms_inclusive = False  # False: IoU > thr as the reference CUDA op (nms.cu:60); True: CPU op (>=)
         dim_in = self.pool_feat_dim
 
@@ -409,6 +411,26 @@ class DAnARCNN(nn.Module):
             e = self._conv_cache[key] = (sig, ops.split_weight(w.detach().contiguous().view(-1)[col0:], n, k, ldw=ktot))
         return e[1], 0
 
+    def _roi_query_fold(self, plan, n_roi, dev):
+        """RoI-level query projections with the positional encoding folded in (forward-only path): B operand of the fused
+        GEMM = [rcnn_adapt_q_layer.weight ; rcnn_transform_layer.weight[:, :1024]] ([dq + rcnn_dim][1024]) and the
+        row-periodic residual  T[r] = PE49[r % 49] . Wcat^T + [b_q | b_t]  ([n_roi * 49][dq + rcnn_dim]); both cached per
+        weight version (the contraction of the table is one 49-row GEMM on the same kernels)"""
+        lq, lt = self.rcnn_adapt_q_layer, self.rcnn_transform_layer
+        sig = tuple((t.data_ptr(), t._version) for t in (lq.weight, lq.bias, lt.weight, lt.bias)) + (
+            self._epoch, ops.get_mfma_mode(), self.presplit_weights, n_roi)
+        e = self._conv_cache.get("roi_query_fold")
+        if e is None or e[0] != sig:
+            wcat = torch.cat([lq.weight.detach(), lt.weight.detach()[:, :1024]], 0).contiguous()
+            bcat = torch.cat([lq.bias.detach(), lt.bias.detach()]).contiguous()
+            n = wcat.size(0)
+            table = ops.gemm_nt(plan["pe49"], wcat, 49, n, 1024, shift=bcat)
+            tfull = table.repeat(n_roi, 1).contiguous()
+            b3 = ops.split_weight(wcat, n, 1024) if (self.presplit_weights and ops.get_mfma_mode() != 0) else None
+            e = self._conv_cache["roi_query_fold"] = (sig, (b3 if b3 is not None else wcat, 0 if b3 is not None else 1024,
+                                                            tfull))
+        return e[1]
+
     # ---- trunk -----------------------------------------------------------------------------------
     @staticmethod
     def _conv(x, n, h, w, c, relu, residual=None, res_stride=0, out=None, out_stride=0, in_stride=0, keep_v=None):
@@ -455,12 +477,25 @@ class DAnARCNN(nn.Module):
     def _rcnn_base(self, im, plan, out_stride=0, out_buf=None, save=None):
         """RCNN_base (dana.py:344-345) on NCHW input -> (NHWC flat buffer [n*h*w][out_stride or 1024], h, w).
         out_buf: write the result there (row stride out_stride) instead of allocating."""
+        gen = self._rcnn_base_gen(im, plan, out_stride, out_buf, save)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as done:
+            return done.value
+
+    def _rcnn_base_gen(self, im, plan, out_stride=0, out_buf=None, save=None):
+        """_rcnn_base as a generator that pauses after the stem and after every bottleneck block: the forward issues the
+        query and the support trunk ALTERNATELY (each on its own stream), so both streams have work from the step's first
+        launch on -- issued one after the other, the second trunk's first kernel reaches the GPU a millisecond of host
+        time after the first's, and until then one stream of dependent launches has the chip to itself"""
         n, _, H, W = im.shape
         x4 = ops.nchw_to_nhwc(im, cpad=4)
         st = plan["stem"]
         x, h, w = ops.conv2d_nhwc(x4, n, H, W, 4, st.get("ws") or st["w"], 64, 7, 7, 2, 3, scale=st["scale"],
                                   shift=st["shift"], relu=True, stem=True)
         x, h, w = ops.maxpool3x3s2_ceil(x, n, h, w, 64)
+        yield
         nl = len(plan["layers"])
         for li, layer in enumerate(plan["layers"]):
             for bi, bp in enumerate(layer):
@@ -473,6 +508,8 @@ class DAnARCNN(nn.Module):
                                                                           dtype=torch.float32, device=im.device)
                 x, h, w = self._bottleneck(x, n, h, w, bp, out=out, out_stride=out_stride if last else 0,
                                            save=save if li > 0 else None, key="RCNN_base.%d.%d" % (4 + li, bi))
+                if not last:
+                    yield
         return x, h, w
 
     @staticmethod
@@ -794,15 +831,36 @@ class DAnARCNN(nn.Module):
             sup_stream.wait_event(trunk_done)
         else:
             sup_stream.wait_event(inputs_ready)
-            with torch.cuda.stream(sup_stream):
-                sup, sh_, sw_ = self._rcnn_base(sup_ims, plan, save=ctx["s_saved"] if ctx is not None else None)
-            # the query batch itself is split over `query_streams` streams: kernels of different images
-            # overlap each other's prologue / epilogue / tail phases on the CUs
             qs = max(1, min(int(self.query_streams), B))
             fh, fw = self._feat_size(im_data.size(2), im_data.size(3))
             corr = torch.empty((B * fh * fw, 2048), dtype=torch.float32, device=dev)
+            interleave = qs == 1 and sup_stream != main and self.interleave_trunks
+            if interleave:
+                # alternate issue, block by block: support trunk on its stream, query trunk on the caller's
+                g_s = self._rcnn_base_gen(sup_ims, plan, save=ctx["s_saved"] if ctx is not None else None)
+                g_q = self._rcnn_base_gen(im_data, plan, out_stride=2048, out_buf=corr,
+                                          save=ctx["q_saved"] if ctx is not None else None)
+                r_s = r_q = None
+                while r_s is None or r_q is None:
+                    if r_q is None:
+                        try:
+                            next(g_q)
+                        except StopIteration as done_:
+                            r_q = done_.value
+                    if r_s is None:
+                        with torch.cuda.stream(sup_stream):
+                            try:
+                                next(g_s)
+                            except StopIteration as done_:
+                                r_s = done_.value
+                sup, sh_, sw_ = r_s
+            else:
+                with torch.cuda.stream(sup_stream):
+                    sup, sh_, sw_ = self._rcnn_base(sup_ims, plan, save=ctx["s_saved"] if ctx is not None else None)
+            # the query batch itself is split over `query_streams` streams: kernels of different images
+            # overlap each other's prologue / epilogue / tail phases on the CUs
             bounds = [B * i // qs for i in range(qs + 1)]
-            for i in range(qs):
+            for i in range(0 if not interleave else qs, qs):
                 b0, b1 = bounds[i], bounds[i + 1]
                 if i == 0 or self.query_sequential:
                     self._rcnn_base(im_data[b0:b1], plan, out_stride=2048, out_buf=corr[b0 * fh * fw:],
@@ -982,7 +1040,14 @@ class DAnARCNN(nn.Module):
         n_roi = B * R
 
         # -- RoIAlign on base_feat (dana.py:181-186), emitting pooled and pooled+PE in one pass --
-        if cfg.POOLING_MODE == "align":
+        # Forward-only runs (nothing saved for a backward) fold the positional encoding of dana.py:259 into the two
+        # projections that consume it: (pooled + PE) W^T = pooled W^T + (PE W^T), a [49][N] table per weight version --
+        # RoIAlign then writes ONE [n,49,1024] output instead of two (it is bound by its own writes), and the
+        # Q projection and the query half of rcnn_transform_layer are ONE N = 128 GEMM over pooled (one read of it).
+        fold_pe = ctx is None and cfg.POOLING_MODE == "align" and getattr(self, "fold_roi_pe", True)
+        if cfg.POOLING_MODE == "align" and fold_pe:
+            pooled, q_pe = ops.roi_align_forward_nhwc(corr, B, fh, fw, 1024, 2048, rois.view(-1, 5), 1.0 / 16.0, P, 0)
+        elif cfg.POOLING_MODE == "align":
             pooled, q_pe = ops.roi_align_forward_nhwc(corr, B, fh, fw, 1024, 2048, rois.view(-1, 5), 1.0 / 16.0, P, 0,
                                                       pe=plan["pe49"])  # pooled [n,49,1024] and pooled + PE (dana.py:259)
         elif cfg.POOLING_MODE == "pool":
@@ -1025,9 +1090,17 @@ class DAnARCNN(nn.Module):
         if support_roi_done is not None:
             main.wait_event(support_roi_done)
         wq2, bq2 = self._w(self.rcnn_adapt_q_layer)
-        q2b3, q2ld = self._lin_b(self.rcnn_adapt_q_layer)
-        q2 = ops.gemm_nt(q_pe, q2b3, n_roi * P2, dq, 1024, ldb=q2ld, shift=bq2)
-        ops.colmean_sub_(q2, n_roi, P2, dq)
+        if fold_pe:
+            wcat, wcat_ld, tfull = self._roi_query_fold(plan, n_roi, dev)
+            qld = dq + self.rcnn_dim
+            qt = ops.gemm_nt(pooled, wcat, n_roi * P2, qld, 1024, ldb=wcat_ld, residual=tfull, ldr=qld)  # [n*49][dq | 64]
+            q2 = qt.view(-1)
+            ops.colmean_sub_(q2, n_roi, P2, dq, ld=qld)
+        else:
+            qld = dq
+            q2b3, q2ld = self._lin_b(self.rcnn_adapt_q_layer)
+            q2 = ops.gemm_nt(q_pe, q2b3, n_roi * P2, dq, 1024, ldb=q2ld, shift=bq2)
+            ops.colmean_sub_(q2, n_roi, P2, dq)
         K2 = shot * P2
         K2p = (K2 + 31) // 32 * 32
         wt, bt_ = self._w(self.rcnn_transform_layer)
@@ -1036,7 +1109,11 @@ class DAnARCNN(nn.Module):
         wt_q, wt_q_ld = self._lin_b(self.rcnn_transform_layer, 0, 1024)      # the two column halves of Wt [64][2048]
         wt_a, wt_a_ld = self._lin_b(self.rcnn_transform_layer, 1024, 1024)
         w1b3, w1ld = self._lin_b(self.output_score_layer.linear1)
-        tr_q = ops.gemm_nt(q_pe, wt_q, n_roi * P2, self.rcnn_dim, 1024, ldb=wt_q_ld, shift=bt_)  # [n*49][64]
+        if fold_pe:
+            tr_q, tr_q_ld = qt.view(-1)[dq:], qld  # the second column block of the fused projection
+        else:
+            tr_q = ops.gemm_nt(q_pe, wt_q, n_roi * P2, self.rcnn_dim, 1024, ldb=wt_q_ld, shift=bt_)  # [n*49][64]
+            tr_q_ld = self.rcnn_dim
         q_ready = torch.cuda.Event()
         q_ready.record()
 
@@ -1048,7 +1125,7 @@ class DAnARCNN(nn.Module):
             ub = un2.view(-1)[offset * P2:]
             sb = sp_pe.view(-1)[offset * P2 * 1024:]
             sc2 = torch.empty((B, R * P2, K2p), dtype=torch.float32, device=dev)
-            ops.gemm_nt(q2, kb, R * P2, K2, dq, out=sc2, ldc=K2p, batch=B, batch_a=R * P2 * dq,
+            ops.gemm_nt(q2, kb, R * P2, K2, dq, lda=qld, out=sc2, ldc=K2p, batch=B, batch_a=R * P2 * qld,
                         batch_b=way * shot * P2 * dq, batch_c=R * P2 * K2p, alpha=1.0 / math.sqrt(dq))
             ops.attn_softmax_unary_(sc2, ub, n_roi * P2, R * P2, shot, P2, K2p, K2p, self.unary_gamma, 1.0 / shot,
                                     unary_batch_stride=way * shot * P2)
@@ -1057,7 +1134,7 @@ class DAnARCNN(nn.Module):
             ops.gemm_nt(sc2, st2, R * P2, 1024, K2p, lda=K2p, ldb=K2p, out=dense, ldc=1024, batch=B,
                         batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 1024, k_true=K2)
             tr = ops.gemm_nt(dense, wt_a, n_roi * P2, self.rcnn_dim, 1024, ldb=wt_a_ld,
-                             residual=tr_q, ldr=self.rcnn_dim)  # [n*49][64] == [n][3136]
+                             residual=tr_q, ldr=tr_q_ld)  # [n*49][64] == [n][3136]
             hid = ops.gemm_nt(tr, w1b3, n_roi, w1.size(0), P2 * self.rcnn_dim, ldb=w1ld, shift=b1, relu=True)
             score = ops.gemm_nt(hid, w2, n_roi, 2, w1.size(0), shift=b2)
             prob = ops.softmax_rows_to(score, prob_all[(n_roi if offset else 0):], n_roi, 2)[:n_roi]
@@ -1075,7 +1152,8 @@ class DAnARCNN(nn.Module):
                 for t_ in (neg_prob, neg_score):
                     t_.record_stream(main)
                 for t_ in (q2, tr_q, q_pe, prob_all):
-                    t_.record_stream(neg_stream)
+                    if t_ is not None:  # (q_pe: None when the positional encoding is folded into the projections)
+                        t_.record_stream(neg_stream)
                 neg_done = torch.cuda.Event()
                 neg_done.record()
         cls_prob, cls_score_all = head(0)
