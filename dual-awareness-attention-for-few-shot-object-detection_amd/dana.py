@@ -183,6 +183,8 @@ class DAnARCNN(nn.Module):
         self.merge_from = int(__import__('os').environ.get('DANA_MERGE_FROM', '0'))
         # issue the query and the support trunk alternately, block by block (two streams fed from the first launch on)
         self.interleave_trunks = __import__('os').environ.get('DANA_INTERLEAVE', '1') != '0'
+        # forward-only runs: RoI-level positional encoding folded into one fused query projection (see _roi_query_fold)
+        self.fold_roi_pe = __import__('os').environ.get('DANA_FOLD_ROI_PE', '1') != '0'
         self.nms_inclusive = False  # False: IoU > thr as the reference CUDA op (nms.cu:60); True: CPU op (>=)
         dim_in = self.pool_feat_dim
 
