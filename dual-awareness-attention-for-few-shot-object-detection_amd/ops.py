@@ -848,7 +848,7 @@ def _splitk_slices(m, n, k, batch):
 
 
 def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None, residual=None, ldr=0, batch=1,
-            batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False, k_true=0):
+            batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False, k_true=0, force_slices=0):
     """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous."""
     _chk(a, "a")
     bp, wfl = _wf(b)
@@ -864,7 +864,7 @@ def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None
         ldc = n
         batch_c = m * n
     e0 = _prof_begin()
-    slices = _splitk_slices(m, n, k, batch) if SPLIT_K else 1
+    slices = (force_slices or _splitk_slices(m, n, k, batch)) if SPLIT_K else 1
     if wfl and slices > 1 and (k // slices) % 16:
         slices = 1
     if slices > 1:

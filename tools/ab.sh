@@ -9,7 +9,7 @@ run() { env $1 timeout 900 python bench.py --mode $MODE --no-cpu-baseline --no-p
 import json,sys
 j=json.loads(sys.stdin.read()); r=j.get('roofline') or {}
 f=r.get('families',{})
-print('%-34s %7.1f img/s %6.3f ms (%s)  contraction %s ms frac %s direct %s wino %s launches %s' % ('$1', j['value'], j['ms_per_step'], j['launch'][:5], r.get('kernel_ms_per_step'), r.get('frac'), (f.get('direct') or {}).get('ms_per_step'), (f.get('winograd') or {}).get('ms_per_step'), r.get('launches_per_step')))"; }
+print('%-34s %7.1f img/s %6.3f ms median %6.3f (%s)  contraction %s ms frac %s direct %s wino %s launches %s' % ('$1', j['value'], j['ms_per_step'], j['ms_per_step_median'] or 0, j['launch'][:5], r.get('kernel_ms_per_step'), r.get('frac'), (f.get('direct') or {}).get('ms_per_step'), (f.get('winograd') or {}).get('ms_per_step'), r.get('launches_per_step')))"; }
 for rep in $(seq 1 $REPS); do
   run "DEFAULT=1"
   for v in "$@"; do run "$v"; done
