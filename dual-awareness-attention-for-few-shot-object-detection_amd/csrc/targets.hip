@@ -210,7 +210,8 @@ __device__ __forceinline__ float gt_iou(float4 a, float a_area, const float* __r
 //   anchor_target_iou_kernel    per-anchor max / first argmax over gt, per-gt max over the inside anchors (LDS atomicMax
 //                               on the float bits, IoU >= 0, then one global atomicMax per gt and block)
 //   anchor_target_label_kernel  labels before subsampling (:109-124)
-//   anchor_target_lists_kernel  ascending fg / bg index lists + counts (one workgroup per image: an ordered compaction)
+//   anchor_target_lists_kernel  ascending fg / bg index lists + counts (one workgroup per image: an ordered compaction,
+//                               32 rounds of 1024 anchors per memory round trip)
 // The per-gt maxima live in the first n_gt ints of the image's fg_list row until the third launch overwrites them.
 __device__ __forceinline__ void load_gt(const float* __restrict__ gt, int b, int n_gt, float* sgt) {
   for (int k = threadIdx.x; k < n_gt; k += blockDim.x) {
@@ -303,46 +304,70 @@ anchor_target_label_kernel(const float* __restrict__ gt, const float* __restrict
   labels[(long)b * total + i] = label;
 }
 
-// grid = B, block = 1024
+// grid = B, block = 1024. One workgroup per image keeps the lists ordered without a second pass; what made it slow
+// (round 3: 35 us) was one memory round trip and two barriers PER 1024 anchors. Now a wave takes 64 consecutive anchors
+// per round and up to LISTS_R rounds of labels are requested together (one round trip per 32 768 anchors), every
+// (round, wave) pair's fg / bg counts go to LDS in one go, and each wave derives its own offsets from that table:
+// two barriers per super-chunk instead of two per round.
+constexpr int LISTS_R = 32;  // rounds of 1024 anchors in flight per super-chunk
 __global__ void __launch_bounds__(1024)
 anchor_target_lists_kernel(const float* __restrict__ labels, int total, int* __restrict__ fg_list,
                            int* __restrict__ bg_list, int* __restrict__ counts) {
-  __shared__ int wsum_fg[16], wsum_bg[16];
+  __shared__ unsigned short cnt_fg[LISTS_R][16], cnt_bg[LISTS_R][16];
   __shared__ int run_fg, run_bg;
   const int b = blockIdx.x;
   if (threadIdx.x == 0) run_fg = run_bg = 0;
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i0 = 0; i0 < total; i0 += blockDim.x) {
-    const int i = i0 + threadIdx.x;
-    const float label = i < total ? labels[(long)b * total + i] : -1.f;
-    const bool fg = label == 1.f, bg = label == 0.f;
-    const unsigned long long mf = __ballot(fg), mb = __ballot(bg);
-    if (lane == 0) {
-      wsum_fg[wave] = __builtin_popcountll(mf);
-      wsum_bg[wave] = __builtin_popcountll(mb);
+  const unsigned long long below = (1ULL << lane) - 1;
+  const float* lab = labels + (long)b * total;
+  for (int base = 0; base < total; base += LISTS_R * 1024) {
+    const int rounds = min(LISTS_R, (total - base + 1023) / 1024);
+    float v[LISTS_R];
+#pragma unroll
+    for (int r = 0; r < LISTS_R; ++r) {
+      const int i = base + r * 1024 + threadIdx.x;
+      v[r] = (r < rounds && i < total) ? lab[i] : -1.f;
     }
-    __syncthreads();
-    int off_fg = run_fg, off_bg = run_bg;
-    for (int w = 0; w < wave; ++w) {
-      off_fg += wsum_fg[w];
-      off_bg += wsum_bg[w];
-    }
-    const unsigned long long below = (1ULL << lane) - 1;
-    if (fg) fg_list[(long)b * total + off_fg + __builtin_popcountll(mf & below)] = i;
-    if (bg) bg_list[(long)b * total + off_bg + __builtin_popcountll(mb & below)] = i;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tf = 0, tb = 0;
-      for (int w = 0; w < 16; ++w) {
-        tf += wsum_fg[w];
-        tb += wsum_bg[w];
+#pragma unroll
+    for (int r = 0; r < LISTS_R; ++r) {
+      const unsigned long long mf = __ballot(v[r] == 1.f), mb = __ballot(v[r] == 0.f);
+      if (lane == 0 && r < rounds) {
+        cnt_fg[r][wave] = (unsigned short)__builtin_popcountll(mf);
+        cnt_bg[r][wave] = (unsigned short)__builtin_popcountll(mb);
       }
-      run_fg += tf;
-      run_bg += tb;
     }
-    __syncthreads();
+    __syncthreads();  // (also orders thread 0's run_* initialisation / update of the previous super-chunk)
+    // this wave's offset in round r = everything of earlier rounds + the earlier waves of round r: lanes 0..15 read one
+    // (round, wave) cell each, a 16-lane sum gives the round's total, a masked sum the part below this wave
+    int off_f = run_fg, off_b = run_bg;
+#pragma unroll
+    for (int r = 0; r < LISTS_R; ++r) {
+      if (r < rounds) {  // (uniform)
+        int cf = lane < 16 ? cnt_fg[r][lane] : 0, cb = lane < 16 ? cnt_bg[r][lane] : 0;
+        int bf = lane < wave ? cf : 0, bb = lane < wave ? cb : 0;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          cf += __shfl_xor(cf, o);
+          cb += __shfl_xor(cb, o);
+          bf += __shfl_xor(bf, o);
+          bb += __shfl_xor(bb, o);
+        }
+        cf = __shfl(cf, 0); cb = __shfl(cb, 0); bf = __shfl(bf, 0); bb = __shfl(bb, 0);
+        const int i = base + r * 1024 + threadIdx.x;
+        const unsigned long long mf = __ballot(v[r] == 1.f), mb = __ballot(v[r] == 0.f);  // (recomputed: 64 mask pairs
+        if (v[r] == 1.f) fg_list[(long)b * total + off_f + bf + __builtin_popcountll(mf & below)] = i;  //  would not fit
+        if (v[r] == 0.f) bg_list[(long)b * total + off_b + bb + __builtin_popcountll(mb & below)] = i;  //  the SGPR file)
+        off_f += cf;
+        off_b += cb;
+      }
+    }
+    __syncthreads();  // (every wave has read run_* and the table)
+    if (threadIdx.x == 0) {
+      run_fg = off_f;
+      run_bg = off_b;
+    }
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
     counts[b * 2 + 0] = run_fg;
     counts[b * 2 + 1] = run_bg;
