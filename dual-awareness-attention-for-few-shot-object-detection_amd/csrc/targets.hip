@@ -210,8 +210,7 @@ __device__ __forceinline__ float gt_iou(float4 a, float a_area, const float* __r
 //   anchor_target_iou_kernel    per-anchor max / first argmax over gt, per-gt max over the inside anchors (LDS atomicMax
 //                               on the float bits, IoU >= 0, then one global atomicMax per gt and block)
 //   anchor_target_label_kernel  labels before subsampling (:109-124)
-//   anchor_target_lists_kernel  ascending fg / bg index lists + counts (one workgroup per image: an ordered compaction,
-//                               32 rounds of 1024 anchors per memory round trip)
+//   anchor_target_lists_kernel  ascending fg / bg index lists + counts (an ordered compaction, one workgroup per 1024 anchors)
 // The per-gt maxima live in the first n_gt ints of the image's fg_list row until the third launch overwrites them.
 __device__ __forceinline__ void load_gt(const float* __restrict__ gt, int b, int n_gt, float* sgt) {
   for (int k = threadIdx.x; k < n_gt; k += blockDim.x) {
@@ -304,73 +303,91 @@ anchor_target_label_kernel(const float* __restrict__ gt, const float* __restrict
   labels[(long)b * total + i] = label;
 }
 
-// grid = B, block = 1024. One workgroup per image keeps the lists ordered without a second pass; what made it slow
-// (round 3: 35 us) was one memory round trip and two barriers PER 1024 anchors. Now a wave takes 64 consecutive anchors
-// per round and up to LISTS_R rounds of labels are requested together (one round trip per 32 768 anchors), every
-// (round, wave) pair's fg / bg counts go to LDS in one go, and each wave derives its own offsets from that table:
-// two barriers per super-chunk instead of two per round.
-constexpr int LISTS_R = 32;  // rounds of 1024 anchors in flight per super-chunk
-__global__ void __launch_bounds__(1024)
+// grid = (chunks of 1024 anchors, B), block = 256. Rounds 1-3 ran ONE 1024-thread workgroup per image: its ~5 000 wave
+// instructions were issue-bound on a single CU (16 waves on 4 SIMDs: 33-35 us, however the loads were batched). Now every
+// chunk is its own workgroup and there is no hand-off between them at all: a workgroup first counts the fg / bg anchors
+// in FRONT of its chunk itself (a strided read of at most `total` labels, L2-resident: ~22 loads per thread for the last
+// chunk of a 600 x 1000 image), then compacts its own 1024 anchors in order -- four consecutive anchors per thread, a
+// wave scan of the per-thread counts, the four waves' totals through LDS. No flags, no spinning, no dependence on the
+// dispatch order; the last chunk writes the image's counts.
+constexpr int LISTS_CHUNK = 1024;
+__global__ void __launch_bounds__(256)
 anchor_target_lists_kernel(const float* __restrict__ labels, int total, int* __restrict__ fg_list,
                            int* __restrict__ bg_list, int* __restrict__ counts) {
-  __shared__ unsigned short cnt_fg[LISTS_R][16], cnt_bg[LISTS_R][16];
-  __shared__ int run_fg, run_bg;
-  const int b = blockIdx.x;
-  if (threadIdx.x == 0) run_fg = run_bg = 0;
+  __shared__ int red_f[4], red_b[4], tot_f[4], tot_b[4];
+  const int b = blockIdx.y, c = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long below = (1ULL << lane) - 1;
   const float* lab = labels + (long)b * total;
-  for (int base = 0; base < total; base += LISTS_R * 1024) {
-    const int rounds = min(LISTS_R, (total - base + 1023) / 1024);
-    float v[LISTS_R];
+  // (1) anchors in front of the chunk
+  int pf = 0, pb = 0;
+  const int front = c * LISTS_CHUNK;
+  int i = threadIdx.x;
+  for (; i + 7 * 256 < front; i += 8 * 256) {
+    float v[8];
 #pragma unroll
-    for (int r = 0; r < LISTS_R; ++r) {
-      const int i = base + r * 1024 + threadIdx.x;
-      v[r] = (r < rounds && i < total) ? lab[i] : -1.f;
-    }
+    for (int u = 0; u < 8; ++u) v[u] = lab[i + u * 256];
 #pragma unroll
-    for (int r = 0; r < LISTS_R; ++r) {
-      const unsigned long long mf = __ballot(v[r] == 1.f), mb = __ballot(v[r] == 0.f);
-      if (lane == 0 && r < rounds) {
-        cnt_fg[r][wave] = (unsigned short)__builtin_popcountll(mf);
-        cnt_bg[r][wave] = (unsigned short)__builtin_popcountll(mb);
-      }
-    }
-    __syncthreads();  // (also orders thread 0's run_* initialisation / update of the previous super-chunk)
-    // this wave's offset in round r = everything of earlier rounds + the earlier waves of round r: lanes 0..15 read one
-    // (round, wave) cell each, a 16-lane sum gives the round's total, a masked sum the part below this wave
-    int off_f = run_fg, off_b = run_bg;
-#pragma unroll
-    for (int r = 0; r < LISTS_R; ++r) {
-      if (r < rounds) {  // (uniform)
-        int cf = lane < 16 ? cnt_fg[r][lane] : 0, cb = lane < 16 ? cnt_bg[r][lane] : 0;
-        int bf = lane < wave ? cf : 0, bb = lane < wave ? cb : 0;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          cf += __shfl_xor(cf, o);
-          cb += __shfl_xor(cb, o);
-          bf += __shfl_xor(bf, o);
-          bb += __shfl_xor(bb, o);
-        }
-        cf = __shfl(cf, 0); cb = __shfl(cb, 0); bf = __shfl(bf, 0); bb = __shfl(bb, 0);
-        const int i = base + r * 1024 + threadIdx.x;
-        const unsigned long long mf = __ballot(v[r] == 1.f), mb = __ballot(v[r] == 0.f);  // (recomputed: 64 mask pairs
-        if (v[r] == 1.f) fg_list[(long)b * total + off_f + bf + __builtin_popcountll(mf & below)] = i;  //  would not fit
-        if (v[r] == 0.f) bg_list[(long)b * total + off_b + bb + __builtin_popcountll(mb & below)] = i;  //  the SGPR file)
-        off_f += cf;
-        off_b += cb;
-      }
-    }
-    __syncthreads();  // (every wave has read run_* and the table)
-    if (threadIdx.x == 0) {
-      run_fg = off_f;
-      run_bg = off_b;
+    for (int u = 0; u < 8; ++u) {
+      pf += v[u] == 1.f;
+      pb += v[u] == 0.f;
     }
   }
+  for (; i < front; i += 256) {
+    const float v = lab[i];
+    pf += v == 1.f;
+    pb += v == 0.f;
+  }
+  // (2) this chunk: thread t owns anchors front + 4t .. front + 4t + 3
+  const int i0 = front + 4 * threadIdx.x;
+  float v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] = (i0 + u) < total ? lab[i0 + u] : -1.f;
+  int nf = 0, nb = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    nf += v[u] == 1.f;
+    nb += v[u] == 0.f;
+  }
+  // wave sums of the front counts, inclusive wave scans of the per-thread chunk counts
+  int sf = nf, sb = nb;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int tf = __shfl_up(sf, o), tb = __shfl_up(sb, o);
+    if (lane >= o) {
+      sf += tf;
+      sb += tb;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    pf += __shfl_xor(pf, o);
+    pb += __shfl_xor(pb, o);
+  }
+  if (lane == 63) {
+    tot_f[wave] = sf;
+    tot_b[wave] = sb;
+  }
+  if (lane == 0) {
+    red_f[wave] = pf;
+    red_b[wave] = pb;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    counts[b * 2 + 0] = run_fg;
-    counts[b * 2 + 1] = run_bg;
+  int off_f = red_f[0] + red_f[1] + red_f[2] + red_f[3] + (sf - nf);
+  int off_b = red_b[0] + red_b[1] + red_b[2] + red_b[3] + (sb - nb);
+  for (int w = 0; w < wave; ++w) {
+    off_f += tot_f[w];
+    off_b += tot_b[w];
+  }
+  int* fl = fg_list + (long)b * total;
+  int* bl = bg_list + (long)b * total;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (v[u] == 1.f) fl[off_f++] = i0 + u;
+    if (v[u] == 0.f) bl[off_b++] = i0 + u;
+  }
+  if (c == (int)gridDim.x - 1 && threadIdx.x == 255) {  // (the last thread of the last chunk has seen everything)
+    counts[b * 2 + 0] = off_f;
+    counts[b * 2 + 1] = off_b;
   }
 }
 
@@ -829,7 +846,7 @@ int dana_anchor_target_prepare(const float* gt_boxes, const float* im_info, cons
   anchor_target_iou_kernel<<<grid, 256, lds, s>>>(gt_boxes, im_info, base_anchors, g, max_overlaps, argmax, fg_list);
   anchor_target_label_kernel<<<grid, 256, lds, s>>>(gt_boxes, base_anchors, g, negative_overlap, positive_overlap,
                                                     max_overlaps, fg_list, labels);
-  anchor_target_lists_kernel<<<B, 1024, 0, s>>>(labels, total, fg_list, bg_list, counts);
+  anchor_target_lists_kernel<<<dim3(dana_ceil_div(total, LISTS_CHUNK), B), 256, 0, s>>>(labels, total, fg_list, bg_list, counts);
   DANA_CHECK_LAUNCH("dana_anchor_target_prepare");
   return DANA_OK;
 }
