@@ -181,3 +181,68 @@ def test_graphed_training_iteration_equals_trainer_step(dev, rccl):
     finally:
         if rccl:
             dist.destroy_process_group()
+
+
+def test_replays_keep_the_host_rng_count_and_the_warmup_keeps_np_random(dev):
+    """advisor round 3: (a) the device-RNG replays advance the device Philox counter; the host-side call count follows, so
+    an eager device-RNG forward AFTER the replays continues the stream instead of repeating the first draws; (b)
+    GraphedTrainer's eager warm-up iterations consume np.random draws in host-RNG mode: the state is restored with the
+    parameters, so the training trajectory does not depend on the warm-up."""
+    from dana_amd import synthetic as S
+    from dana_amd.graphs import GraphedDAnA, GraphedTrainer
+    from dana_amd.trainer import Trainer
+    m = _model(dev, ba=False)
+    m.device_rng = True
+    inputs = [t.to(dev) for t in S.episode_inputs(2, 2, 2, 192, 256, seed=9)]
+    m._rng_calls = 0
+    with torch.no_grad():
+        eager = [[t.clone() for t in m(*inputs)] for _ in range(4)]  # draws 0..3 of the counter sequence
+    m._rng_calls = 0
+    run = GraphedDAnA(m, *inputs, warmup=0)
+    m._rng_calls = 0
+    m._rng_counter(dev).zero_()
+    for k in range(3):
+        out = run(*inputs)
+        torch.cuda.synchronize()
+        _same(out, eager[k])
+    assert m._rng_calls == 3
+    with torch.no_grad():
+        nxt = m(*inputs)  # eager, device RNG: continues with draw 3, not draw 0
+    torch.cuda.synchronize()
+    _same(nxt, eager[3])
+    # (b)
+    m2 = _model(dev)
+    tr = Trainer(m2, 0.01)
+    tin = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=6)]
+    np.random.seed(77)
+    before = np.random.get_state()[1].copy()
+    p0 = _params(m2)
+    GraphedTrainer(tr, *tin, warmup=2)
+    assert np.array_equal(np.random.get_state()[1], before) and np.array_equal(_params(m2), p0) and tr.steps == 0
+
+
+def test_trainer_leaves_the_models_configured_forward_path_alone(dev):
+    """advisor round 3: the Trainer's shared [query | support] buffers are a preference for the forwards that save for ITS
+    backward only -- eval / inference / bench forwards of the same model keep merge_trunk / merge_from as configured, and
+    give the same bits as before the Trainer existed"""
+    from dana_amd import synthetic as S
+    from dana_amd.trainer import Trainer
+    m = _model(dev)
+    inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=6)]
+    np.random.seed(5)
+    with torch.no_grad():
+        ref = [t.clone() if torch.is_tensor(t) else t for t in m(*inputs)]
+    cfgd = (m.merge_trunk, m.merge_from)
+    tr = Trainer(m, 0.0)  # lr 0: the step leaves the weights alone
+    assert (m.merge_trunk, m.merge_from) == cfgd and m._train_merge == (True, 3)
+    np.random.seed(5)
+    out_t = tr.step(*inputs)  # saving forward: shared buffers (bit-identical outputs in every merge mode)
+    np.random.seed(5)
+    with torch.no_grad():
+        out = m(*inputs)
+    torch.cuda.synchronize()
+    _same(out, ref)
+    # (the saving forward keeps the two-output RoIAlign / two query GEMMs its backward reads, the forward-only run folds the
+    # positional encoding into one projection: same rois, scores equal to fp32 roundoff)
+    assert torch.equal(out_t[0], ref[0])
+    assert float((out_t[1] - ref[1]).abs().max()) <= 2e-6 and float((out_t[2] - ref[2]).abs().max()) <= 2e-5
