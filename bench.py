@@ -734,7 +734,7 @@ def main():
         # secondary object: the same forward with the training targets sampled by the device Philox RNG -- no host round
         # trip, so the whole forward is ONE hipGraph. Same distributions as the reference's np.random draws, another random
         # stream (which is why it is not the headline: the parity tests pin the host-RNG path). The one-graph replay has no
-        # host-issue gaps and no graph-to-graph hand-over (0.6 ms in the three-graph host-RNG replay: tools/r3_sync_gap.py).
+        # host-issue gaps and no graph-to-graph hand-over (0.6 ms in the three-graph host-RNG replay: tools/sync_gap.py).
         from dana_amd.graphs import GraphedDAnA
         model.device_rng = True
         try:

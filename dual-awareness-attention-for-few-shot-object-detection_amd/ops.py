@@ -49,7 +49,7 @@ _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 def _stream():
     """the caller's current HIP stream as a raw handle. torch.cuda.current_stream() builds a Stream object through
     several layers of Python (device index resolution, environment look-ups): 7.8 us per call, 1.4 ms of the eager
-    step's ~3 ms of host time (tools/r3_hostprof.py); the two C entry points below take 0.3 us."""
+    step's ~3 ms of host time (tools/hostprof.py); the two C entry points below take 0.3 us."""
     if _raw_stream is not None and _raw_device is not None:
         return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
@@ -481,7 +481,7 @@ def draw_and_upload(req, device, static=None):
     -- the list of anchors to disable, ~3 MB at 600 x 1000 -- run while the GPU still works on the trunk, on a copy stream
     of their own. The proposal counts are the one read that waits for the caller's stream; behind it only the proposal
     draws (~20-50 us) and a 2 KB upload stand between the GPU and the rest of the step (round 2 assembled and uploaded
-    everything as ONE array after the second read). Measured (tools/r3_sync_gap.py): the GPU idles 0.10 ms at this round
+    everything as ONE array after the second read). Measured (tools/sync_gap.py): the GPU idles 0.10 ms at this round
     trip in the eager forward -- and 0.63 ms when the two halves are hipGraphs (the runtime's end-of-graph hand-over, not
     host work: the host spends 70 us there; polling instead of a blocking read changes nothing), which is why the
     three-graph replay of the host-RNG forward loses to eager issue while the one-graph replay of the device-RNG forward
@@ -490,7 +490,7 @@ def draw_and_upload(req, device, static=None):
     B, R = req["B"], req["R"]
     lay = draw_layout(B, R, req["total"])
     gap = GAP_EVENTS
-    if gap is not None:  # (tools/r3_sync_gap.py: GPU time between the last kernel in front of the round trip and the first behind it)
+    if gap is not None:  # (tools/sync_gap.py: GPU time between the last kernel in front of the round trip and the first behind it)
         e_in = torch.cuda.Event(enable_timing=True)
         e_in.record()
     t0 = _time.perf_counter()

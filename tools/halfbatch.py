@@ -1,5 +1,5 @@
 """Two half-batches in flight: one hipGraph of the bs-4 train-mode forward (device RNG: the forward is ONE graph) against
-two bs-2 graphs replayed concurrently on two streams. usage: r3_halfbatch.py"""
+two bs-2 graphs replayed concurrently on two streams. usage: halfbatch.py"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""Which blocks of a launch share a CU? (dispatch order vs. CU slots; dana_set_igemm_trace) usage: r3_slots.py h"""
+"""Which blocks of a launch share a CU? (dispatch order vs. CU slots; dana_set_igemm_trace) usage: slots.py h"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of one split-kernel shape: bash tools/r3_sq.sh "<one_conv args>" tag
+# SQ counters of one split-kernel shape: bash tools/sq.sh "<one_conv args>" tag
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 ARGS=$1; TAG=$2

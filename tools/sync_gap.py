@@ -1,5 +1,5 @@
 """How long does the GPU idle at the training forward's host round trip? hipGraph replay, host RNG: events behind graph 1
-and in front of graph 2. usage: r3_sync_gap.py"""
+and in front of graph 2. usage: sync_gap.py"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

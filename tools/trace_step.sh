@@ -1,6 +1,6 @@
 #!/bin/bash
 # one step's kernel timeline of the default (two-stream, eager) forward: rocprofv3 --kernel-trace, then the rows of the
-# last complete step (marker = rcnn_loss_b_kernel) -> $O/step_trace.csv   usage: bash tools/r4_trace.sh <outdir> [bench args]
+# last complete step (marker = rcnn_loss_b_kernel) -> $O/step_trace.csv   usage: bash tools/trace_step.sh <outdir> [bench args]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-r4a}; shift
 mkdir -p $O

@@ -1,5 +1,5 @@
 """what-if timing of the eager training iteration (NOT numerically valid variants): where would the wall clock go if a
-piece were free? usage: r3_train_exp.py"""
+piece were free? usage: train_exp.py"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
