@@ -1157,6 +1157,8 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) 
   igemm_split_body<128, 128, STEM, BPRE, 0>(p);
 }
 
+#include "igemm_ws.h"
+
 // ---- skinny GEMM (N <= 8): one wave per output row, lanes split K (RCNN_bbox_pred 2048->4,
 // output_score_layer.linear2 1024->2: dana.py:246,304). HBM-bound on reading A once. ------------
 template <int NMAX>
@@ -1288,6 +1290,46 @@ std::atomic<int>& mfma_mode_cell() {
 }
 unsigned long long* g_trace = nullptr;  // debug: per-block timestamps of the next split launches (dana_set_igemm_trace)
 
+// The warp-specialised persistent kernel (igemm_ws.h) for GEMM-type launches -- EXPERIMENTAL, off by default (round 4: same
+// bits as igemm_split_kernel on every shape, 1.03-1.9x its duration). DANA_WS / dana_set_ws_mode: 0 off (default), 1 the
+// launches with >= 100 128 x 128 tiles and N > 64, 2 every eligible launch.
+std::atomic<int>& ws_mode_cell() {
+  static std::atomic<int> cell(getenv("DANA_WS") ? atoi(getenv("DANA_WS")) : 0);
+  return cell;
+}
+int ws_mode() { return ws_mode_cell().load(std::memory_order_relaxed); }
+bool ws_eligible(const IgemmParams& p, int batch, int stem) {
+  return !stem && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.A2 && p.M0 == p.M && !p.mask && p.vec_io &&
+         p.K >= 64 && p.K % 4 == 0 && p.N % 4 == 0 && (!p.residual || batch == 1);
+}
+int launch_ws(const IgemmParams& p0, int batch, hipStream_t s) {
+  IgemmParams p = p0;
+  p.tiles_m = (p.M + 127) / 128;
+  p.tiles_n = (p.N + 127) / 128;
+  const int total = p.tiles_m * p.tiles_n * batch;
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int grid = total < cus ? total : cus;
+  static bool attr_set[2] = {false, false};
+  if (p.bpre) {
+    if (!attr_set[1]) {
+      (void)hipFuncSetAttribute((const void*)igemm_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
+      attr_set[1] = true;
+    }
+    igemm_ws_kernel<1><<<grid, 768, WS_LDS_BYTES, s>>>(p, total);
+  } else {
+    if (!attr_set[0]) {
+      (void)hipFuncSetAttribute((const void*)igemm_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
+      attr_set[0] = true;
+    }
+    igemm_ws_kernel<0><<<grid, 768, WS_LDS_BYTES, s>>>(p, total);
+  }
+  return 0;
+}
+
 int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   if (stem) {
     const int smode = mfma_mode_cell().load(std::memory_order_relaxed);
@@ -1297,6 +1339,10 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   // dana_set_mfma_mode(0) / DANA_MFMA_SPLIT=0 selects the f32-MFMA kernel. 128x128 blocks amortise the split best; a
   // launch that cannot give most CUs one of those falls back to 64x64 blocks (measured: tools/conv_sweep.py).
   const int mode = mfma_mode_cell().load(std::memory_order_relaxed);
+  if (mode == 1 && ws_mode() && ws_eligible(p, batch, stem)) {
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+    if (ws_mode() == 2 || (p.N > 64 && t128 >= 100)) return launch_ws(p, batch, s);
+  }
   if (mode && p.KH * p.KW <= 32) {
     if (mode == 2) return launch_split<128, 64>(p, batch, s);
     if (mode == 3) return launch_split<64, 64>(p, batch, s);
@@ -1351,6 +1397,13 @@ int run(IgemmParams& p, int batch, int stem, hipStream_t s) {
 }  // namespace
 
 extern "C" {
+
+int dana_set_ws_mode(int mode) {
+  DANA_CHECK_ARG(mode >= 0 && mode <= 2, "dana_set_ws_mode: 0 (off), 1 (where it measured faster) or 2 (every eligible launch)");
+  ws_mode_cell().store(mode, std::memory_order_relaxed);
+  return DANA_OK;
+}
+int dana_get_ws_mode(void) { return ws_mode(); }
 
 int dana_set_mfma_mode(int mode) {
   DANA_CHECK_ARG(mode >= 0 && mode <= 5, "dana_set_mfma_mode: mode must be 0 (f32 MFMA) or 1 (bf16x6 split; 2-5: forced tiles)");

@@ -826,6 +826,14 @@ def set_mfma_mode(mode):
     return prev
 
 
+def set_ws_mode(mode):
+    """0 / 1 / 2: which GEMM-type launches take the warp-specialised persistent kernel (dana_set_ws_mode). Returns the
+    previous mode."""
+    prev = lib().query("dana_get_ws_mode")
+    lib().call("dana_set_ws_mode", int(mode))
+    return prev
+
+
 def get_mfma_mode():
     return lib().query("dana_get_mfma_mode")
 

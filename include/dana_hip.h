@@ -43,6 +43,14 @@ int dana_abi_version(void);
  * Replaces nothing in the reference: cuDNN picks its own algorithm / math mode there (lib/model/framework/resnet.py). */
 int dana_set_mfma_mode(int mode);
 int dana_get_mfma_mode(void);
+/* EXPERIMENTAL (round 4), off by default: which GEMM-type launches of the split kernel (1x1 / stride 1 / no padding
+ * contractions over one row range: every nn.Linear / bmm of dana.py:124-147,266-290 and the 1x1 convs of resnet.py:84-100)
+ * take the warp-specialised persistent form (csrc/igemm_ws.h: consumer waves multiply, stager waves load / split / stage the
+ * next K-steps and tiles, finisher waves run the previous tile's epilogue). 0 = none (default; environment DANA_WS), 1 = the
+ * launches with >= 100 tiles of 128 x 128 and n > 64, 2 = every eligible launch. Same results bit for bit; measured
+ * 1.03-1.9x the split kernel's duration, which is why it is off. A configuration call like dana_set_mfma_mode. */
+int dana_set_ws_mode(int mode);
+int dana_get_ws_mode(void);
 /* debug / profiling aid (tools/igemm_trace.py, gemm_power.py): while `buffer` is non-null every split-kernel block writes
  * eight 64-bit words {shader-clock at start, at the first K-step, after the K loop, at the end, HW_ID, 100 MHz wall clock
  * at the end, wall clock at the start, 0} at buffer[(z * grid + block) * 8]. The caller sizes the buffer for the launches it traces; null switches it off. */

@@ -428,3 +428,40 @@ def test_presplit_weights_are_bit_identical_to_fp32_weights(dev, mfma_mode):
     a, _, _ = ops.conv2d_nhwc(x4, 2, 64, 80, 4, wst, 64, 7, 7, 2, 3, relu=True, stem=True)
     b, _, _ = ops.conv2d_nhwc(x4, 2, 64, 80, 4, ops.split_weight(wst, 64, wst.numel() // 64), 64, 7, 7, 2, 3, relu=True, stem=True)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(9576, 1024, 256, True, 1, True), (1000, 200, 100, True, 1, False), (2394, 1200, 256, False, 4, False),
+                                   (640, 256, 256, False, 9, True), (300, 128, 64, False, 1, True), (25088, 128, 1024, True, 1, True)],
+                         ids=["l3-expand+res", "ragged-fp32B", "bmm-b4", "planes-b9", "one-round", "roi-proj+res"])
+def test_warp_specialised_kernel_gives_the_split_kernels_bits(dev, shape):
+    """csrc/igemm_ws.h (experimental, off by default: dana_set_ws_mode): consumer / stager / finisher waves and a persistent
+    walk over the tiles, but the same K-step order, the same six products in the same order, the same split and the same
+    epilogue arithmetic -> bit-identical to igemm_split_kernel, on full, ragged, batched, fp32-B and pre-split-B launches"""
+    from dana_amd import ops
+    if ops.get_mfma_mode() == 0:
+        pytest.skip("the warp-specialised form exists for the split kernel only")
+    m, n, k, res, batch, pre = shape
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(batch, m, k, generator=g).to(dev)
+    w = (torch.randn(batch, n, k, generator=g) * 0.05).to(dev)
+    sc, sh = (torch.rand(n, generator=g) + 0.5).to(dev), torch.randn(n, generator=g).to(dev)
+    r = torch.randn(m, n, generator=g).to(dev) if res else None
+    b3 = ops.split_weight(w.view(-1), n, k, batch=batch) if pre else None
+    outs = []
+    prev = ops.set_ws_mode(0)
+    try:
+        for mode in (0, 2):
+            ops.set_ws_mode(mode)
+            out = torch.full((batch, m, n), float("nan"), device=dev)
+            if batch > 1 and pre:
+                ops.lib().call("dana_gemm_nt", a.data_ptr(), b3.t.data_ptr(), out.data_ptr(), None, None, None, m, n, k, k, b3.kp, n,
+                               0, batch, m * k, 3 * n * b3.kp, m * n, 1.0, ops.W_SPLIT3, ops._stream())
+            elif batch > 1:
+                ops.gemm_nt(a, w, m, n, k, out=out, ldc=n, batch=batch, batch_a=m * k, batch_b=n * k, batch_c=m * n)
+            else:
+                ops.gemm_nt(a, b3 if pre else w, m, n, k, out=out, ldc=n, scale=sc, shift=sh, residual=r, relu=True)
+            outs.append(out)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_ws_mode(prev)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
