@@ -139,12 +139,12 @@ class WeightGrads:
         """the caller's stream waits for every weight-gradient launch issued so far"""
         if self.stream is None:
             self.compact.clear()
-            del _FRESH_GRADS[:]
+            del _FRESH.grads[:]
             return
         cur = torch.cuda.current_stream()
-        for t in _FRESH_GRADS:
+        for t in _FRESH.grads:
             t.record_stream(cur)
-        del _FRESH_GRADS[:]
+        del _FRESH.grads[:]
         for st, keep in self.side.values():
             if keep:
                 done = torch.cuda.Event()
@@ -286,7 +286,15 @@ def _ready(model, names):
         cb(names)
 
 
-_FRESH_GRADS = []  # gradients _acc() allocated since the last WeightGrads.join() (possibly in a side stream's pool)
+class _Fresh(__import__("threading").local):
+    """gradients _acc() allocated since the last WeightGrads.join() (possibly in a side stream's pool); per THREAD: under
+    nn.DataParallel every replica's backward runs in its own thread (train.py:104-105)"""
+
+    def __init__(self):
+        self.grads = []
+
+
+_FRESH = _Fresh()
 
 
 def _acc(param, g):
@@ -296,7 +304,7 @@ def _acc(param, g):
         # When this runs on the weight-gradient side stream, the clone's block belongs to THAT stream's pool, while the
         # optimizer / clipping / all-reduce read it on the caller's stream: join() marks it as used there
         param.grad = g.clone()
-        _FRESH_GRADS.append(param.grad)
+        _FRESH.grads.append(param.grad)
     else:
         param.grad.add_(g)
 
