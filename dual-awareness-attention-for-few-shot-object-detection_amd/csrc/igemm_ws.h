@@ -5,7 +5,7 @@
 // ablation showed: consumers alone hold 0.52 us per K-step (768 MFMA cycles = 0.41); the stagers' VALU / LDS
 // work on out-of-range loads costs +0.05; REAL loads cost +0.35 -- four K-steps of loads in flight per stager thread
 // (80 KB per CU, the split kernel's amount) do not cover the loaded latency when ONE tile per CU has to be fed at the
-// matrix pipe's full rate; a deeper ring does not fit the 168 registers of three waves per SIMD.
+// matrix pipe's full rate; a ring of six K-steps (it fits the stagers' registers) measured the same.
 //
 // Why: a 128 x 128 tile of igemm_split_kernel spends 7 800 cycles before its first MFMA and 1 700 .. 14 500 behind its
 // last one, against a K loop of 740 cycles per step and tile: at K = 256 the fixed phases are as long as the loop, and two
