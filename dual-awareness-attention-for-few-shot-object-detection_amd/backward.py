@@ -21,6 +21,7 @@ SAVED_WINOGRAD_V = __import__("os").environ.get("DANA_WGRAD_SAVED_V", "1") != "0
 PREFETCH_DGRAD_W = __import__("os").environ.get("DANA_PREFETCH_DGRAD_W", "1") != "0"  # trunk dgrad weights derived on a side stream
 LINEAR_WGRAD_ON_SIDE = __import__("os").environ.get("DANA_LINEAR_WGRAD_SIDE", "1") != "0"  # Linear dW / db off the dgrad chain
 GATHER_STRIDED_WGRAD = __import__("os").environ.get("DANA_WGRAD_GATHER", "1") != "0"
+RPN_CHAIN_EARLY = __import__("os").environ.get("DANA_RPN_CHAIN_EARLY", "1") != "0"  # RPN adjoints beside the RoI stage's
 
 
 class WeightGrads:
@@ -415,15 +416,99 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
                             seen.add(id(c))
                             _dgrad_weights(c)
 
-            derive(ctx["l4_saved"])  # (in the order the backward needs them: box branch, RPN conv, trunk)
-            l4w_ready = torch.cuda.Event()
-            l4w_ready.record()
+            # (in the order the backward needs them: the RPN chain and the box branch start at once, then the trunk)
             _dgrad_weights(c_rpn)
             rpnw_ready = torch.cuda.Event()
             rpnw_ready.record()
+            derive(ctx["l4_saved"])
+            l4w_ready = torch.cuda.Event()
+            l4w_ready.record()
             derive(ctx["q_saved"])
             dgw_ready = torch.cuda.Event()
             dgw_ready.record()
+
+    # -- RPN chain: RPN losses -> heads -> 3x3 conv -> RPN-level attention (rpn.py:58-115, dana.py:118-154). It depends on
+    #    the forward's saved tensors only and meets the RoI stage's gradients in base_feat / the support maps, so it runs
+    #    on a stream of its own FROM THE START of the backward, beside the box branch and the RoI heads (round 4: it used
+    #    to follow them on the caller's stream, 1.4 ms of launches with nothing beside them). Under stream capture its
+    #    weight gradients stay inline on the chain's stream (a side stream forked from an already forked stream crashes
+    #    hipStreamEndCapture on ROCm 7.2). --
+    main = torch.cuda.current_stream()
+    single = getattr(model, "_single_stream", False)
+    capturing = torch.cuda.is_current_stream_capturing()
+    rpn_early = RPN_CHAIN_EARLY and not single
+    rpn_stream = model._stream("rpn_bwd", dev) if rpn_early else main
+
+    def rpn_chain():
+        grads_r = grads if not rpn_early else WeightGrads(None if capturing else model._stream("wgrad_rpn", dev), model)
+        # -- RPN: losses -> heads -> 3x3 conv (rpn.py:58-115) --
+        rpn = model.RCNN_rpn
+        nh = ctx["nh"]
+        d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
+                                        inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0], grad_dev=g_dev)
+        ns = rpn.nc_score_out
+        grads_r.linear(d_heads, ctx["rpn_x"], B * hw, nh, 512,
+                     lambda dw, db: (_acc(rpn.RPN_cls_score.weight, dw[:ns]), _acc(rpn.RPN_cls_score.bias, db[:ns]),
+                                     _acc(rpn.RPN_bbox_pred.weight, dw[ns:]), _acc(rpn.RPN_bbox_pred.bias, db[ns:])))
+        _, _, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512, need_dw=False)
+        ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
+        if rpnw_ready is not None:
+            torch.cuda.current_stream().wait_event(rpnw_ready)
+        grads_r.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn, v=ctx.get("rpn_v"))
+        _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
+        d_corr = conv_dgrad(d_x, B, fh, fw, c_rpn)  # [B*hw][2048]
+
+        # -- RPN-level attention (dana.py:118-154): corr = [base_feat | dense] --
+        K1 = shot * L
+        s_pe, kp, qp, unary = ctx["s_pe"], ctx["kp"], ctx["qp"], ctx["unary"]
+        d_s_pe = torch.zeros((B, K1, 1024), dtype=torch.float32, device=dev)
+        d_kp = torch.zeros((B * K1, d), dtype=torch.float32, device=dev)
+        d_un = torch.zeros((B * shot, L), dtype=torch.float32, device=dev)
+        d_qp = _attention_backward(d_corr.view(-1)[1024:], 2048, ctx["scores"], unary, qp, kp, s_pe, B, hw, shot, L, K1, d,
+                                   ug, K1 * d, K1 * 1024, K1, d_kp, d_s_pe, d_un)
+        ops.colmean_sub_(d_qp, B, hw, d)
+        ops.colmean_sub_(d_kp, B * shot, L, d)
+        wq = model.rpn_adapt_q_layer.weight.detach()
+        grads_r.linear(d_qp, corr, B * hw, d, 1024,
+                     lambda dw, db: (_acc(model.rpn_adapt_q_layer.weight, dw), _acc(model.rpn_adapt_q_layer.bias, db)), ldx=2048)
+        ops.linear_backward(d_qp, corr, wq, B * hw, d, 1024, ldx=2048, dx_out=d_corr, dx_ld=2048, need_dw=False)
+        wk = model.rpn_adapt_k_layer.weight.detach()
+        grads_r.linear(d_kp, s_pe, B * K1, d, 1024,
+                     lambda dw, db: (_acc(model.rpn_adapt_k_layer.weight, dw), _acc(model.rpn_adapt_k_layer.bias, db)))
+        ops.linear_backward(d_kp, s_pe, wk, B * K1, d, 1024, dx_out=d_s_pe, dx_ld=1024, need_dw=False)
+        ops.softmax_rows_backward_(d_un, unary, B * shot, L)
+        wu = model.rpn_unary_layer.weight.detach()
+        _acc(model.rpn_unary_layer.weight, ops.rowdot_backward(s_pe, d_un, wu, B * K1, 1024, grad_x=d_s_pe))
+        _acc(model.rpn_unary_layer.bias, ops.colsum(d_un, B * K1, 1))
+        if model.semantic_enhance:  # BA block (dana.py:133-137)
+            s_pre, ba_w = ctx["s_pre"], ctx["ba_w"]
+            G = B * shot
+            gvec = torch.empty((G, 1024), dtype=torch.float32, device=dev)
+            gsum = torch.empty((G, 1024), dtype=torch.float32, device=dev)
+            dsf, spf = d_s_pe.view(-1), s_pre.view(-1)
+            for gi in range(G):
+                gv = ops.gemm_small(ba_w.view(-1)[gi * L:], (0, 1), spf[gi * L * 1024:], (1024, 1), 1, 1024, L)
+                gvec[gi].copy_(gv.view(-1))
+                gsum[gi].copy_(ops.colsum(dsf[gi * L * 1024:], L, 1024))
+            d_w = ops.ba_backward_(d_s_pe, s_pre, ba_w, gvec, gsum, G, L, 1024, gamma=model.channel_gamma, slope=0.01)
+            ops.softmax_rows_backward_(d_w, ba_w, G, L)
+            wc = model.rpn_channel_k_layer.weight.detach()
+            _acc(model.rpn_channel_k_layer.weight, ops.rowdot_backward(s_pre, d_w, wc, G * L, 1024, grad_x=d_s_pe))
+            _acc(model.rpn_channel_k_layer.bias, ops.colsum(d_w, G * L, 1))
+        grads_r.finish_all(model, "RCNN_rpn")
+        return d_corr, d_s_pe
+
+    rpn_out = rpn_done = None
+    if rpn_early:
+        start = torch.cuda.Event()
+        start.record()
+        rpn_stream.wait_event(start)
+        with torch.cuda.stream(rpn_stream):
+            rpn_out = rpn_chain()
+            for t_ in rpn_out:
+                t_.record_stream(main)
+            rpn_done = torch.cuda.Event()
+            rpn_done.record()
 
     # -- seeds: d RCNN losses / d (scores, bbox_pred) were written by the fused loss kernel (dana_rcnn_loss);
     #    the upstream scalars g3 / g4 ride as alpha on the first launches that consume them --
@@ -537,60 +622,16 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     grads.join()  # (the heads' Linear weight / bias gradients were accumulated on the weight-gradient stream)
     _ready(model, stages[1][1])
 
-    # -- RPN: losses -> heads -> 3x3 conv (rpn.py:58-115) --
-    rpn = model.RCNN_rpn
-    nh = ctx["nh"]
-    d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
-                                    inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0], grad_dev=g_dev)
-    ns = rpn.nc_score_out
-    grads.linear(d_heads, ctx["rpn_x"], B * hw, nh, 512,
-                 lambda dw, db: (_acc(rpn.RPN_cls_score.weight, dw[:ns]), _acc(rpn.RPN_cls_score.bias, db[:ns]),
-                                 _acc(rpn.RPN_bbox_pred.weight, dw[ns:]), _acc(rpn.RPN_bbox_pred.bias, db[ns:])))
-    _, _, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512, need_dw=False)
-    ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
-    if rpnw_ready is not None:
-        torch.cuda.current_stream().wait_event(rpnw_ready)
-    grads.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn, v=ctx.get("rpn_v"))
-    _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
-    d_corr = conv_dgrad(d_x, B, fh, fw, c_rpn)  # [B*hw][2048]
-
-    # -- RPN-level attention (dana.py:118-154): corr = [base_feat | dense] --
+    if rpn_early:
+        main.wait_event(rpn_done)
+        for n_ in stages[2][1]:  # (gradients first allocated on the chain's streams are read on the caller's from here on)
+            g_ = model.get_parameter(n_).grad
+            if g_ is not None:
+                g_.record_stream(main)
+    else:
+        rpn_out = rpn_chain()
+    d_corr, d_s_pe = rpn_out
     K1 = shot * L
-    s_pe, kp, qp, unary = ctx["s_pe"], ctx["kp"], ctx["qp"], ctx["unary"]
-    d_s_pe = torch.zeros((B, K1, 1024), dtype=torch.float32, device=dev)
-    d_kp = torch.zeros((B * K1, d), dtype=torch.float32, device=dev)
-    d_un = torch.zeros((B * shot, L), dtype=torch.float32, device=dev)
-    d_qp = _attention_backward(d_corr.view(-1)[1024:], 2048, ctx["scores"], unary, qp, kp, s_pe, B, hw, shot, L, K1, d,
-                               ug, K1 * d, K1 * 1024, K1, d_kp, d_s_pe, d_un)
-    ops.colmean_sub_(d_qp, B, hw, d)
-    ops.colmean_sub_(d_kp, B * shot, L, d)
-    wq = model.rpn_adapt_q_layer.weight.detach()
-    grads.linear(d_qp, corr, B * hw, d, 1024,
-                 lambda dw, db: (_acc(model.rpn_adapt_q_layer.weight, dw), _acc(model.rpn_adapt_q_layer.bias, db)), ldx=2048)
-    ops.linear_backward(d_qp, corr, wq, B * hw, d, 1024, ldx=2048, dx_out=d_corr, dx_ld=2048, need_dw=False)
-    wk = model.rpn_adapt_k_layer.weight.detach()
-    grads.linear(d_kp, s_pe, B * K1, d, 1024,
-                 lambda dw, db: (_acc(model.rpn_adapt_k_layer.weight, dw), _acc(model.rpn_adapt_k_layer.bias, db)))
-    ops.linear_backward(d_kp, s_pe, wk, B * K1, d, 1024, dx_out=d_s_pe, dx_ld=1024, need_dw=False)
-    ops.softmax_rows_backward_(d_un, unary, B * shot, L)
-    wu = model.rpn_unary_layer.weight.detach()
-    _acc(model.rpn_unary_layer.weight, ops.rowdot_backward(s_pe, d_un, wu, B * K1, 1024, grad_x=d_s_pe))
-    _acc(model.rpn_unary_layer.bias, ops.colsum(d_un, B * K1, 1))
-    if model.semantic_enhance:  # BA block (dana.py:133-137)
-        s_pre, ba_w = ctx["s_pre"], ctx["ba_w"]
-        G = B * shot
-        gvec = torch.empty((G, 1024), dtype=torch.float32, device=dev)
-        gsum = torch.empty((G, 1024), dtype=torch.float32, device=dev)
-        dsf, spf = d_s_pe.view(-1), s_pre.view(-1)
-        for gi in range(G):
-            gv = ops.gemm_small(ba_w.view(-1)[gi * L:], (0, 1), spf[gi * L * 1024:], (1024, 1), 1, 1024, L)
-            gvec[gi].copy_(gv.view(-1))
-            gsum[gi].copy_(ops.colsum(dsf[gi * L * 1024:], L, 1024))
-        d_w = ops.ba_backward_(d_s_pe, s_pre, ba_w, gvec, gsum, G, L, 1024, gamma=model.channel_gamma, slope=0.01)
-        ops.softmax_rows_backward_(d_w, ba_w, G, L)
-        wc = model.rpn_channel_k_layer.weight.detach()
-        _acc(model.rpn_channel_k_layer.weight, ops.rowdot_backward(s_pre, d_w, wc, G * L, 1024, grad_x=d_s_pe))
-        _acc(model.rpn_channel_k_layer.bias, ops.colsum(d_w, G * L, 1))
     for b in range(B):  # the positive supports' PE-added maps (dana.py:103,130)
         ops.axpy_rows_(d_sup.view(-1)[b * way * shot * L * 1024:], d_s_pe[b], K1, 1024)
     grads.finish_all(model, "RCNN_rpn")
