@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 REPS=${REPS:-2}; STEPS=${STEPS:-60}; MODE=${MODE:-train}
-run() { env $1 timeout 900 python bench.py --mode $MODE --no-cpu-baseline --no-pmc --no-train-step --no-secondary --steps $STEPS $EXTRA 2>/dev/null | python -c "
+run() { env $1 timeout ${TMO:-900} python bench.py --mode $MODE --no-cpu-baseline --no-pmc --no-train-step --no-secondary --steps $STEPS $EXTRA 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); r=j.get('roofline') or {}
 f=r.get('families',{})
