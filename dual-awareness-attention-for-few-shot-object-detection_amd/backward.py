@@ -336,6 +336,90 @@ def _attention_backward(d_dense, ld_dd, a, unary, q, k_, s_mat, Bn, rows_b, nseg
     return d_q.view(Bn * rows_b, dq)
 
 
+def _rpn_conv_plan(model, ctx):
+    """the RPN 3x3 conv as a plan entry, one per saved forward (its data-gradient weights are derived into it once)"""
+    c = ctx.get("_c_rpn")
+    if c is None:
+        plan = ctx["plan"]
+        c = ctx["_c_rpn"] = dict(cin=model.RCNN_rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None,
+                                 u=plan["rpn_conv_u"])
+    return c
+
+
+def _rpn_chain(model, ctx, g1, g2, g_dev, grads_r, rpnw_ready=None):
+    """Adjoint of the RPN branch: RPN losses -> heads -> 3x3 conv -> RPN-level attention (rpn.py:58-115, dana.py:118-154),
+    on the CURRENT stream. It reads the forward's saved tensors only; -> (d_corr [B*hw][2048]: the gradient into
+    [base_feat | attended], d_s_pe [B][shot*L][1024]: into the positive supports' PE-added maps). Weight gradients of the
+    branch are accumulated into .grad (through grads_r) before it returns."""
+    plan = ctx["plan"]
+    B, shot = ctx["B"], ctx["shot"]
+    fh, fw = ctx["fh"], ctx["fw"]
+    hw = fh * fw
+    L = ctx["s_pe"].size(1) // shot
+    d = model.rpn_reduce_dim
+    corr = ctx["corr"]
+    dev = corr.device
+    ug = model.unary_gamma
+    c_rpn = _rpn_conv_plan(model, ctx)
+    # -- RPN: losses -> heads -> 3x3 conv (rpn.py:58-115) --
+    rpn = model.RCNN_rpn
+    nh = ctx["nh"]
+    d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
+                                    inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0], grad_dev=g_dev)
+    ns = rpn.nc_score_out
+    grads_r.linear(d_heads, ctx["rpn_x"], B * hw, nh, 512,
+                 lambda dw, db: (_acc(rpn.RPN_cls_score.weight, dw[:ns]), _acc(rpn.RPN_cls_score.bias, db[:ns]),
+                                 _acc(rpn.RPN_bbox_pred.weight, dw[ns:]), _acc(rpn.RPN_bbox_pred.bias, db[ns:])))
+    _, _, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512, need_dw=False)
+    ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
+    if rpnw_ready is not None:
+        torch.cuda.current_stream().wait_event(rpnw_ready)
+    grads_r.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn, v=ctx.get("rpn_v"))
+    _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
+    d_corr = conv_dgrad(d_x, B, fh, fw, c_rpn)  # [B*hw][2048]
+
+    # -- RPN-level attention (dana.py:118-154): corr = [base_feat | dense] --
+    K1 = shot * L
+    s_pe, kp, qp, unary = ctx["s_pe"], ctx["kp"], ctx["qp"], ctx["unary"]
+    d_s_pe = torch.zeros((B, K1, 1024), dtype=torch.float32, device=dev)
+    d_kp = torch.zeros((B * K1, d), dtype=torch.float32, device=dev)
+    d_un = torch.zeros((B * shot, L), dtype=torch.float32, device=dev)
+    d_qp = _attention_backward(d_corr.view(-1)[1024:], 2048, ctx["scores"], unary, qp, kp, s_pe, B, hw, shot, L, K1, d,
+                               ug, K1 * d, K1 * 1024, K1, d_kp, d_s_pe, d_un)
+    ops.colmean_sub_(d_qp, B, hw, d)
+    ops.colmean_sub_(d_kp, B * shot, L, d)
+    wq = model.rpn_adapt_q_layer.weight.detach()
+    grads_r.linear(d_qp, corr, B * hw, d, 1024,
+                 lambda dw, db: (_acc(model.rpn_adapt_q_layer.weight, dw), _acc(model.rpn_adapt_q_layer.bias, db)), ldx=2048)
+    ops.linear_backward(d_qp, corr, wq, B * hw, d, 1024, ldx=2048, dx_out=d_corr, dx_ld=2048, need_dw=False)
+    wk = model.rpn_adapt_k_layer.weight.detach()
+    grads_r.linear(d_kp, s_pe, B * K1, d, 1024,
+                 lambda dw, db: (_acc(model.rpn_adapt_k_layer.weight, dw), _acc(model.rpn_adapt_k_layer.bias, db)))
+    ops.linear_backward(d_kp, s_pe, wk, B * K1, d, 1024, dx_out=d_s_pe, dx_ld=1024, need_dw=False)
+    ops.softmax_rows_backward_(d_un, unary, B * shot, L)
+    wu = model.rpn_unary_layer.weight.detach()
+    _acc(model.rpn_unary_layer.weight, ops.rowdot_backward(s_pe, d_un, wu, B * K1, 1024, grad_x=d_s_pe))
+    _acc(model.rpn_unary_layer.bias, ops.colsum(d_un, B * K1, 1))
+    if model.semantic_enhance:  # BA block (dana.py:133-137)
+        s_pre, ba_w = ctx["s_pre"], ctx["ba_w"]
+        G = B * shot
+        gvec = torch.empty((G, 1024), dtype=torch.float32, device=dev)
+        gsum = torch.empty((G, 1024), dtype=torch.float32, device=dev)
+        dsf, spf = d_s_pe.view(-1), s_pre.view(-1)
+        for gi in range(G):
+            gv = ops.gemm_small(ba_w.view(-1)[gi * L:], (0, 1), spf[gi * L * 1024:], (1024, 1), 1, 1024, L)
+            gvec[gi].copy_(gv.view(-1))
+            gsum[gi].copy_(ops.colsum(dsf[gi * L * 1024:], L, 1024))
+        d_w = ops.ba_backward_(d_s_pe, s_pre, ba_w, gvec, gsum, G, L, 1024, gamma=model.channel_gamma, slope=0.01)
+        ops.softmax_rows_backward_(d_w, ba_w, G, L)
+        wc = model.rpn_channel_k_layer.weight.detach()
+        _acc(model.rpn_channel_k_layer.weight, ops.rowdot_backward(s_pre, d_w, wc, G * L, 1024, grad_x=d_s_pe))
+        _acc(model.rpn_channel_k_layer.bias, ops.colsum(d_w, G * L, 1))
+    grads_r.finish_all(model, "RCNN_rpn")
+    return d_corr, d_s_pe
+
+
+
 def _take_ctx(model, ctx):
     """the saved-for-backward context to differentiate: the one handed in (the loss bridge captured it at forward time)
     or the model's latest. A context is consumed exactly once; its tensors are released here."""
@@ -398,7 +482,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     #    instead of one by one in front of the trunk's data-gradient launches that need them (the chain every other
     #    launch of the trunk's backward waits for); joined into the caller's stream before the pause below --
     rpn = model.RCNN_rpn
-    c_rpn = dict(cin=rpn.din, cout=512, k=3, stride=1, pad=1, w=plan["rpn_conv_w"], scale=None, u=plan["rpn_conv_u"])
+    c_rpn = _rpn_conv_plan(model, ctx)
     dgw_ready = l4w_ready = rpnw_ready = None
     if PREFETCH_DGRAD_W and not getattr(model, "_single_stream", False):
         prep = model._stream("dgradw", dev)
@@ -427,84 +511,27 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
             dgw_ready = torch.cuda.Event()
             dgw_ready.record()
 
-    # -- RPN chain: RPN losses -> heads -> 3x3 conv -> RPN-level attention (rpn.py:58-115, dana.py:118-154). It depends on
-    #    the forward's saved tensors only and meets the RoI stage's gradients in base_feat / the support maps, so it runs
-    #    on a stream of its own FROM THE START of the backward, beside the box branch and the RoI heads (round 4: it used
-    #    to follow them on the caller's stream, 1.4 ms of launches with nothing beside them). Under stream capture its
-    #    weight gradients stay inline on the chain's stream (a side stream forked from an already forked stream crashes
-    #    hipStreamEndCapture on ROCm 7.2). --
+    # -- RPN chain (_rpn_chain). It depends on the forward's saved tensors only and meets the RoI stage's gradients in
+    #    base_feat / the support maps, so it runs on a stream of its own FROM THE START of the backward, beside the box
+    #    branch and the RoI heads (round 4: it used to follow them on the caller's stream, 1.4 ms of launches with nothing
+    #    beside them). Under stream capture its weight gradients stay inline on the chain's stream (a side stream forked
+    #    from an already forked stream crashes hipStreamEndCapture on ROCm 7.2). Issuing the chain even earlier -- from the
+    #    eager forward, right behind the RPN head, under the proposal layer and the host round trip -- was built and
+    #    measured: +-0 (18.10 / 18.03 vs 18.07 ms): the eager iteration is host-bound there, the chain's ~100 launches
+    #    delay the host's count read by what they save on the GPU. --
     main = torch.cuda.current_stream()
     single = getattr(model, "_single_stream", False)
     capturing = torch.cuda.is_current_stream_capturing()
     rpn_early = RPN_CHAIN_EARLY and not single
-    rpn_stream = model._stream("rpn_bwd", dev) if rpn_early else main
-
-    def rpn_chain():
-        grads_r = grads if not rpn_early else WeightGrads(None if capturing else model._stream("wgrad_rpn", dev), model)
-        # -- RPN: losses -> heads -> 3x3 conv (rpn.py:58-115) --
-        rpn = model.RCNN_rpn
-        nh = ctx["nh"]
-        d_heads = ops.rpn_loss_backward(ctx["rpn_heads"], nh, ctx["at"], ctx["rpn_l"], g1, g2, sigma=3.0,
-                                        inside_weight=cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0], grad_dev=g_dev)
-        ns = rpn.nc_score_out
-        grads_r.linear(d_heads, ctx["rpn_x"], B * hw, nh, 512,
-                     lambda dw, db: (_acc(rpn.RPN_cls_score.weight, dw[:ns]), _acc(rpn.RPN_cls_score.bias, db[:ns]),
-                                     _acc(rpn.RPN_bbox_pred.weight, dw[ns:]), _acc(rpn.RPN_bbox_pred.bias, db[ns:])))
-        _, _, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512, need_dw=False)
-        ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
-        if rpnw_ready is not None:
-            torch.cuda.current_stream().wait_event(rpnw_ready)
-        grads_r.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn, v=ctx.get("rpn_v"))
-        _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
-        d_corr = conv_dgrad(d_x, B, fh, fw, c_rpn)  # [B*hw][2048]
-
-        # -- RPN-level attention (dana.py:118-154): corr = [base_feat | dense] --
-        K1 = shot * L
-        s_pe, kp, qp, unary = ctx["s_pe"], ctx["kp"], ctx["qp"], ctx["unary"]
-        d_s_pe = torch.zeros((B, K1, 1024), dtype=torch.float32, device=dev)
-        d_kp = torch.zeros((B * K1, d), dtype=torch.float32, device=dev)
-        d_un = torch.zeros((B * shot, L), dtype=torch.float32, device=dev)
-        d_qp = _attention_backward(d_corr.view(-1)[1024:], 2048, ctx["scores"], unary, qp, kp, s_pe, B, hw, shot, L, K1, d,
-                                   ug, K1 * d, K1 * 1024, K1, d_kp, d_s_pe, d_un)
-        ops.colmean_sub_(d_qp, B, hw, d)
-        ops.colmean_sub_(d_kp, B * shot, L, d)
-        wq = model.rpn_adapt_q_layer.weight.detach()
-        grads_r.linear(d_qp, corr, B * hw, d, 1024,
-                     lambda dw, db: (_acc(model.rpn_adapt_q_layer.weight, dw), _acc(model.rpn_adapt_q_layer.bias, db)), ldx=2048)
-        ops.linear_backward(d_qp, corr, wq, B * hw, d, 1024, ldx=2048, dx_out=d_corr, dx_ld=2048, need_dw=False)
-        wk = model.rpn_adapt_k_layer.weight.detach()
-        grads_r.linear(d_kp, s_pe, B * K1, d, 1024,
-                     lambda dw, db: (_acc(model.rpn_adapt_k_layer.weight, dw), _acc(model.rpn_adapt_k_layer.bias, db)))
-        ops.linear_backward(d_kp, s_pe, wk, B * K1, d, 1024, dx_out=d_s_pe, dx_ld=1024, need_dw=False)
-        ops.softmax_rows_backward_(d_un, unary, B * shot, L)
-        wu = model.rpn_unary_layer.weight.detach()
-        _acc(model.rpn_unary_layer.weight, ops.rowdot_backward(s_pe, d_un, wu, B * K1, 1024, grad_x=d_s_pe))
-        _acc(model.rpn_unary_layer.bias, ops.colsum(d_un, B * K1, 1))
-        if model.semantic_enhance:  # BA block (dana.py:133-137)
-            s_pre, ba_w = ctx["s_pre"], ctx["ba_w"]
-            G = B * shot
-            gvec = torch.empty((G, 1024), dtype=torch.float32, device=dev)
-            gsum = torch.empty((G, 1024), dtype=torch.float32, device=dev)
-            dsf, spf = d_s_pe.view(-1), s_pre.view(-1)
-            for gi in range(G):
-                gv = ops.gemm_small(ba_w.view(-1)[gi * L:], (0, 1), spf[gi * L * 1024:], (1024, 1), 1, 1024, L)
-                gvec[gi].copy_(gv.view(-1))
-                gsum[gi].copy_(ops.colsum(dsf[gi * L * 1024:], L, 1024))
-            d_w = ops.ba_backward_(d_s_pe, s_pre, ba_w, gvec, gsum, G, L, 1024, gamma=model.channel_gamma, slope=0.01)
-            ops.softmax_rows_backward_(d_w, ba_w, G, L)
-            wc = model.rpn_channel_k_layer.weight.detach()
-            _acc(model.rpn_channel_k_layer.weight, ops.rowdot_backward(s_pre, d_w, wc, G * L, 1024, grad_x=d_s_pe))
-            _acc(model.rpn_channel_k_layer.bias, ops.colsum(d_w, G * L, 1))
-        grads_r.finish_all(model, "RCNN_rpn")
-        return d_corr, d_s_pe
-
     rpn_out = rpn_done = None
     if rpn_early:
+        rpn_stream = model._stream("rpn_bwd", dev)
         start = torch.cuda.Event()
         start.record()
         rpn_stream.wait_event(start)
         with torch.cuda.stream(rpn_stream):
-            rpn_out = rpn_chain()
+            grads_r = WeightGrads(None if capturing else model._stream("wgrad_rpn", dev), model)
+            rpn_out = _rpn_chain(model, ctx, g1, g2, g_dev, grads_r, rpnw_ready)
             for t_ in rpn_out:
                 t_.record_stream(main)
             rpn_done = torch.cuda.Event()
@@ -629,7 +656,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
             if g_ is not None:
                 g_.record_stream(main)
     else:
-        rpn_out = rpn_chain()
+        rpn_out = _rpn_chain(model, ctx, g1, g2, g_dev, grads, rpnw_ready)
     d_corr, d_s_pe = rpn_out
     K1 = shot * L
     for b in range(B):  # the positive supports' PE-added maps (dana.py:103,130)

@@ -15,6 +15,8 @@
 
 namespace {
 
+int g_sort_mode = 0;  // dana_set_library_sort: 0 = measured dispatch, 1 = always the library sort, 2 = the hand-written kernel wherever it can run
+
 // one lane per (image, cell k=h*W+w, anchor a); output index i = k*A + a (proposal_layer.py:98-103)
 __global__ void __launch_bounds__(256)
 rpn_decode_kernel(const float* __restrict__ cls, long cls_sb, long cls_sc, long cls_sp, int cls_is_prob,
@@ -155,6 +157,279 @@ detect_decode_kernel(const float* __restrict__ rois, const float* __restrict__ c
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __builtin_popcountll(m));
 }
 
+// ---- hand-written top-k + sort (round 4): proposal_layer.py:135-150 sorts every anchor's score and keeps the first
+// pre_nms_topN. One 1024-lane workgroup per image does exactly that and nothing more:
+//   1. keys ~monotone(score) (ascending = descending score) live in REGISTERS, up to 40 per lane;
+//   2. radix select, 4 passes of 8 bits from the top: the key T of rank topn and how many of its ties belong to the top
+//      (histograms in LDS, one atomic per distinct digit and wave: lanes with equal digits are matched with 8 ballots);
+//   3. ordered compaction of {key < T} and the first ties {key == T} in index order into LDS (key 32 bit, index 16 bit);
+//   4. stable LSD radix sort of those <= 12 288 pairs in LDS, 4 passes of 8 bits: every wave owns a contiguous run, ranks
+//      its keys per digit with the same ballot match (no atomics), digit-major / wave-minor scan of the 16 x 256 counts,
+//      scatter to the other LDS buffer; a pass whose keys all share one digit is skipped;
+//   5. the indices (and optionally the scores) go out in order.
+// Same result as a stable descending sort cut at topn (ties in ascending index order) -- rocPRIM's device-wide radix sort
+// of all B x n 64-bit keys takes 8-10 launches. Can run when n <= 40 960 and min(topn, n) <= 12 288; WHERE it runs is
+// decided by measurement (topk_preferred below).
+constexpr int TK_THREADS = 1024, TK_WAVES = 16, TK_CAP = 12288, TK_MAXR = 40, TK_SEGR = TK_CAP / (TK_WAVES * 64);
+// (the kernel is instantiated for <= 24 and <= 40 register-resident keys per lane: rows of <= 24 576 / <= 40 960 scores)
+struct TopkSmem {
+  unsigned keys[2][TK_CAP];
+  unsigned short idx[2][TK_CAP];
+  unsigned short cnt[TK_WAVES][256];
+  unsigned hist[256];
+  unsigned tot[256];
+  unsigned wsum[2][2][TK_WAVES];
+  unsigned bc[4];
+};
+
+// lanes of `act` whose 8-bit digit equals this lane's
+__device__ __forceinline__ unsigned long long match_digit(unsigned d, bool in, unsigned long long act) {
+  unsigned long long m = act;
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    const bool one = (d >> bit) & 1u;
+    const unsigned long long bal = __ballot(in && one);
+    m &= one ? bal : ~bal;
+  }
+  return m;
+}
+
+template <int MAXR>
+__global__ void __launch_bounds__(TK_THREADS)
+topk_sort_kernel(const float* __restrict__ scores, int n, int topn, int* __restrict__ order, int order_stride,
+                 float* __restrict__ sorted_scores) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tk_raw[];
+  TopkSmem& sm = *reinterpret_cast<TopkSmem*>(tk_raw);
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const float* sc = scores + (long)b * n;
+  const int m = topn < n ? topn : n;  // pairs that get sorted
+  const int R = (n + TK_THREADS - 1) / TK_THREADS;
+
+  if (n > topn) {
+    unsigned K[MAXR];
+#pragma unroll
+    for (int j = 0; j < MAXR; ++j) {
+      const int i = j * TK_THREADS + tid;
+      K[j] = (j < R && i < n) ? ~monotone_bits(sc[i]) : 0xFFFFFFFFu;
+    }
+    // ---- radix select: T = key of rank topn (ascending), k = how many keys == T belong to the first topn ----
+    unsigned prefix = 0;
+    int k = topn;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) sm.hist[tid] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < MAXR; ++j) {
+        if (j < R) {
+          const int i = j * TK_THREADS + tid;
+          const bool in = i < n && (shift == 24 || (K[j] >> (shift + 8)) == prefix);
+          const unsigned d = (K[j] >> shift) & 255u;
+          const unsigned long long act = __ballot(in);
+          if (act) {
+            const unsigned long long mm = match_digit(d, in, act);
+            if (in && (mm & lt_mask) == 0) atomicAdd(&sm.hist[d], (unsigned)__builtin_popcountll(mm));
+          }
+        }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        unsigned c[4], s = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          c[q] = sm.hist[4 * lane + q];
+          s += c[q];
+        }
+        unsigned incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned t = __shfl_up(incl, off);
+          if (lane >= off) incl += t;
+        }
+        unsigned before = incl - s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if ((int)before < k && k <= (int)(before + c[q])) {
+            sm.bc[0] = 4 * lane + q;
+            sm.bc[1] = (unsigned)k - before;
+          }
+          before += c[q];
+        }
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | sm.bc[0];
+      k = (int)sm.bc[1];
+      __syncthreads();
+    }
+    const unsigned T = prefix;
+    // ---- ordered compaction (index order): keys < T, and the first k keys == T ----
+    unsigned run_eq = 0, run_sel = 0;
+#pragma unroll
+    for (int j = 0; j < MAXR; ++j) {
+      if (j < R) {
+      const int i = j * TK_THREADS + tid;
+      const bool valid = i < n;
+      const bool lt = valid && K[j] < T, eq = valid && K[j] == T;
+      const unsigned long long be = __ballot(eq);
+      unsigned(*ws)[TK_WAVES] = sm.wsum[j & 1];
+      if (lane == 0) ws[0][wave] = (unsigned)__builtin_popcountll(be);
+      __syncthreads();
+      unsigned eq_before = run_eq, eq_all = 0;
+#pragma unroll
+      for (int w = 0; w < TK_WAVES; ++w) {
+        const unsigned cw = ws[0][w];
+        if (w < wave) eq_before += cw;
+        eq_all += cw;
+      }
+      eq_before += (unsigned)__builtin_popcountll(be & lt_mask);
+      const bool sel = lt || (eq && (int)eq_before < k);
+      const unsigned long long bs = __ballot(sel);
+      if (lane == 0) ws[1][wave] = (unsigned)__builtin_popcountll(bs);
+      __syncthreads();
+      unsigned pos = run_sel, sel_all = 0;
+#pragma unroll
+      for (int w = 0; w < TK_WAVES; ++w) {
+        const unsigned cw = ws[1][w];
+        if (w < wave) pos += cw;
+        sel_all += cw;
+      }
+      pos += (unsigned)__builtin_popcountll(bs & lt_mask);
+      if (sel) {
+        sm.keys[0][pos] = K[j];
+        sm.idx[0][pos] = (unsigned short)i;
+      }
+      run_eq += eq_all;
+      run_sel += sel_all;
+      }
+    }
+  } else {
+    for (int i = tid; i < n; i += TK_THREADS) {
+      sm.keys[0][i] = ~monotone_bits(sc[i]);
+      sm.idx[0][i] = (unsigned short)i;
+    }
+  }
+  __syncthreads();
+
+  // ---- stable LSD radix sort of m (key, index) pairs in LDS ----
+  const int seg = (m + TK_WAVES * 64 - 1) / (TK_WAVES * 64) * 64;  // elements per wave, a multiple of 64
+  const int RW = seg / 64;
+  int cur = 0;
+  for (int shift = 0; shift < 32; shift += 8) {
+    unsigned kk[TK_SEGR];
+    unsigned short ii[TK_SEGR], rk[TK_SEGR];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sm.cnt[wave][4 * lane + q] = 0;
+#pragma unroll
+    for (int r = 0; r < TK_SEGR; ++r) {
+      const int e = wave * seg + r * 64 + lane;
+      const bool valid = r < RW && e < m;
+      kk[r] = valid ? sm.keys[cur][e] : 0u;
+      ii[r] = valid ? sm.idx[cur][e] : (unsigned short)0;
+      const unsigned d = (kk[r] >> shift) & 255u;
+      const unsigned long long act = __ballot(valid);
+      unsigned base = 0;
+      unsigned long long mm = 1ull << lane;
+      if (act) {
+        mm = match_digit(d, valid, act);
+        if (valid && (mm & lt_mask) == 0) {
+          base = sm.cnt[wave][d];
+          sm.cnt[wave][d] = (unsigned short)(base + (unsigned)__builtin_popcountll(mm));
+        }
+      }
+      const int leader = valid ? __builtin_ctzll(mm) : lane;
+      base = __shfl(base, leader);
+      rk[r] = (unsigned short)(base + (unsigned)__builtin_popcountll(mm & lt_mask));
+    }
+    __syncthreads();
+    if (tid < 256) {  // digit-major, wave-minor: exclusive prefix over the waves, total per digit
+      unsigned run = 0;
+#pragma unroll
+      for (int w = 0; w < TK_WAVES; ++w) {
+        const unsigned c = sm.cnt[w][tid];
+        sm.cnt[w][tid] = (unsigned short)run;
+        run += c;
+      }
+      sm.tot[tid] = run;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      unsigned c[4], s = 0;
+      bool one_digit = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        c[q] = sm.tot[4 * lane + q];
+        s += c[q];
+        one_digit |= c[q] == (unsigned)m;
+      }
+      unsigned incl = s;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      unsigned before = incl - s;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sm.tot[4 * lane + q] = before;
+        before += c[q];
+      }
+      const unsigned long long any = __ballot(one_digit);
+      if (lane == 0) sm.bc[2] = any ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool skip = sm.bc[2] != 0;  // every key has the same digit: the pass is the identity
+    if (!skip) {
+#pragma unroll
+      for (int r = 0; r < TK_SEGR; ++r) {
+        const int e = wave * seg + r * 64 + lane;
+        if (r < RW && e < m) {
+          const unsigned d = (kk[r] >> shift) & 255u;
+          const unsigned dst = sm.tot[d] + sm.cnt[wave][d] + rk[r];
+          sm.keys[cur ^ 1][dst] = kk[r];
+          sm.idx[cur ^ 1][dst] = ii[r];
+        }
+      }
+      cur ^= 1;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < m; e += TK_THREADS) {
+    order[(long)b * order_stride + e] = (int)sm.idx[cur][e];
+    if (sorted_scores) sorted_scores[(long)b * order_stride + e] = from_monotone_bits(~sm.keys[cur][e]);
+  }
+}
+
+// Measured (tools/topk_bench.py, one MI355X): ONE workgroup per row is all of 4 SIMDs -- 19 us against the library's 27 us for
+// a row of 300 scores (detection post-processing), but 122 vs 102 us for 4 x 21 546 -> 12 000 and 177 vs 87 us for
+// 2 x 37 800 -> 12 000: the ballot matches of ~100 000 (key, pass) pairs serialise on one CU while rocPRIM spreads its passes
+// over the chip. So the hand-written kernel takes rows of <= 4 096 scores and the proposal layer keeps the library sort.
+bool topk_preferred(int n, int topn);
+bool topk_supported(int n, int topn) {
+  const int m = topn < n ? topn : n;
+  return n > 0 && n <= TK_MAXR * TK_THREADS && n < 65536 && m <= TK_CAP;
+}
+
+bool topk_preferred(int n, int topn) {
+  if (!topk_supported(n, topn) || g_sort_mode == 1) return false;
+  return g_sort_mode == 2 || n <= 4096;
+}
+
+int topk_launch(const float* scores, int B, int n, int topn, int* order, int order_stride, float* sorted_scores,
+                hipStream_t s) {
+  static const hipError_t a24 = hipFuncSetAttribute((const void*)topk_sort_kernel<24>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
+  static const hipError_t a40 = hipFuncSetAttribute((const void*)topk_sort_kernel<TK_MAXR>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
+  (void)a24;
+  (void)a40;
+  if (n <= 24 * TK_THREADS)
+    topk_sort_kernel<24><<<B, TK_THREADS, sizeof(TopkSmem), s>>>(scores, n, topn, order, order_stride, sorted_scores);
+  else
+    topk_sort_kernel<TK_MAXR><<<B, TK_THREADS, sizeof(TopkSmem), s>>>(scores, n, topn, order, order_stride, sorted_scores);
+  return 0;
+}
+
 int sort_end_bit(int B) {
   int bits = 0;
   while ((1 << bits) < B) ++bits;
@@ -206,7 +481,7 @@ int dana_rpn_decode(const float* cls, long cls_sb, long cls_sc, long cls_sp, int
 
 size_t dana_sort_desc_workspace_bytes(int B, int n) {
   if (B <= 0 || n <= 0) return 0;
-  return sort_plan(B, n).total;
+  return sort_plan(B, n).total;  // (also for rows the hand-written kernel takes: dana_set_library_sort may switch back)
 }
 
 // Stable descending sort of each row of scores[B][n]; order[B][n] = source index within the row.
@@ -215,6 +490,11 @@ int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_
   DANA_CHECK_ARG(B >= 0 && n >= 0, "dana_sort_desc: bad shape");
   if (B == 0 || n == 0) return DANA_OK;
   DANA_CHECK_ARG(scores && order, "dana_sort_desc: null pointer");
+  if (topk_preferred(n, n)) {  // short rows: the hand-written select + LDS sort, one launch
+    topk_launch(scores, B, n, n, order, n, sorted_scores, (hipStream_t)stream);
+    DANA_CHECK_LAUNCH("dana_sort_desc(topk)");
+    return DANA_OK;
+  }
   SortPlan p = sort_plan(B, n);
   if (!workspace || workspace_bytes < p.total) {
     dana_set_error("dana_sort_desc: workspace %zu < %zu", workspace_bytes, p.total);
@@ -241,6 +521,54 @@ int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_
     DANA_CHECK_LAUNCH("dana_sort_desc(unkey)");
   }
   return DANA_OK;
+}
+
+int dana_set_library_sort(int on) {
+  g_sort_mode = on;
+  return DANA_OK;
+}
+
+int dana_topk_desc(const float* scores, int B, int n, int topn, int* order, int order_stride, float* sorted_scores,
+                   void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(B >= 0 && n >= 0 && topn >= 0 && order_stride >= (topn < n ? topn : n), "dana_topk_desc: bad shape");
+  if (B == 0 || n == 0 || topn == 0) return DANA_OK;
+  DANA_CHECK_ARG(scores && order, "dana_topk_desc: null pointer");
+  if (topk_preferred(n, topn)) {
+    topk_launch(scores, B, n, topn, order, order_stride, sorted_scores, (hipStream_t)stream);
+    DANA_CHECK_LAUNCH("dana_topk_desc");
+    return DANA_OK;
+  }
+  // larger problems: the full library sort into the workspace, then the first topn of every row
+  const size_t need = dana_topk_desc_workspace_bytes(B, n, topn);
+  if (!workspace || workspace_bytes < need) {
+    dana_set_error("dana_topk_desc: workspace %zu < %zu", workspace_bytes, need);
+    return DANA_ERR_WORKSPACE;
+  }
+  char* ws = (char*)workspace;
+  const size_t ob = dana_align_up((size_t)B * n * 4, 256);
+  int* full = (int*)ws;
+  float* fulls = (float*)(ws + ob);
+  const int saved = g_sort_mode;
+  g_sort_mode = 1;
+  const int rc = dana_sort_desc(scores, B, n, full, sorted_scores ? fulls : nullptr, ws + 2 * ob, workspace_bytes - 2 * ob, stream);
+  g_sort_mode = saved;
+  if (rc) return rc;
+  const int m = topn < n ? topn : n;
+  for (int b = 0; b < B; ++b) {
+    if (hipMemcpyAsync(order + (long)b * order_stride, full + (long)b * n, (size_t)m * 4, hipMemcpyDeviceToDevice,
+                       (hipStream_t)stream) != hipSuccess ||
+        (sorted_scores && hipMemcpyAsync(sorted_scores + (long)b * order_stride, fulls + (long)b * n, (size_t)m * 4,
+                                         hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)) {
+      dana_set_error("dana_topk_desc: copy failed");
+      return DANA_ERR_HIP;
+    }
+  }
+  return DANA_OK;
+}
+
+size_t dana_topk_desc_workspace_bytes(int B, int n, int topn) {
+  if (B <= 0 || n <= 0 || topn <= 0 || (topk_supported(n, topn) && g_sort_mode == 2)) return 0;
+  return 2 * dana_align_up((size_t)B * n * 4, 256) + sort_plan(B, n).total;
 }
 
 int dana_gather_boxes(const float* src, const int* order, int B, int n, int order_stride, int topn, float* dst,
@@ -324,8 +652,13 @@ int dana_proposal_layer(const float* cls, long cls_sb, long cls_sc, long cls_sp,
   int rc = dana_rpn_decode(cls, cls_sb, cls_sc, cls_sp, cls_is_prob, bbox, bbox_sb, bbox_sc, bbox_sp, im_info,
                            base_anchors, B, A, H, W, feat_stride, proposals, scores, stream);
   if (rc) return rc;
-  rc = dana_sort_desc(scores, B, n, order, nullptr, ws + p.sort_ws, p.nms_ws - p.sort_ws, stream);
-  if (rc) return rc;
+  if (topk_preferred(n, p.topn)) {
+    topk_launch(scores, B, n, p.topn, order, n, nullptr, (hipStream_t)stream);
+    DANA_CHECK_LAUNCH("dana_proposal_layer(topk)");
+  } else {
+    rc = dana_sort_desc(scores, B, n, order, nullptr, ws + p.sort_ws, p.nms_ws - p.sort_ws, stream);
+    if (rc) return rc;
+  }
   rc = dana_gather_boxes(proposals, order, B, n, n, p.topn, sorted_boxes, stream);
   if (rc) return rc;
   rc = dana_nms(sorted_boxes, p.topn, B, nms_thresh, nms_inclusive, mk, keep, mk, num_keep, ws + p.nms_ws,

@@ -214,6 +214,20 @@ def sort_desc(scores):
     return order, sorted_scores
 
 
+def topk_desc(scores, topn):
+    """scores [B, n] -> (order int32 [B, m], sorted scores [B, m]), m = min(topn, n): the first topn entries of a stable
+    descending sort of every row (proposal_layer.py:135-150), one hand-written launch (dana_topk_desc)."""
+    scores = _chk(scores.contiguous(), "scores")
+    B, n = scores.shape
+    m = min(int(topn), n)
+    order = torch.empty((B, m), dtype=torch.int32, device=scores.device)
+    sorted_scores = torch.empty((B, m), dtype=torch.float32, device=scores.device)
+    nbytes = lib().query("dana_topk_desc_workspace_bytes", B, n, int(topn))
+    ws = _ws(nbytes, scores.device)
+    lib().call("dana_topk_desc", _p(scores), B, n, int(topn), _p(order), m, _p(sorted_scores), _p(ws), ws.numel(), _stream())
+    return order, sorted_scores
+
+
 def nms_sorted(boxes, thr, inclusive=False, max_keep=0):
     """boxes [P, n, 4] already in descending-score order -> (keep int32 [P, mk], num_keep int32 [P])."""
     boxes = _chk(boxes.contiguous(), "boxes")

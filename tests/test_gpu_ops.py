@@ -341,6 +341,45 @@ def test_sort_desc_stable(dev):
     assert np.array_equal(ss.cpu().numpy(), np.take_along_axis(s, ref, 1))
 
 
+@pytest.mark.parametrize("n,topn", [(21546, 12000), (21546, 6000), (37800, 12000), (2394, 12000), (12288, 12288),
+                                    (40960, 300), (1, 5), (65, 64), (28728, 12000), (50000, 12000)])
+def test_topk_desc_is_the_head_of_the_stable_sort(dev, n, topn):
+    """round 4: the hand-written select + LDS radix sort (proposal_layer.py:135-150 as one launch) against numpy's stable
+    sort: random scores, heavy ties (the cut falls INSIDE a run of equal scores), negative / zero / denormal values, and
+    bit-identity with the library sort it replaced"""
+    ops = _ops()
+    from dana_amd._lib import lib
+    rng = np.random.default_rng(n + topn)
+    B = 3
+    s = rng.uniform(-1.0, 1.0, size=(B, n)).astype(np.float32)
+    s[1] = np.round(s[1] * 8) / 8          # 17 distinct values: every cut is inside a tie run
+    s[2, ::3] = 0.0
+    s[2, 1::7] = -0.0
+    s[2, 5::11] = 1e-42                    # denormal
+    m = min(topn, n)
+    lib().call("dana_set_library_sort", 2)  # the hand-written kernel wherever it can run (n = 50 000: the library path)
+    try:
+        order, ss = ops.topk_desc(torch.from_numpy(s).to(dev), topn)
+        torch.cuda.synchronize()
+    finally:
+        lib().call("dana_set_library_sort", 0)
+    # -0.0 sorts behind +0.0 (the key is the bit pattern, like the library sort's): compare through the same total order
+    bits = s.view(np.uint32).astype(np.int64)
+    key = np.where(bits & 0x80000000, (~bits) & 0xFFFFFFFF, bits | 0x80000000)
+    ref = np.argsort(-key, axis=1, kind="stable")[:, :m]
+    assert np.array_equal(order.cpu().numpy(), ref)
+    assert np.array_equal(ss.cpu().numpy().view(np.uint32), np.take_along_axis(s, ref, 1).view(np.uint32))
+    lib().call("dana_set_library_sort", 1)
+    try:
+        order_l, ss_l = ops.topk_desc(torch.from_numpy(s).to(dev), topn)
+        torch.cuda.synchronize()
+    finally:
+        lib().call("dana_set_library_sort", 0)
+    assert torch.equal(order, order_l) and torch.equal(ss, ss_l)
+    order_d, ss_d = ops.topk_desc(torch.from_numpy(s).to(dev), topn)  # ... and the measured dispatch
+    assert torch.equal(order, order_d) and torch.equal(ss, ss_d)
+
+
 def test_decode_clip_golden(G, dev):
     ops = _ops()
     deltas = torch.from_numpy(G["dec_deltas"]).to(dev)  # [2, K*A, 4]
