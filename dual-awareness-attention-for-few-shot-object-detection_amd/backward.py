@@ -518,7 +518,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     #    from an already forked stream crashes hipStreamEndCapture on ROCm 7.2). Issuing the chain even earlier -- from the
     #    eager forward, right behind the RPN head, under the proposal layer and the host round trip -- was built and
     #    measured: +-0 (18.10 / 18.03 vs 18.07 ms): the eager iteration is host-bound there, the chain's ~100 launches
-    #    delay the host's count read by what they save on the GPU. --
+    #    delay the host's count read by what they save on the GPU. Letting every side stream enter the capture through
+    #    an event of the capturing stream itself (a flat fork structure) does not avoid that crash either (measured). --
     main = torch.cuda.current_stream()
     single = getattr(model, "_single_stream", False)
     capturing = torch.cuda.is_current_stream_capturing()
