@@ -42,7 +42,7 @@ class WeightGrads:
         self.compact = {}  # gathered input rows of strided 1x1 convs (shared by a block's conv1 and downsample conv)
 
     def _side_for_current(self):
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         ent = self.side.get(cur.cuda_stream)
         if ent is None:
             if not self.side or self.model is None:
@@ -73,11 +73,10 @@ class WeightGrads:
             self._launch(key, g, x, n, h, w, c, in_stride, grad_stride, v)
             return
         st, keep = self._side_for_current()
-        ready = torch.cuda.Event()
-        ready.record()
+        ready = ops.record_event()
         st.wait_event(ready)
         keep.append((g, x, v))
-        with torch.cuda.stream(st):
+        with ops.on_stream(st):
             self._launch(key, g, x, n, h, w, c, in_stride, grad_stride, v)
 
     def side_run(self, fn, *keep):
@@ -88,11 +87,10 @@ class WeightGrads:
             fn()
             return
         st, kept = self._side_for_current()
-        ready = torch.cuda.Event()
-        ready.record()
+        ready = ops.record_event()
         st.wait_event(ready)
         kept.append(keep)
-        with torch.cuda.stream(st):
+        with ops.on_stream(st):
             fn()
 
     def linear(self, g, x, m, n, k, then, ldx=0, ldg=0):
@@ -107,7 +105,7 @@ class WeightGrads:
         if c["k"] == 1 and c["stride"] > 1 and c["pad"] == 0 and GATHER_STRIDED_WGRAD:
             # a strided 1x1 conv (first block of layer2-4: conv1 and the downsample conv read the same pixels): gather those
             # pixels once into plain rows -- both weight gradients then run on the software-pipelined plain-row kernel
-            ck = (x.data_ptr(), n, h, w, c["cin"], c["stride"], in_stride, torch.cuda.current_stream().cuda_stream)
+            ck = (x.data_ptr(), n, h, w, c["cin"], c["stride"], in_stride, ops.cur_stream().cuda_stream)
             ent = self.compact.get(ck)
             if ent is None:
                 ent = self.compact[ck] = (ops.downsample_gather(x, n, h, w, c["cin"], c["stride"], in_stride), x)
@@ -142,7 +140,7 @@ class WeightGrads:
             self.compact.clear()
             del _FRESH.grads[:]
             return
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         for t in _FRESH.grads:
             t.record_stream(cur)
         del _FRESH.grads[:]
@@ -373,7 +371,7 @@ def _rpn_chain(model, ctx, g1, g2, g_dev, grads_r, rpnw_ready=None):
     _, _, d_x = ops.linear_backward(d_heads, ctx["rpn_x"], plan["rpn_head_w"], B * hw, nh, 512, need_dw=False)
     ops.relu_mask_(d_x, ctx["rpn_x"], B * hw, 512)
     if rpnw_ready is not None:
-        torch.cuda.current_stream().wait_event(rpnw_ready)
+        ops.cur_stream().wait_event(rpnw_ready)
     grads_r.add_conv("RCNN_rpn.RPN_Conv", d_x, corr, B, fh, fw, c_rpn, v=ctx.get("rpn_v"))
     _acc(rpn.RPN_Conv.bias, ops.colsum(d_x, B * hw, 512))
     d_corr = conv_dgrad(d_x, B, fh, fw, c_rpn)  # [B*hw][2048]
@@ -486,10 +484,9 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     dgw_ready = l4w_ready = rpnw_ready = None
     if PREFETCH_DGRAD_W and not getattr(model, "_single_stream", False):
         prep = model._stream("dgradw", dev)
-        ev0 = torch.cuda.Event()
-        ev0.record()
+        ev0 = ops.record_event()
         prep.wait_event(ev0)
-        with torch.cuda.stream(prep):
+        with ops.on_stream(prep):
             seen = set()
 
             def derive(saved):
@@ -502,14 +499,11 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
 
             # (in the order the backward needs them: the RPN chain and the box branch start at once, then the trunk)
             _dgrad_weights(c_rpn)
-            rpnw_ready = torch.cuda.Event()
-            rpnw_ready.record()
+            rpnw_ready = ops.record_event()
             derive(ctx["l4_saved"])
-            l4w_ready = torch.cuda.Event()
-            l4w_ready.record()
+            l4w_ready = ops.record_event()
             derive(ctx["q_saved"])
-            dgw_ready = torch.cuda.Event()
-            dgw_ready.record()
+            dgw_ready = ops.record_event()
 
     # -- RPN chain (_rpn_chain). It depends on the forward's saved tensors only and meets the RoI stage's gradients in
     #    base_feat / the support maps, so it runs on a stream of its own FROM THE START of the backward, beside the box
@@ -520,23 +514,21 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     #    measured: +-0 (18.10 / 18.03 vs 18.07 ms): the eager iteration is host-bound there, the chain's ~100 launches
     #    delay the host's count read by what they save on the GPU. Letting every side stream enter the capture through
     #    an event of the capturing stream itself (a flat fork structure) does not avoid that crash either (measured). --
-    main = torch.cuda.current_stream()
+    main = ops.cur_stream()
     single = getattr(model, "_single_stream", False)
     capturing = torch.cuda.is_current_stream_capturing()
     rpn_early = RPN_CHAIN_EARLY and not single
     rpn_out = rpn_done = None
     if rpn_early:
         rpn_stream = model._stream("rpn_bwd", dev)
-        start = torch.cuda.Event()
-        start.record()
+        start = ops.record_event()
         rpn_stream.wait_event(start)
-        with torch.cuda.stream(rpn_stream):
+        with ops.on_stream(rpn_stream):
             grads_r = WeightGrads(None if capturing else model._stream("wgrad_rpn", dev), model)
             rpn_out = _rpn_chain(model, ctx, g1, g2, g_dev, grads_r, rpnw_ready)
             for t_ in rpn_out:
                 t_.record_stream(main)
-            rpn_done = torch.cuda.Event()
-            rpn_done.record()
+            rpn_done = ops.record_event()
 
     # -- seeds: d RCNN losses / d (scores, bbox_pred) were written by the fused loss kernel (dana_rcnn_loss);
     #    the upstream scalars g3 / g4 ride as alpha on the first launches that consume them --
@@ -549,15 +541,14 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     # -- box branch: RCNN_bbox_pred <- mean <- layer4 (dana.py:246,387-389). Independent of the attention heads until
     #    the two gradients of the pooled features meet, so it runs on the forward's layer4 stream: the heads' backward
     #    (many small launches) fills the CUs its big launches leave idle in their tails. --
-    main = torch.cuda.current_stream()
+    main = ops.cur_stream()
     # (under stream capture the box branch stays on the caller's stream: a weight-gradient side stream forked from an
     # already forked stream crashes hipStreamEndCapture on ROCm 7.2 -- tools/graph_debug.py modes 8 / 12 / 13)
     l4_stream = main if (getattr(model, "_single_stream", False) or torch.cuda.is_current_stream_capturing()) \
         else model._stream("layer4", dev)
-    seeds_ready = torch.cuda.Event()
-    seeds_ready.record()
+    seeds_ready = ops.record_event()
     stages = grad_stages(model, plan)
-    with torch.cuda.stream(l4_stream):
+    with ops.on_stream(l4_stream):
         l4_stream.wait_event(seeds_ready)
         if l4w_ready is not None:
             l4_stream.wait_event(l4w_ready)
@@ -576,8 +567,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         d_pooled.record_stream(main)
         grads.finish_all(model, "RCNN_top")
         _ready(model, stages[0][1])
-        box_done = torch.cuda.Event()
-        box_done.record()
+        box_done = ops.record_event()
 
     # -- RoI-level attention heads (dana.py:248-292), positive then negative supports --
     q_pe, q2, sp_pe, k2, un2 = ctx["q_pe"], ctx["q2"], ctx["sp_pe"], ctx["k2"], ctx["un2"]
@@ -665,7 +655,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     grads.finish_all(model, "RCNN_rpn")
     _ready(model, stages[2][1])
     if dgw_ready is not None:
-        torch.cuda.current_stream().wait_event(dgw_ready)
+        ops.cur_stream().wait_event(dgw_ready)
     yield "heads, RPN and attention done; trunk next"
 
     # -- trunk: query (RoIAlign + RPN paths meet in base_feat) and supports; layer3, layer2 (layer1 is frozen) --

@@ -380,7 +380,7 @@ class DAnARCNN(nn.Module):
 
     def _stream(self, name, dev):
         if getattr(self, "_single_stream", False):  # bench.py's per-launch timing pass: no overlap
-            return torch.cuda.current_stream()
+            return ops.cur_stream()
         key = ("stream", name, str(dev))
         st = self._consts.get(key)
         if st is None:
@@ -535,7 +535,7 @@ class DAnARCNN(nn.Module):
         save_q / save_s receive the per-block dicts of `_bottleneck` (views of the merged buffers)."""
         n0, _, H0, W0 = im.shape
         n1, _, H1, W1 = sup_ims.shape
-        main = torch.cuda.current_stream()
+        main = ops.cur_stream()
         if sup_stream is None or sup_stream == main:
             sup_stream = main  # (bench.py's per-launch timing pass: the same launches, one stream)
         two = [merge_from > 0]  # currently issuing the two batches as two launches (on two streams)
@@ -730,7 +730,7 @@ class DAnARCNN(nn.Module):
         if tl is not None:
             import time as _time
             tl.append(("begin", _time.perf_counter()))
-        main = torch.cuda.current_stream()
+        main = ops.cur_stream()
         gev = getattr(self, "_gpu_events", None)
 
         def mark(name):
@@ -756,8 +756,7 @@ class DAnARCNN(nn.Module):
         else:
             self._ctx = None
         mark("begin")
-        inputs_ready = torch.cuda.Event()
-        inputs_ready.record()
+        inputs_ready = ops.record_event()
         sup_stream = self._stream("support", dev)
         at = rng = ctr = side = None
         if training:
@@ -785,11 +784,10 @@ class DAnARCNN(nn.Module):
             if side is not main:
                 side.wait_event(inputs_ready)
                 if gt_f is not gt_boxes:  # converted on the caller's stream: the side stream must see the result
-                    conv_done = torch.cuda.Event()
-                    conv_done.record()
+                    conv_done = ops.record_event()
                     side.wait_event(conv_done)
                 gt_f.record_stream(side)
-            with torch.cuda.stream(side):
+            with ops.on_stream(side):
                 # allocated in the SIDE stream's pool: a block recycled from the caller's stream could still be
                 # written by kernels queued there after this stream has already filled it
                 at = ops.anchor_target_prepare(gt_f, im_info, plan["anchors"], afh, afw, self.RCNN_rpn.feat_stride,
@@ -828,8 +826,7 @@ class DAnARCNN(nn.Module):
                                                                    save_s=ctx["s_saved"] if ctx is not None else None,
                                                                    sup_stream=sup_stream, merge_from=merge_from,
                                                                    save_m=ctx["m_saved"] if ctx is not None else None)
-            trunk_done = torch.cuda.Event()
-            trunk_done.record()
+            trunk_done = ops.record_event()
             sup_stream.wait_event(trunk_done)
         else:
             sup_stream.wait_event(inputs_ready)
@@ -850,14 +847,14 @@ class DAnARCNN(nn.Module):
                         except StopIteration as done_:
                             r_q = done_.value
                     if r_s is None:
-                        with torch.cuda.stream(sup_stream):
+                        with ops.on_stream(sup_stream):
                             try:
                                 next(g_s)
                             except StopIteration as done_:
                                 r_s = done_.value
                 sup, sh_, sw_ = r_s
             else:
-                with torch.cuda.stream(sup_stream):
+                with ops.on_stream(sup_stream):
                     sup, sh_, sw_ = self._rcnn_base(sup_ims, plan, save=ctx["s_saved"] if ctx is not None else None)
             # the query batch itself is split over `query_streams` streams: kernels of different images
             # overlap each other's prologue / epilogue / tail phases on the CUs
@@ -870,7 +867,7 @@ class DAnARCNN(nn.Module):
                 else:
                     st_i = self._stream("query%d" % i, dev)
                     st_i.wait_event(inputs_ready)
-                    with torch.cuda.stream(st_i):
+                    with ops.on_stream(st_i):
                         self._rcnn_base(im_data[b0:b1], plan, out_stride=2048, out_buf=corr[b0 * fh * fw:])
                     main.wait_stream(st_i)
         hw = fh * fw
@@ -883,7 +880,7 @@ class DAnARCNN(nn.Module):
                                    "(dana.py:105); got a %dx%d map%s" % (sh_, sw_, "" if self.generalised_support else
                                    " (set model.generalised_support = True for maps whose sides are multiples of 7)"))
         mark("trunk (query + support)")
-        with torch.cuda.stream(sup_stream):
+        with ops.on_stream(sup_stream):
             sup.record_stream(sup_stream)
             # RPN-level support side (dana.py:126-145): PE, BA block, K projection, unary term, S^T
             s_pe = torch.empty((B, shot * L, 1024), dtype=torch.float32, device=dev)
@@ -907,8 +904,7 @@ class DAnARCNN(nn.Module):
             s_t = ops.transpose_batched(s_pe, B, K1, 1024)  # [B][1024][K1]
             for t_ in (kp, unary, s_t):
                 t_.record_stream(main)
-            support_done = torch.cuda.Event()
-            support_done.record()
+            support_done = ops.record_event()
             if ctx is not None:
                 ctx.update(sup=sup, s_pe=s_pe, kp=kp, unary=unary, Ns=Ns)
 
@@ -948,9 +944,8 @@ class DAnARCNN(nn.Module):
         #    reference recomputes them for every RoI). Only the RoI heads need them, so they are queued behind the RPN
         #    head: they run while the proposal layer (sort / NMS: a handful of workgroups) leaves the CUs idle,
         #    instead of competing with the query trunk. --
-        proposals_start = torch.cuda.Event()
-        proposals_start.record()
-        with torch.cuda.stream(sup_stream):
+        proposals_start = ops.record_event()
+        with ops.on_stream(sup_stream):
             sup_stream.wait_event(proposals_start)
             if (sh_, sw_) == (20, 20):
                 pool = (14, 1)  # nn.AvgPool2d(14, stride=1) (dana.py:42): 20x20 -> 7x7
@@ -969,8 +964,7 @@ class DAnARCNN(nn.Module):
             ops.softmax_rows_(un2, Ns, P2)
             for t_ in (sp_pe, k2, un2):
                 t_.record_stream(main)
-            support_roi_done = torch.cuda.Event()
-            support_roi_done.record()
+            support_roi_done = ops.record_event()
             if ctx is not None:
                 ctx.update(sp_pe=sp_pe, k2=k2, un2=un2, sup_map=(sh_, sw_), sup_pool=pool)
         A = plan["anchors"].size(0)
@@ -1065,15 +1059,14 @@ class DAnARCNN(nn.Module):
             raise NotImplementedError("POOLING_MODE '%s'" % cfg.POOLING_MODE)
         if inter is not None:
             inter["pooled"] = pooled
-        pooled_ready = torch.cuda.Event()
-        pooled_ready.record()
+        pooled_ready = ops.record_event()
         mark("roi align")
 
         # -- box regression branch: layer4 + mean + Linear (dana.py:246,387-389), shared by the pos/neg heads.
         #    It is independent of the attention head below, so it runs on its own stream (tails overlap). --
         l4_stream = self._stream("layer4", dev)
         l4_stream.wait_event(pooled_ready)
-        with torch.cuda.stream(l4_stream):
+        with ops.on_stream(l4_stream):
             y, h4, w4 = pooled, P, P
             for bi, bp in enumerate(plan["layer4"]):
                 y, h4, w4 = self._bottleneck(y, n_roi, h4, w4, bp, save=ctx["l4_saved"] if ctx is not None else None,
@@ -1083,8 +1076,7 @@ class DAnARCNN(nn.Module):
             bbox_pred = ops.gemm_nt(fc7, wb, n_roi, 4, 2048, shift=bb)
             bbox_pred.record_stream(main)
             pooled.record_stream(l4_stream)
-            l4_done = torch.cuda.Event()
-            l4_done.record()
+            l4_done = ops.record_event()
 
         # -- RoI-level CISA (dana.py:248-292). Query side once: Q projection and the q half of
         #    rcnn_transform_layer (cat([q, attended]) @ Wt^T = q @ Wt[:, :1024]^T + attended @ Wt[:, 1024:]^T,
@@ -1116,8 +1108,7 @@ class DAnARCNN(nn.Module):
         else:
             tr_q = ops.gemm_nt(q_pe, wt_q, n_roi * P2, self.rcnn_dim, 1024, ldb=wt_q_ld, shift=bt_)  # [n*49][64]
             tr_q_ld = self.rcnn_dim
-        q_ready = torch.cuda.Event()
-        q_ready.record()
+        q_ready = ops.record_event()
 
         # cls_prob of both heads in one buffer (positive rows, then negative rows: the torch.cat of dana.py:193)
         prob_all = torch.empty((2 * n_roi if training else n_roi, 2), dtype=torch.float32, device=dev)
@@ -1149,15 +1140,14 @@ class DAnARCNN(nn.Module):
         if training:  # the negative-support head (dana.py:190) on its own stream, concurrent with the positive one
             neg_stream = self._stream("neg_head", dev)
             neg_stream.wait_event(q_ready)
-            with torch.cuda.stream(neg_stream):
+            with ops.on_stream(neg_stream):
                 neg_prob, neg_score = head(shot)
                 for t_ in (neg_prob, neg_score):
                     t_.record_stream(main)
                 for t_ in (q2, tr_q, q_pe, prob_all):
                     if t_ is not None:  # (q_pe: None when the positional encoding is folded into the projections)
                         t_.record_stream(neg_stream)
-                neg_done = torch.cuda.Event()
-                neg_done.record()
+                neg_done = ops.record_event()
         cls_prob, cls_score_all = head(0)
         mark("pos head")
         main.wait_event(l4_done)

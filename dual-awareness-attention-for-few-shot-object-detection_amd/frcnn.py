@@ -61,9 +61,8 @@ class FasterRCNN(DAnARCNN):
         im_info = im_info.data.float().contiguous()
         gt_boxes = gt_boxes.data
         anchor_gt = gt_boxes if anchor_gt_boxes is None else anchor_gt_boxes.data
-        inputs_ready = torch.cuda.Event()
-        inputs_ready.record()
-        main = torch.cuda.current_stream()
+        inputs_ready = ops.record_event()
+        main = ops.cur_stream()
         # ctx (frcnn only): everything backward.frcnn_backward needs is saved into it
         base, fh, fw = self._rcnn_base(im_data, plan, save=ctx["q_saved"] if ctx is not None else None)  # faster_rcnn.py:43
         # -- RPN (rpn.py:58-115) on base_feat (or on the model's own RPN input) --
@@ -90,7 +89,7 @@ class FasterRCNN(DAnARCNN):
             tr_ = cfg.TRAIN
             side = self._stream("targets", dev)
             side.wait_event(inputs_ready)
-            with torch.cuda.stream(side):
+            with ops.on_stream(side):
                 at = ops.anchor_target_assign(anchor_gt.float(), im_info, plan["anchors"], fh, fw, rpn.feat_stride,
                                               tr_.RPN_NEGATIVE_OVERLAP, tr_.RPN_POSITIVE_OVERLAP, tr_.RPN_BATCHSIZE,
                                               tr_.RPN_FG_FRACTION)

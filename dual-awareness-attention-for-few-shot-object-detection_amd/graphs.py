@@ -48,9 +48,9 @@ class GraphedDAnA:
         self.inputs = [_static_like(t) for t in example_inputs]
         self.stream = torch.cuda.Stream(device=dev)
         self.req = self.drawn = self.g2 = None
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream), torch.no_grad():
+        with ops.on_stream(self.stream), torch.no_grad():
             for _ in range(warmup):  # eager: fills the plan / constant caches, sets kernel attributes
                 model(*self.inputs)
         torch.cuda.synchronize(dev)
@@ -92,10 +92,10 @@ class GraphedDAnA:
         for s, t in zip(self.inputs, inputs):
             if torch.is_tensor(t) and t is not s:
                 s.copy_(t, non_blocking=True)
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         if self.g0 is not None:
             self.side.wait_stream(cur)
-            with torch.cuda.stream(self.side):
+            with ops.on_stream(self.side):
                 self.g0.replay()
         self.g1.replay()
         if self.g0 is None and self.g2 is None and getattr(self.model, "device_rng", False) and self.model.training:
@@ -133,7 +133,7 @@ class GraphedTrainer:
         self.inputs = [_static_like(t) for t in example_inputs]
         self.stream = torch.cuda.Stream(device=dev)
         self.ones = torch.ones(4, dtype=torch.float32, device=dev)  # d(sum of the four losses) / d(each)
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         self.stream.wait_stream(cur)
         # eager warm-up iterations (caches, kernel attributes, allocator pools) must not move the training trajectory:
         # parameters, optimizer state and the step count are put back afterwards (warmup=0: the caller's own first
@@ -143,7 +143,7 @@ class GraphedTrainer:
             import numpy as _np
             snap = ([fb.params.clone() for fb, _, _ in trainer.groups], [b.clone() for b in trainer.bufs], trainer.steps,
                     self.model._rng_calls, _np.random.get_state())  # (host-RNG mode draws np.random in the warm-up too)
-        with torch.cuda.stream(self.stream):
+        with ops.on_stream(self.stream):
             for _ in range(warmup):
                 trainer.step(*self.inputs)
         torch.cuda.synchronize(dev)
@@ -252,7 +252,7 @@ class GraphedTrainer:
                 fb.zero_grad_bookkeeping()
         self.outputs = tuple(t.detach() if torch.is_tensor(t) else t for t in out)
         self.collective = collective
-        torch.cuda.current_stream().wait_stream(self.stream)
+        ops.cur_stream().wait_stream(self.stream)
 
     def _sgd(self):
         tr = self.trainer
@@ -279,10 +279,10 @@ class GraphedTrainer:
                 s.copy_(t, non_blocking=True)
         works = []
         last = len(self.graphs) - 1
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         if self.g_anchor is not None:
             self.side.wait_stream(cur)
-            with torch.cuda.stream(self.side):
+            with ops.on_stream(self.side):
                 self.g_anchor.replay()
         for k, (g, buckets) in enumerate(self.graphs):
             if k == 1 and self.req is not None:

@@ -44,15 +44,62 @@ def _prof_end(e0, tag, flops, nbytes=0.0, executed=None):
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
+_get_cur = getattr(torch._C, "_cuda_getCurrentStream", None)
+_set_cur = getattr(torch._C, "_cuda_setStream", None)
+if __import__("os").environ.get("DANA_FAST_STREAMS", "1") == "0":  # (A/B aid: the torch.cuda calls)
+    _get_cur = _set_cur = None
+
+
+# Stream bookkeeping without torch.cuda's Python layers. torch.cuda.current_stream(), `with torch.cuda.stream(s)` and
+# Event.record() each resolve the device index through several wrappers and an os.environ look-up: ~8 us per call and
+# ~1 800 calls per eager training iteration (tools/hostprof_step.py: >1 ms of its host time in the forward alone). The
+# helpers below go to the same C entry points directly; on a torch build without them they are the torch.cuda calls.
+def cur_stream():
+    """torch.cuda.current_stream() of the current device"""
+    if _get_cur is None or _raw_device is None:
+        return torch.cuda.current_stream()
+    sd = _get_cur(_raw_device())
+    return torch.cuda.Stream(stream_id=sd[0], device_index=sd[1], device_type=sd[2])
+
+
+class on_stream:
+    """`with torch.cuda.stream(st)` for a stream of the CURRENT device"""
+    __slots__ = ("st", "prev")
+
+    def __init__(self, st):
+        self.st = st
+
+    def __enter__(self):
+        st = self.st
+        if _get_cur is None or _set_cur is None or _raw_device is None or st.device_index != _raw_device():
+            self.prev = torch.cuda.stream(st)
+            self.prev.__enter__()
+            return
+        self.prev = _get_cur(st.device_index)
+        _set_cur(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+
+    def __exit__(self, *exc):
+        prev = self.prev
+        if isinstance(prev, tuple):
+            _set_cur(stream_id=prev[0], device_index=prev[1], device_type=prev[2])
+        else:
+            prev.__exit__(*exc)
+
+
+def record_event(stream=None, timing=False):
+    """a fresh event recorded on `stream` (default: the current one)"""
+    e = torch.cuda.Event(enable_timing=timing)
+    e.record(stream if stream is not None else cur_stream())
+    return e
 
 
 def _stream():
-    """the caller's current HIP stream as a raw handle. torch.cuda.current_stream() builds a Stream object through
+    """the caller's current HIP stream as a raw handle. cur_stream() builds a Stream object through
     several layers of Python (device index resolution, environment look-ups): 7.8 us per call, 1.4 ms of the eager
     step's ~3 ms of host time (tools/hostprof.py); the two C entry points below take 0.3 us."""
     if _raw_stream is not None and _raw_device is not None:
         return _raw_stream(_raw_device())
-    return torch.cuda.current_stream().cuda_stream
+    return cur_stream().cuda_stream
 
 
 def _chk(t, name, dtype=torch.float32):
@@ -90,8 +137,7 @@ def _h2d_int32(arr, device):
         buf = ring[i][0] = torch.empty((n * 2,), dtype=torch.int32, pin_memory=True)
     buf[:n].numpy()[...] = arr.reshape(-1)
     out = buf[:n].to(device, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
+    ev = record_event()
     ring[i][1] = ev
     return out
 
@@ -476,10 +522,9 @@ def _pinned_upload(arr, dst, stream=None):
     if buf.numel() < n:
         buf = ring[i][0] = torch.empty((n * 2,), dtype=torch.int32, pin_memory=True)
     buf[:n].numpy()[...] = arr.reshape(-1)
-    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+    with on_stream(stream if stream is not None else cur_stream()):
         dst[:n].copy_(buf[:n], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        ev = record_event()
     ring[i][1] = ev
     return ev
 
@@ -508,7 +553,7 @@ def draw_and_upload(req, device, static=None):
         e_in = torch.cuda.Event(enable_timing=True)
         e_in.record()
     t0 = _time.perf_counter()
-    with torch.cuda.stream(req["anchor_stream"]):
+    with on_stream(req["anchor_stream"]):
         cnt_a = req["anchor_counts"].cpu().numpy()
     HOST_WAIT[0] += _time.perf_counter() - t0  # (time the host spent BLOCKED on the GPU, for host-enqueue accounting)
     pairs, num_examples = anchor_target_draw(cnt_a, B, req["rpn_batchsize"], req["num_fg"])
@@ -520,13 +565,13 @@ def draw_and_upload(req, device, static=None):
     cs = _PINNED.get("copy_stream")
     if cs is None or cs.device != torch.device(device):
         cs = _PINNED["copy_stream"] = torch.cuda.Stream(device=device)
-    cur = torch.cuda.current_stream()
+    cur = cur_stream()
     if static is None:
         # a fresh buffer FROM THE COPY STREAM'S POOL: the upload below starts at once, and a block of the caller's pool
         # may still be in use by a kernel that is queued on the caller's stream (released in stream order only) when
         # that stream lags behind the host -- two processes on one GPU, a long kernel in front (regression:
         # tests/test_gpu_backward.py::test_two_stream_trunk_..._recycled_blocks)
-        with torch.cuda.stream(cs):
+        with on_stream(cs):
             static = torch.empty((lay["pairs"] + 2 * n,), dtype=torch.int32, device=device)
         static.record_stream(cur)
     else:

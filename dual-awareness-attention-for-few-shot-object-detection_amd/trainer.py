@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import backward as BW
+from . import ops
 from .config import cfg
 
 
@@ -112,15 +113,14 @@ class FlatBuckets:
             if owner is not None and owner._comm is None:
                 owner._comm = torch.cuda.Stream(device=self.grads.device)
             self._comm = owner._comm if owner is not None else torch.cuda.Stream(device=self.grads.device)
-        final = torch.cuda.Event()
-        final.record()
+        final = ops.record_event()
         self._comm.wait_event(final)
-        with torch.cuda.stream(self._comm):
+        with ops.on_stream(self._comm):
             return dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def join_comm(self):
         if self._comm is not None:
-            torch.cuda.current_stream().wait_stream(self._comm)
+            ops.cur_stream().wait_stream(self._comm)
 
     def wait_all(self):
         """all buckets must have left; blocks the current stream (not the host, for nccl) until the sums arrived"""
@@ -131,7 +131,7 @@ class FlatBuckets:
         for w in self._works:
             w.wait()  # nccl: the CURRENT stream waits for the collective; gloo: the host does
         if self._works and self._comm is not None:
-            torch.cuda.current_stream().wait_stream(self._comm)
+            ops.cur_stream().wait_stream(self._comm)
         self._works = []
 
     def broadcast_params(self, src=0):
