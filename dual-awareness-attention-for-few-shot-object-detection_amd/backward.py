@@ -309,19 +309,20 @@ def _acc(param, g):
 
 
 def _attention_backward(d_dense, ld_dd, a, unary, q, k_, s_mat, Bn, rows_b, nseg, L, Kp, dq, ugamma, k_batch, s_batch,
-                        u_batch, d_k_out, d_s_out, d_u_out):
+                        u_batch, d_k_out, d_s_out, d_u_out, vw=1024):
     """Adjoint of one dual-awareness attention  dense = ((softmax_seg(q k^T / sqrt(dq)) + ugamma u) / nseg) s
     (dana.py:118-154 / 258-283) for Bn images of rows_b query rows each.
-      d_dense [Bn*rows_b][1024] (row stride ld_dd); a = the saved attention [Bn][rows_b][Kp]; q [Bn*rows_b][dq];
+      d_dense [Bn*rows_b][vw] (row stride ld_dd; vw = width of the value rows s_mat: 1024, or 64 where the values are the
+      re-associated table S . Wt_a^T of the RoI heads); a = the saved attention [Bn][rows_b][Kp]; q [Bn*rows_b][dq];
       k_ / s_mat / unary: key, value and unary rows of image b start at b * k_batch / s_batch / u_batch (floats).
     Accumulates into d_k_out (rows of image b at b*k_batch), d_s_out (b*s_batch), d_u_out (b*u_batch); returns d_q."""
     dev = a.device
     K = nseg * L
     dA = torch.zeros((Bn, rows_b, Kp), dtype=torch.float32, device=dev)
-    ops.gemm_nt(d_dense, s_mat, rows_b, K, 1024, lda=ld_dd, out=dA, ldc=Kp, batch=Bn, batch_a=rows_b * ld_dd,
+    ops.gemm_nt(d_dense, s_mat, rows_b, K, vw, lda=ld_dd, out=dA, ldc=Kp, batch=Bn, batch_a=rows_b * ld_dd,
                 batch_b=s_batch, batch_c=rows_b * Kp)
     # d s[b] += a[b]^T . d_dense[b], every image in one launch (a's zero-padded columns K..Kp-1 are computed, not stored)
-    ops.gemm_tn_batched(a, d_dense, Bn, rows_b, Kp, 1024, d_s_out, ldy=Kp, ldx=ld_dd, batch_y=rows_b * Kp,
+    ops.gemm_tn_batched(a, d_dense, Bn, rows_b, Kp, vw, d_s_out, ldy=Kp, ldx=ld_dd, batch_y=rows_b * Kp,
                         batch_x=rows_b * ld_dd, batch_out=s_batch, n_valid=K)
     ops.colsum_batched(dA, Bn, rows_b, K, d_u_out, ld=Kp, x_batch=rows_b * Kp, out_batch=u_batch, alpha=ugamma / nseg)
     ops.attn_softmax_unary_backward_(dA, a, unary, Bn * rows_b, rows_b, nseg, L, Kp, Kp, ugamma, 1.0 / nseg,
@@ -583,6 +584,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     d_k2 = torch.zeros((Ns * P2, dq), dtype=torch.float32, device=dev)
     d_un2 = torch.zeros((Ns, P2), dtype=torch.float32, device=dev)
     d_wt = torch.zeros_like(wt)
+    d_sw = None
     for hc in ctx["heads"]:
         off = hc["offset"]
         hi = 0 if off == 0 else 1  # rows of cls_score_all: positive-support scores first (dana.py:194)
@@ -596,15 +598,34 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         grads.linear(d_hid, hc["tr"], n_roi, nhid, P2 * rd, lambda dw, db: (_acc(lin1.weight, dw), _acc(lin1.bias, db)))
         _, _, d_tr = ops.linear_backward(d_hid, hc["tr"], w1, n_roi, nhid, P2 * rd, need_dw=False)
         ops.axpy_rows_(d_trq, d_tr, n_roi * P2, rd)
-        grads.linear(d_tr, hc["dense"], n_roi * P2, rd, 1024,
-                     lambda dw, db: ops.axpy_rows_(d_wt.view(-1)[1024:], dw, rd, 1024, ld_y=2048))
-        _, _, d_dense = ops.linear_backward(d_tr, hc["dense"], wt.view(-1)[1024:], n_roi * P2, rd, 1024, ldw=2048, need_dw=False)
-        d_qh = _attention_backward(d_dense, 1024, hc["sc2"], un2.view(-1)[off * P2:], q2, k2.view(-1)[off * P2 * dq:],
-                                   sp_pe.view(-1)[off * P2 * 1024:], B, R * P2, shot, P2, K2p, dq, ug,
-                                   way * shot * P2 * dq, way * shot * P2 * 1024, way * shot * P2,
-                                   d_k2.view(-1)[off * P2 * dq:], d_sp_pe.view(-1)[off * P2 * 1024:],
-                                   d_un2.view(-1)[off * P2:])
+        if hc["dense"] is None:
+            # the forward ran  tr = A . (S . Wt_a^T) + q half  (DAnARCNN.fold_roi_attn): the attention's VALUE rows are the
+            # [147][64] table sw of each image, so its adjoint works on 64-wide rows -- the [n*49][1024] gradient of the
+            # attended tensor, its two GEMMs against Wt_a and the two K = 1024 attention adjoints per head do not exist
+            if d_sw is None:
+                d_sw = torch.zeros((Ns * P2, rd), dtype=torch.float32, device=dev)
+            d_qh = _attention_backward(d_tr, rd, hc["sc2"], un2.view(-1)[off * P2:], q2, k2.view(-1)[off * P2 * dq:],
+                                       ctx["sw"].view(-1)[off * P2 * rd:], B, R * P2, shot, P2, K2p, dq, ug,
+                                       way * shot * P2 * dq, way * shot * P2 * rd, way * shot * P2,
+                                       d_k2.view(-1)[off * P2 * dq:], d_sw.view(-1)[off * P2 * rd:],
+                                       d_un2.view(-1)[off * P2:], vw=rd)
+        else:
+            grads.linear(d_tr, hc["dense"], n_roi * P2, rd, 1024,
+                         lambda dw, db: ops.axpy_rows_(d_wt.view(-1)[1024:], dw, rd, 1024, ld_y=2048))
+            _, _, d_dense = ops.linear_backward(d_tr, hc["dense"], wt.view(-1)[1024:], n_roi * P2, rd, 1024, ldw=2048,
+                                                need_dw=False)
+            d_qh = _attention_backward(d_dense, 1024, hc["sc2"], un2.view(-1)[off * P2:], q2, k2.view(-1)[off * P2 * dq:],
+                                       sp_pe.view(-1)[off * P2 * 1024:], B, R * P2, shot, P2, K2p, dq, ug,
+                                       way * shot * P2 * dq, way * shot * P2 * 1024, way * shot * P2,
+                                       d_k2.view(-1)[off * P2 * dq:], d_sp_pe.view(-1)[off * P2 * 1024:],
+                                       d_un2.view(-1)[off * P2:])
         ops.axpy_rows_(d_q2, d_qh, n_roi * P2, dq)
+    if d_sw is not None:
+        # sw = sp_pe . Wt_a^T (once per support, both heads): d Wt_a = d_sw^T . sp_pe, d sp_pe += d_sw . Wt_a
+        grads.linear(d_sw, sp_pe, Ns * P2, rd, 1024,
+                     lambda dw, db: ops.axpy_rows_(d_wt.view(-1)[1024:], dw, rd, 1024, ld_y=2048))
+        ops.linear_backward(d_sw, sp_pe, wt.view(-1)[1024:], Ns * P2, rd, 1024, ldw=2048, dx_out=d_sp_pe, dx_ld=1024,
+                            need_dw=False)
 
     # -- RoI-level query side: Q projection + the q half of rcnn_transform_layer; PE is additive --
     ops.colmean_sub_(d_q2, n_roi, P2, dq)

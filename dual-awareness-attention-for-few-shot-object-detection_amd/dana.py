@@ -185,6 +185,7 @@ class DAnARCNN(nn.Module):
         self.interleave_trunks = __import__('os').environ.get('DANA_INTERLEAVE', '1') != '0'
         # forward-only runs: RoI-level positional encoding folded into one fused query projection (see _roi_query_fold)
         self.fold_roi_pe = __import__('os').environ.get('DANA_FOLD_ROI_PE', '1') != '0'
+        self.fold_roi_attn = __import__('os').environ.get('DANA_FOLD_ROI_ATTN', '1') != '0'  # forward-only: A.(S.Wt^T) instead of (A.S).Wt^T
         self.nms_inclusive = False  # False: IoU > thr as the reference CUDA op (nms.cu:60); True: CPU op (>=)
         dim_in = self.pool_feat_dim
 
@@ -962,6 +963,19 @@ class DAnARCNN(nn.Module):
             wu2, bu2 = self._w(self.rcnn_unary_layer)
             un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
             ops.softmax_rows_(un2, Ns, P2)
+            sw = None
+            if getattr(self, "fold_roi_attn", True):
+                # The head's two contractions re-associated (dana.py:279-286): the attended rows only feed the second half
+                # of rcnn_transform_layer, and (A . S) . Wt_a^T = A . (S . Wt_a^T) -- S . Wt_a^T is a [147][64] table per
+                # image computed ONCE here (under the proposal layer), the per-RoI work drops from K = 147 -> 1024 -> 64
+                # (10.8 GF per head at bs 4) to K = 147 -> 64 (0.5 GF) and the [n*49][1024] attended tensor (103 MB written
+                # and read back, per head) never exists -- nor do its adjoints in the backward, which differentiates the
+                # same re-associated form (backward.model_backward_gen).
+                wt_a_s, wt_a_s_ld = self._lin_b(self.rcnn_transform_layer, 1024, 1024)
+                sw = ops.gemm_nt(sp_pe, wt_a_s, Ns * P2, self.rcnn_dim, 1024, ldb=wt_a_s_ld)  # [Ns*49][64]
+                sw.record_stream(main)
+                if ctx is not None:
+                    ctx["sw"] = sw
             for t_ in (sp_pe, k2, un2):
                 t_.record_stream(main)
             support_roi_done = ops.record_event()
@@ -1122,12 +1136,22 @@ class DAnARCNN(nn.Module):
                         batch_b=way * shot * P2 * dq, batch_c=R * P2 * K2p, alpha=1.0 / math.sqrt(dq))
             ops.attn_softmax_unary_(sc2, ub, n_roi * P2, R * P2, shot, P2, K2p, K2p, self.unary_gamma, 1.0 / shot,
                                     unary_batch_stride=way * shot * P2)
-            st2 = ops.transpose_batched(sb, B, K2, 1024, ldi=1024, ldo=K2p, in_batch=way * shot * P2 * 1024)
-            dense = torch.empty((n_roi * P2, 1024), dtype=torch.float32, device=dev)
-            ops.gemm_nt(sc2, st2, R * P2, 1024, K2p, lda=K2p, ldb=K2p, out=dense, ldc=1024, batch=B,
-                        batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 1024, k_true=K2)
-            tr = ops.gemm_nt(dense, wt_a, n_roi * P2, self.rcnn_dim, 1024, ldb=wt_a_ld,
-                             residual=tr_q, ldr=tr_q_ld)  # [n*49][64] == [n][3136]
+            rd_ = self.rcnn_dim
+            if sw is not None:
+                swt = ops.transpose_batched(sw.view(-1)[offset * P2 * rd_:], B, K2, rd_, ldi=rd_, ldo=K2p,
+                                            in_batch=way * shot * P2 * rd_)  # [B][64][K2p], zero padded
+                dense = None
+                tr = torch.empty((n_roi * P2, rd_), dtype=torch.float32, device=dev)
+                ops.gemm_nt(sc2, swt, R * P2, rd_, K2p, lda=K2p, ldb=K2p, out=tr, ldc=rd_, batch=B,
+                            batch_a=R * P2 * K2p, batch_b=rd_ * K2p, batch_c=R * P2 * rd_, k_true=K2)
+                ops.axpy_rows_(tr, tr_q, n_roi * P2, rd_, ld_y=rd_, ld_x=tr_q_ld)  # + q half (and the bias)
+            else:
+                st2 = ops.transpose_batched(sb, B, K2, 1024, ldi=1024, ldo=K2p, in_batch=way * shot * P2 * 1024)
+                dense = torch.empty((n_roi * P2, 1024), dtype=torch.float32, device=dev)
+                ops.gemm_nt(sc2, st2, R * P2, 1024, K2p, lda=K2p, ldb=K2p, out=dense, ldc=1024, batch=B,
+                            batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 1024, k_true=K2)
+                tr = ops.gemm_nt(dense, wt_a, n_roi * P2, rd_, 1024, ldb=wt_a_ld,
+                                 residual=tr_q, ldr=tr_q_ld)  # [n*49][64] == [n][3136]
             hid = ops.gemm_nt(tr, w1b3, n_roi, w1.size(0), P2 * self.rcnn_dim, ldb=w1ld, shift=b1, relu=True)
             score = ops.gemm_nt(hid, w2, n_roi, 2, w1.size(0), shift=b2)
             prob = ops.softmax_rows_to(score, prob_all[(n_roi if offset else 0):], n_roi, 2)[:n_roi]

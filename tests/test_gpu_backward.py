@@ -533,6 +533,46 @@ def test_merged_trunk_modes_equal_the_two_stream_trunk(dev, mfma_mode, merge_fro
             assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-12, k
 
 
+def test_reassociated_roi_attention_gives_the_reference_orders_losses_and_gradients(dev):
+    """round 4: tr = A . (S . Wt_a^T) + q half instead of (A . S) . Wt_a^T (DAnARCNN.fold_roi_attn, dana.py:279-286): the
+    [n*49][1024] attended tensor and its adjoints are never formed. Same mathematics in another order -> losses and every
+    gradient agree with the reference's order to fp32 roundoff (each form is checked against the oracle's autograd by
+    test_model_backward_vs_oracle_autograd; this pins them against each other and keeps the unfolded path alive)."""
+    import dana_amd
+    from dana_amd import synthetic as S, backward as BW
+    B, way, shot, H, W = 2, 2, 2, 160, 224
+    outs, grads = [], []
+    for fold in (True, False):
+        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=way, shot=shot, classes=["fg", "bg"])
+        m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=21, profile="test"))
+        m.to(dev).train()
+        m.fold_roi_attn = fold
+        m.save_for_backward = True
+        inputs = [t.to(dev) for t in S.episode_inputs(B, way, shot, H, W, seed=4)]
+        np.random.seed(7)
+        with torch.no_grad():
+            out = m(*inputs)
+        assert (m._ctx["heads"][0]["dense"] is None) == fold
+        for p_ in m.parameters():
+            p_.grad = None
+        BW.model_backward(m, (1.0, 1.0, 1.0, 1.0))
+        torch.cuda.synchronize()
+        outs.append([t.detach().clone() if torch.is_tensor(t) else t for t in out])
+        grads.append({k: p_.grad.detach().clone() for k, p_ in m.named_parameters() if p_.grad is not None})
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[7], b[7])
+    assert float((a[1] - b[1]).abs().max()) <= 2e-6
+    for i in range(3, 7):
+        assert abs(float(a[i]) - float(b[i])) <= 2e-6 * max(1.0, abs(float(b[i])))
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) >= 60
+    gmax = max(float(g_.abs().max()) for g_ in grads[1].values())
+    for k in grads[0]:
+        ga, gb = grads[0][k], grads[1][k]
+        # (biases in front of a mean subtraction / softmax have an exactly-zero gradient: round-off on both sides, hence
+        # the floor relative to the model's largest gradient, as in the oracle comparison above)
+        assert float((ga - gb).abs().max()) <= 2e-4 * (float(gb.abs().max()) + 1e-3 * gmax), k
+
+
 def test_two_stream_trunk_in_shared_buffers_does_not_race_on_recycled_blocks(dev):
     """The Trainer's forward (merge_trunk, merge_from 3) runs the query and the support batch on two streams over the row
     ranges of shared buffers that come from the caller's stream pool. A block that pool hands out may still be in use by a

@@ -579,6 +579,17 @@ def test_folded_roi_positional_encoding_equals_the_two_output_roi_align(dev, tra
         with torch.no_grad():
             outs.append(m(*inputs))
     a, b = outs
+    # (round 4, second fold of the forward-only path: (A . S) . Wt_a^T re-associated as A . (S . Wt_a^T), dana.py:279-286)
+    m.fold_roi_pe, m.fold_roi_attn = True, False
+    np.random.seed(4)
+    with torch.no_grad():
+        c = m(*inputs)
+    m.fold_roi_attn = True
+    assert torch.equal(a[0], c[0])
+    assert (a[1] - c[1]).abs().max().item() <= 2e-6 and (a[2] - c[2]).abs().max().item() <= 2e-5
+    if training:
+        for i in range(3, 7):
+            assert abs(float(a[i]) - float(c[i])) <= 2e-6 * max(1.0, abs(float(c[i])))
     assert torch.equal(a[0], b[0])
     assert (a[1] - b[1]).abs().max().item() <= 2e-6 and (a[2] - b[2]).abs().max().item() <= 2e-5
     if training:
