@@ -21,6 +21,7 @@ SAVED_WINOGRAD_V = __import__("os").environ.get("DANA_WGRAD_SAVED_V", "1") != "0
 PREFETCH_DGRAD_W = __import__("os").environ.get("DANA_PREFETCH_DGRAD_W", "1") != "0"  # trunk dgrad weights derived on a side stream
 LINEAR_WGRAD_ON_SIDE = __import__("os").environ.get("DANA_LINEAR_WGRAD_SIDE", "1") != "0"  # Linear dW / db off the dgrad chain
 GATHER_STRIDED_WGRAD = __import__("os").environ.get("DANA_WGRAD_GATHER", "1") != "0"
+MERGED_WINO_DGRAD = __import__("os").environ.get("DANA_MERGED_WINO_DGRAD", "1") != "0"  # merged blocks: one dual-group 3x3 dgrad
 RPN_CHAIN_EARLY = __import__("os").environ.get("DANA_RPN_CHAIN_EARLY", "1") != "0"  # RPN adjoints beside the RoI stage's
 
 
@@ -238,9 +239,17 @@ def bottleneck_backward_merged(g, sq, ss, sm, bp, grads, key):
     grads.add_conv(key + ".conv3", g, sm["o2"], 1, mt, 1, c3)
     g2 = conv_dgrad(g, 1, mt, 1, c3, mask=sm["o2"])
     g1 = torch.empty((mt, c2["cin"]), dtype=torch.float32, device=g.device)
+    ud = _dgrad_weights(c2)[1]
+    dual = MERGED_WINO_DGRAD and ud is not None and ud.size(0) == 36
     for part, s_ in ((slice(0, mq), sq), (slice(mq, mt), ss)):
         grads.add_conv(key + ".conv2", g2[part], sm["o1"][part], s_["n"], s_["h1"], s_["w1"], c2, v=s_.get("v2"))
-        conv_dgrad(g2[part], s_["n"], s_["h1"], s_["w1"], c2, mask=sm["o1"][part], out=g1[part])
+        if not dual:
+            conv_dgrad(g2[part], s_["n"], s_["h1"], s_["w1"], c2, mask=sm["o1"][part], out=g1[part])
+    if dual:
+        # both batches' 3x3 data gradients as ONE batched plane GEMM (two input / output transforms around it): the
+        # 600-tile launches of one batch leave a third of the chip's slots empty
+        ops.conv3x3_winograd_dual_dgrad(g2, sq["n"], sq["h1"], sq["w1"], ss["n"], ss["h1"], ss["w1"], c2["cout"], ud,
+                                        c2["cin"], mask=sm["o1"], out=g1)
     grads.add_conv(key + ".conv1", g1, sm["x"], 1, mt, 1, c1)
     return conv_dgrad(g1, 1, mt, 1, c1, residual=g, mask=sm["x"])
 

@@ -613,7 +613,21 @@ int dana_conv3x3_winograd4_nhwc_dual(const float* input, const float* u, float* 
                                      const float* shift, int n0, int h0, int w0, int n1, int h1, int w1, int cin,
                                      int cout, long in_pix_stride, long out0_pix_stride, long out1_pix_stride, int flags,
                                      void* workspace, size_t workspace_bytes, dana_stream_t stream) {
+  return dana_conv3x3_winograd4_nhwc_dual_masked(input, u, out0, out1, scale, shift, nullptr, nullptr, n0, h0, w0, n1, h1,
+                                                 w1, cin, cout, in_pix_stride, out0_pix_stride, out1_pix_stride, 0, 0,
+                                                 flags, workspace, workspace_bytes, stream);
+}
+
+int dana_conv3x3_winograd4_nhwc_dual_masked(const float* input, const float* u, float* out0, float* out1,
+                                            const float* scale, const float* shift, const float* mask0,
+                                            const float* mask1, int n0, int h0, int w0, int n1, int h1, int w1, int cin,
+                                            int cout, long in_pix_stride, long out0_pix_stride, long out1_pix_stride,
+                                            long mask0_pix_stride, long mask1_pix_stride, int flags, void* workspace,
+                                            size_t workspace_bytes, dana_stream_t stream) {
   const char* who = "dana_conv3x3_winograd4_nhwc_dual";
+  const long ldm0 = mask0_pix_stride > 0 ? mask0_pix_stride : cout, ldm1 = mask1_pix_stride > 0 ? mask1_pix_stride : cout;
+  DANA_CHECK_ARG((!mask0 || (ldm0 % 4 == 0 && ((uintptr_t)mask0 & 15) == 0)) && (!mask1 || (ldm1 % 4 == 0 && ((uintptr_t)mask1 & 15) == 0)),
+                 "%s: mask rows must be 16-byte aligned", who);
   DANA_CHECK_ARG(n0 > 0 && n1 > 0 && h0 > 0 && w0 > 0 && h1 > 0 && w1 > 0 && cin > 0 && cout > 0 && cin % 4 == 0 && cout % 4 == 0,
                  "%s: bad shape", who);
   DANA_CHECK_ARG(input && u && out0 && out1, "%s: null pointer", who);
@@ -647,9 +661,9 @@ int dana_conv3x3_winograd4_nhwc_dual(const float* input, const float* u, float* 
                         w3 ? 3 * cout * kp : (long)cout * cin, T * cout, 1.f, w3 ? DANA_W_SPLIT3 : 0, stream);
   if (rc) return rc;
   const int relu = (flags & DANA_EPI_RELU) ? 1 : 0;
-  wino4_output_kernel<<<dana_ceil_div(p0.tiles * N4, 256), 256, 0, s>>>(M, out0, scale, shift, nullptr, 0, h0, w0, N4, p0.th,
+  wino4_output_kernel<<<dana_ceil_div(p0.tiles * N4, 256), 256, 0, s>>>(M, out0, scale, shift, mask0, ldm0, h0, w0, N4, p0.th,
                                                                        p0.tw, p0.tiles, ldc0, relu, T, 0);
-  wino4_output_kernel<<<dana_ceil_div(p1.tiles * N4, 256), 256, 0, s>>>(M, out1, scale, shift, nullptr, 0, h1, w1, N4, p1.th,
+  wino4_output_kernel<<<dana_ceil_div(p1.tiles * N4, 256), 256, 0, s>>>(M, out1, scale, shift, mask1, ldm1, h1, w1, N4, p1.th,
                                                                        p1.tw, p1.tiles, ldc1, relu, T, p0.tiles);
   DANA_CHECK_LAUNCH("dana_conv3x3_winograd4_nhwc_dual(output transforms)");
   return DANA_OK;

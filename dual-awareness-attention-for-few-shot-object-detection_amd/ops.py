@@ -819,23 +819,39 @@ def conv1x1_cat2_dual(a0, k0, a1, k1, n0, h0, w0, n1, h1, w1, stride1, w_cat, sh
     return out0, out1, (oh0, ow0), (oh1, ow1)
 
 
-def conv3x3_winograd_dual(x, n0, h0, w0, n1, h1, w1, cin, u, cout, scale=None, shift=None, relu=False):
+def conv3x3_winograd_dual(x, n0, h0, w0, n1, h1, w1, cin, u, cout, scale=None, shift=None, relu=False, mask=None, out=None):
     """stride-1 pad-1 3x3 conv through Winograd F(4x4,3x3) over two image groups with ONE batched plane GEMM (x: group
-    0's pixels, then group 1's) -> merged [M0 + M1][cout]"""
+    0's pixels, then group 1's) -> merged [M0 + M1][cout]. mask [M0 + M1][cout]: the ReLU adjoint of a data gradient
+    (zero where mask <= 0), as in conv3x3_winograd(mask=...)."""
     _chk(x, "x")
     up, wfl = _wf(u)
     if (u.batch if isinstance(u, W3) else u.size(0)) != 36:
         raise ValueError("conv3x3_winograd_dual: F(4x4,3x3) filters only")
     m0, m1 = n0 * h0 * w0, n1 * h1 * w1
-    out = torch.empty((m0 + m1, cout), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((m0 + m1, cout), dtype=torch.float32, device=x.device)
     ws = _ws(lib().query("dana_conv3x3_winograd4_dual_workspace_bytes", n0, h0, w0, n1, h1, w1, cin, cout), x.device)
     e0 = _prof_begin()
-    lib().call("dana_conv3x3_winograd4_nhwc_dual", _p(x), up, _p(out), _p(out[m0:]), _p(scale), _p(shift), n0, h0, w0,
-               n1, h1, w1, cin, cout, 0, 0, 0, (EPI_RELU if relu else 0) | wfl, _p(ws), ws.numel(), _stream())
+    lib().call("dana_conv3x3_winograd4_nhwc_dual_masked", _p(x), up, _p(out), _p(out[m0:]), _p(scale), _p(shift),
+               _p(mask), _p(mask[m0:]) if mask is not None else None, n0, h0, w0, n1, h1, w1, cin, cout, 0, 0, 0, 0, 0,
+               (EPI_RELU if relu else 0) | wfl, _p(ws), ws.numel(), _stream())
     tiles = n0 * ((h0 + 3) // 4) * ((w0 + 3) // 4) + n1 * ((h1 + 3) // 4) * ((w1 + 3) // 4)
     _prof_end(e0, ("wino3x3 M=%d N=%d K=%d s1", (m0 + m1, cout, 9 * cin)), 2.0 * (m0 + m1) * cout * 9 * cin,
               4.0 * 36 * (tiles * (cin + cout) + cout * cin), executed=2.0 * 36 * tiles * cin * cout)
     return out
+
+
+def conv3x3_winograd_dual_dgrad(grad_out, n0, h0, w0, n1, h1, w1, cout, ud, cin, mask=None, out=None):
+    """data gradient of a stride-1 pad-1 3x3 conv over two image groups (the forward kernel on the flipped / transposed
+    filters ud, as conv2d_dgrad does per group), labelled as a data gradient in the per-launch profile"""
+    global PROF_ROLE
+    if PROFILE is not None and PROF_ROLE is None:
+        PROF_ROLE = "dgrad"
+        try:
+            return conv3x3_winograd_dual(grad_out, n0, h0, w0, n1, h1, w1, cout, ud, cin, mask=mask, out=out)
+        finally:
+            PROF_ROLE = None
+    return conv3x3_winograd_dual(grad_out, n0, h0, w0, n1, h1, w1, cout, ud, cin, mask=mask, out=out)
 
 
 def winograd_filter_transform(w_packed, cout, cin, tile=2):

@@ -233,6 +233,15 @@ int dana_conv3x3_winograd4_nhwc_dual(const float* input, const float* u, float* 
                                      const float* shift, int n0, int h0, int w0, int n1, int h1, int w1, int cin,
                                      int cout, long in_pix_stride, long out0_pix_stride, long out1_pix_stride, int flags,
                                      void* workspace, size_t workspace_bytes, dana_stream_t stream);
+/* ... with the ReLU adjoint of the masked data-gradient form (dana_conv3x3_winograd4_nhwc_masked) per group: out = mask > 0 ?
+ * conv : 0. The merged backward of an identity bottleneck (resnet.py:84-100 differentiated over the [query | support]
+ * buffers) runs its 3x3 data gradient for both batches as ONE batched plane GEMM with it. mask0 / mask1 may be NULL. */
+int dana_conv3x3_winograd4_nhwc_dual_masked(const float* input, const float* u, float* out0, float* out1,
+                                            const float* scale, const float* shift, const float* mask0,
+                                            const float* mask1, int n0, int h0, int w0, int n1, int h1, int w1, int cin,
+                                            int cout, long in_pix_stride, long out0_pix_stride, long out1_pix_stride,
+                                            long mask0_pix_stride, long mask1_pix_stride, int flags, void* workspace,
+                                            size_t workspace_bytes, dana_stream_t stream);
 
 /* weight gradient of a stride-1 pad-1 3x3 conv in the F(4x4,3x3) domain: dU[36] = sum over tiles of
  * (A dY A^T)^T (B^T x B), dW = G^T dU G -- 4x fewer multiplies than dana_conv2d_wgrad_nhwc; same packed
