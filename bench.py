@@ -336,15 +336,29 @@ def main():
                 step = lambda: run(*run.inputs)  # noqa: E731
     graph_step = step
 
+    def median_interval(evs):
+        """median GPU-side interval between consecutive iteration-end events (ms): robust against the host stalls of a
+        shared box, reported NEXT to the wall-clock figure the contract asks for"""
+        iv = sorted(a.elapsed_time(b) for a, b in zip(evs, evs[1:]))
+        return round(iv[len(iv) // 2], 3) if iv else None
+
     def trial(fn, k):
+        """ms per step of k steps: the MEDIAN GPU-side interval between consecutive steps (one slow step -- a collector
+        pause, the first eager steps after a capture re-deriving their plan -- must not decide the launch mode), falling
+        back to the wall-clock mean where no median is available"""
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True)]
+        marks[0].record()
         t0 = time.perf_counter()
         for _ in range(k):
             fn()
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / k * 1e3
+        mean = (time.perf_counter() - t0) / k * 1e3
+        return median_interval(marks) or mean
 
     launch_trial = None
     if use_graphs and args.launch == "auto":
@@ -385,12 +399,6 @@ def main():
         if world > 1:
             dist_barrier()
         torch.cuda.synchronize()
-
-    def median_interval(evs):
-        """median GPU-side interval between consecutive iteration-end events (ms): robust against the host stalls of a
-        shared box, reported NEXT to the wall-clock figure the contract asks for"""
-        iv = sorted(a.elapsed_time(b) for a, b in zip(evs, evs[1:]))
-        return round(iv[len(iv) // 2], 3) if iv else None
 
     barrier()
     marks_f = [torch.cuda.Event(enable_timing=True)]
@@ -473,8 +481,8 @@ def main():
             graph_train_step = lambda: gtr.step(*gtr.inputs)  # noqa: E731
             train_step = graph_train_step
             if args.launch == "auto":
-                ts_trial = {"graph_ms_per_step": round(trial(graph_train_step, 8), 3),
-                            "eager_ms_per_step": round(trial(eager_train_step, 8), 3)}
+                ts_trial = {"graph_ms_per_step": round(trial(graph_train_step, 12), 3),
+                            "eager_ms_per_step": round(trial(eager_train_step, 12), 3)}
                 ts_eager = ts_trial["eager_ms_per_step"] < ts_trial["graph_ms_per_step"]
                 if world > 1:
                     t = torch.tensor([ts_trial["graph_ms_per_step"], ts_trial["eager_ms_per_step"]], device=dev)
