@@ -19,6 +19,9 @@ from .config import cfg
 USE_WINOGRAD_WGRAD = __import__("os").environ.get("DANA_WINO_WGRAD", "1") != "0"
 SAVED_WINOGRAD_V = __import__("os").environ.get("DANA_WGRAD_SAVED_V", "1") != "0"  # weight gradients reuse the forward's V planes
 PREFETCH_DGRAD_W = __import__("os").environ.get("DANA_PREFETCH_DGRAD_W", "1") != "0"  # trunk dgrad weights derived on a side stream
+# 3 (default): the RPN conv's and layer4's copies are derived on their own chains, the trunk's on a side stream issued BEHIND the
+# heads' backward; 1: everything on the side stream from the backward's start (round 3); 2: the trunk's from the start; 0: all lazy
+PREFETCH_MODE = int(__import__("os").environ.get("DANA_PREFETCH_MODE", "3"))
 LINEAR_WGRAD_ON_SIDE = __import__("os").environ.get("DANA_LINEAR_WGRAD_SIDE", "1") != "0"  # Linear dW / db off the dgrad chain
 GATHER_STRIDED_WGRAD = __import__("os").environ.get("DANA_WGRAD_GATHER", "1") != "0"
 MERGED_WINO_DGRAD = __import__("os").environ.get("DANA_MERGED_WINO_DGRAD", "1") != "0"  # merged blocks: one dual-group 3x3 dgrad
@@ -486,27 +489,38 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     ug = model.unary_gamma
 
     # -- the trunk's data-gradient weights (flipped / transposed / BN-scaled copies, Winograd-domain filters: ~45 small
-    #    launches that depend on the weights only) are derived NOW on a stream of their own, under the heads' backward,
-    #    instead of one by one in front of the trunk's data-gradient launches that need them (the chain every other
-    #    launch of the trunk's backward waits for); joined into the caller's stream before the pause below --
+    #    launches that depend on the weights only) are derived on a stream of their own instead of one by one in front of
+    #    the trunk's data-gradient launches that need them (the chain every other launch of the trunk's backward waits
+    #    for); joined into the caller's stream before the pause below. Round 4: that stream is issued BEHIND the heads'
+    #    backward, not at the backward's start -- since the RPN chain starts there too, ~55 more small launches on a
+    #    seventh stream slowed the three chains down (17.15 -> 16.86 ms per iteration, PREFETCH_MODE 1 vs 3); the RPN
+    #    conv's and layer4's copies are derived by their own chains --
     rpn = model.RCNN_rpn
     c_rpn = _rpn_conv_plan(model, ctx)
     dgw_ready = l4w_ready = rpnw_ready = None
-    if PREFETCH_DGRAD_W and not getattr(model, "_single_stream", False):
+    pmode = PREFETCH_MODE if (PREFETCH_DGRAD_W and not getattr(model, "_single_stream", False)) else 0
+    seen = set()
+
+    def derive(saved):
+        for sv in reversed(saved):
+            for name in ("c3", "c2", "c1", "ds"):
+                c = sv["bp"].get(name)
+                if c is not None and id(c) not in seen:
+                    seen.add(id(c))
+                    _dgrad_weights(c)
+
+    def prefetch_trunk():
+        prep = model._stream("dgradw", dev)
+        prep.wait_event(ops.record_event())
+        with ops.on_stream(prep):
+            derive(ctx["q_saved"])
+            return ops.record_event()
+
+    if pmode == 1:
         prep = model._stream("dgradw", dev)
         ev0 = ops.record_event()
         prep.wait_event(ev0)
         with ops.on_stream(prep):
-            seen = set()
-
-            def derive(saved):
-                for sv in reversed(saved):
-                    for name in ("c3", "c2", "c1", "ds"):
-                        c = sv["bp"].get(name)
-                        if c is not None and id(c) not in seen:
-                            seen.add(id(c))
-                            _dgrad_weights(c)
-
             # (in the order the backward needs them: the RPN chain and the box branch start at once, then the trunk)
             _dgrad_weights(c_rpn)
             rpnw_ready = ops.record_event()
@@ -514,6 +528,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
             l4w_ready = ops.record_event()
             derive(ctx["q_saved"])
             dgw_ready = ops.record_event()
+    elif pmode == 2:
+        dgw_ready = prefetch_trunk()
 
     # -- RPN chain (_rpn_chain). It depends on the forward's saved tensors only and meets the RoI stage's gradients in
     #    base_feat / the support maps, so it runs on a stream of its own FROM THE START of the backward, beside the box
@@ -667,6 +683,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     _acc(model.rcnn_unary_layer.bias, ops.colsum(d_un2, Ns * P2, 1))
     (sh_, sw_), pool = ctx["sup_map"], ctx["sup_pool"]
     d_sup = ops.avgpool_backward(d_sp_pe, Ns, sh_, sw_, 1024, pool[0], pool[1])  # [Ns][L][1024]
+    if pmode == 3:
+        dgw_ready = prefetch_trunk()
     grads.join()  # (the heads' Linear weight / bias gradients were accumulated on the weight-gradient stream)
     _ready(model, stages[1][1])
 
