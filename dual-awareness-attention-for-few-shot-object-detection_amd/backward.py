@@ -29,6 +29,7 @@ PREFETCH_MODE = int(__import__("os").environ.get("DANA_PREFETCH_MODE", "3"))
 LINEAR_WGRAD_ON_SIDE = __import__("os").environ.get("DANA_LINEAR_WGRAD_SIDE", "auto")
 GATHER_STRIDED_WGRAD = __import__("os").environ.get("DANA_WGRAD_GATHER", "1") != "0"
 MERGED_WINO_DGRAD = __import__("os").environ.get("DANA_MERGED_WINO_DGRAD", "1") != "0"  # merged blocks: one dual-group 3x3 dgrad
+RPN_CHAIN_ORDER = int(__import__("os").environ.get("DANA_RPN_CHAIN_ORDER", "0"))  # host issue order: 0 first, 1 behind the box branch, 2 behind the heads
 RPN_CHAIN_EARLY = __import__("os").environ.get("DANA_RPN_CHAIN_EARLY", "1") != "0"  # RPN adjoints beside the RoI stage's
 
 
@@ -550,16 +551,20 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     capturing = torch.cuda.is_current_stream_capturing()
     rpn_early = RPN_CHAIN_EARLY and not single
     rpn_out = rpn_done = None
-    if rpn_early:
+    rpn_start = ops.record_event() if rpn_early else None
+
+    def launch_rpn_chain():
         rpn_stream = model._stream("rpn_bwd", dev)
-        start = ops.record_event()
-        rpn_stream.wait_event(start)
+        rpn_stream.wait_event(rpn_start)
         with ops.on_stream(rpn_stream):
             grads_r = WeightGrads(None if capturing else model._stream("wgrad_rpn", dev), model)
-            rpn_out = _rpn_chain(model, ctx, g1, g2, g_dev, grads_r, rpnw_ready)
-            for t_ in rpn_out:
+            out = _rpn_chain(model, ctx, g1, g2, g_dev, grads_r, rpnw_ready)
+            for t_ in out:
                 t_.record_stream(main)
-            rpn_done = ops.record_event()
+            return out, ops.record_event()
+
+    if rpn_early and RPN_CHAIN_ORDER == 0:
+        rpn_out, rpn_done = launch_rpn_chain()
 
     # -- seeds: d RCNN losses / d (scores, bbox_pred) were written by the fused loss kernel (dana_rcnn_loss);
     #    the upstream scalars g3 / g4 ride as alpha on the first launches that consume them --
@@ -599,6 +604,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         grads.finish_all(model, "RCNN_top")
         _ready(model, stages[0][1])
         box_done = ops.record_event()
+    if rpn_early and RPN_CHAIN_ORDER == 1:
+        rpn_out, rpn_done = launch_rpn_chain()
 
     # -- RoI-level attention heads (dana.py:248-292), positive then negative supports --
     q_pe, q2, sp_pe, k2, un2 = ctx["q_pe"], ctx["q2"], ctx["sp_pe"], ctx["k2"], ctx["un2"]
@@ -688,6 +695,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     _acc(model.rcnn_unary_layer.bias, ops.colsum(d_un2, Ns * P2, 1))
     (sh_, sw_), pool = ctx["sup_map"], ctx["sup_pool"]
     d_sup = ops.avgpool_backward(d_sp_pe, Ns, sh_, sw_, 1024, pool[0], pool[1])  # [Ns][L][1024]
+    if rpn_early and RPN_CHAIN_ORDER == 2:
+        rpn_out, rpn_done = launch_rpn_chain()
     if pmode == 3:
         dgw_ready = prefetch_trunk()
     grads.join()  # (the heads' Linear weight / bias gradients were accumulated on the weight-gradient stream)
