@@ -19,9 +19,11 @@ from .config import cfg
 USE_WINOGRAD_WGRAD = __import__("os").environ.get("DANA_WINO_WGRAD", "1") != "0"
 SAVED_WINOGRAD_V = __import__("os").environ.get("DANA_WGRAD_SAVED_V", "1") != "0"  # weight gradients reuse the forward's V planes
 PREFETCH_DGRAD_W = __import__("os").environ.get("DANA_PREFETCH_DGRAD_W", "1") != "0"  # trunk dgrad weights derived on a side stream
-# 3 (default): the RPN conv's and layer4's copies are derived on their own chains, the trunk's on a side stream issued BEHIND the
-# heads' backward; 1: everything on the side stream from the backward's start (round 3); 2: the trunk's from the start; 0: all lazy
-PREFETCH_MODE = int(__import__("os").environ.get("DANA_PREFETCH_MODE", "3"))
+# 1 (default): everything on the side stream from the backward's start (round 3); 3: the RPN conv's and layer4's copies derived
+# on their own chains, the trunk's on a side stream issued BEHIND the heads' backward; 2: the trunk's from the start; 0: all lazy.
+# Which is fastest depends on what the PROCESS did before (profiles/r4_graph_handover.md 3): in a process that only trains,
+# mode 3 wins by 0.3 ms (17.15 -> 16.86); behind bench.py's forward runs and graph captures mode 1 wins by 1.6 ms (18.47 -> 16.88).
+PREFETCH_MODE = int(__import__("os").environ.get("DANA_PREFETCH_MODE", "1"))
 # Linear dW / db off the dgrad chain, on the weight-gradient stream: "1" always, "0" never, "auto" (default) only under stream
 # capture. Round 3 measured -0.5 ms for the side stream; since the RPN chain runs beside the box branch and the heads from the
 # backward's start (round 4), the eager iteration is 0.3 ms FASTER with these launches on the heads' own chain (17.40 -> 17.08 ms,
@@ -497,10 +499,8 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     # -- the trunk's data-gradient weights (flipped / transposed / BN-scaled copies, Winograd-domain filters: ~45 small
     #    launches that depend on the weights only) are derived on a stream of their own instead of one by one in front of
     #    the trunk's data-gradient launches that need them (the chain every other launch of the trunk's backward waits
-    #    for); joined into the caller's stream before the pause below. Round 4: that stream is issued BEHIND the heads'
-    #    backward, not at the backward's start -- since the RPN chain starts there too, ~55 more small launches on a
-    #    seventh stream slowed the three chains down (17.15 -> 16.86 ms per iteration, PREFETCH_MODE 1 vs 3); the RPN
-    #    conv's and layer4's copies are derived by their own chains --
+    #    for); joined into the caller's stream before the pause below. (PREFETCH_MODE 3 issues that stream behind the
+    #    heads' backward instead: faster in a process that only trains, much slower behind other work -- see above) --
     rpn = model.RCNN_rpn
     c_rpn = _rpn_conv_plan(model, ctx)
     dgw_ready = l4w_ready = rpnw_ready = None
