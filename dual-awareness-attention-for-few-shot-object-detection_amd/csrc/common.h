@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <atomic>
 
 #define DANA_OK 0
 #define DANA_ERR_ARG (-1)
@@ -30,6 +31,19 @@ void dana_set_error(const char* fmt, ...);
       return DANA_ERR_HIP;                                                    \
     }                                                                         \
   } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE attribute of a kernel: the opt-in above 64 KiB is made
+// once per (kernel, device) -- a process that drives several devices (nn.DataParallel's thread per device,
+// include/dana_hip.h) launches on each of them. One static DeviceOnce per kernel instantiation.
+struct DeviceOnce {
+  std::atomic<unsigned long long> done{0};  // bit d: device d has the attribute (devices >= 64: set on every call)
+  bool need() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const unsigned long long bit = 1ull << dev;
+    return !(done.fetch_or(bit, std::memory_order_relaxed) & bit);
+  }
+};
 
 static inline int dana_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t dana_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

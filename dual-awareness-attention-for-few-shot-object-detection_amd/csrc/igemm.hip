@@ -81,6 +81,9 @@ struct IgemmParams {
   const float* shift2;
   int N2, relu2;
   unsigned a2_bytes;
+  // A as pre-split planes (igemm_pp_kernel): A = bf16 planes [Kp / 16][3][a_rows][16] of the activation rows (the layout of
+  // dana_split_weight with n = a_rows), written by the producing kernel's epilogue or by dana_split_weight; GEMM geometry only
+  int apre, a_rows;
   unsigned long long* trace;  // debug (dana_set_igemm_trace): per block {start, first MFMA, loop end, end} in 100 MHz ticks + HW id
 };
 
@@ -448,10 +451,126 @@ constexpr StepSched<NM, NL, NR, NCVF, NBW> make_step_sched() {
 template <int NM, int NL, int NR, int NCVF, int NBW>
 inline constexpr StepSched<NM, NL, NR, NCVF, NBW> kStepSched = make_step_sched<NM, NL, NR, NCVF, NBW>();
 
+// ---- epilogue on the accumulator registers (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+// With the output channel on the lane axis one accumulator register across a half-wave is 32 consecutive floats of one
+// output row = one 128-byte segment, so scale / shift / residual / ReLU / mask run where the values are and every access is
+// a dword buffer access (descriptor + 32-bit lane offset + a uniform row term): no LDS C tile (49 instead of 67.6 KB per
+// 128 x 128 tile), no barrier, no alignment condition on the rows. Rows past M fall outside the descriptors' ranges (loads
+// return zeros, stores are dropped); lanes whose channel is past N carry an out-of-range offset. Same arithmetic, in the
+// same order, as the LDS form of igemm_split_body (ELDS: dana_set_epilogue_mode(1)) -> the same bits.
+template <int BM, int BN, int HALVES = 0, int WITH_MASK = 1>
+__device__ __forceinline__ void epilogue_regs(const IgemmParams& p, f32x16 (&acc)[BM / 64][BN / 64], int m0, int n0, float* Cb,
+                                              int wm, int wn, int li, int lh) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  // (uniform) the tile lies in ONE geometry segment -- rows past M are not a segment: the descriptors' ranges drop them
+  const bool one_seg = m0 + BM <= p.M0 || m0 >= p.M0 || p.M0 >= p.M;
+  float scv[TN], shv[TN];
+  int ncol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    ncol[j] = n0 + wn * (BN / 2) + j * 32 + li;
+    const bool nok = ncol[j] < p.N;
+    scv[j] = ((nok && p.scale) ? p.scale[ncol[j]] : 1.f) * p.alpha;
+    shv[j] = (nok && p.shift) ? p.shift[ncol[j]] : 0.f;
+  }
+  if (one_seg) {
+    const bool seg1 = m0 >= p.M0;
+    const long ld_c = seg1 ? p.ldc1 : p.ldc, ld_r = seg1 ? p.ldr1 : p.ldr;
+    const long mrel = seg1 ? m0 - p.M0 : m0;
+    const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
+    const int ldc4 = (int)ld_c * 4, ldr4 = (int)ld_r * 4, ldm4 = (int)p.ldm * 4;
+    const __amdgpu_buffer_rsrc_t rc_dst = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((seg1 ? p.C1 : Cb) + mrel * ld_c), 0, rows_valid * ldc4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc_res = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.residual ? (seg1 ? p.residual1 : p.residual) + mrel * ld_r : p.A), 0, p.residual ? rows_valid * ldr4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc_msk = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.mask ? p.mask + (long)m0 * p.ldm : p.A), 0, p.mask ? rows_valid * ldm4 : 0, 0x00020000);
+    const int lrow = wm * (BM / 2) + 4 * lh;  // the lane's first row of the tile
+    unsigned vo_c[TN], vo_r[TN], vo_m[TN];    // lane offsets (bytes) at accumulator row 0; out of range past N
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bool nok = ncol[j] < p.N;
+      vo_c[j] = nok ? (unsigned)(lrow * ldc4 + ncol[j] * 4) : OOB;
+      vo_r[j] = nok ? (unsigned)(lrow * ldr4 + ncol[j] * 4) : OOB;
+      vo_m[j] = nok ? (unsigned)(lrow * ldm4 + ncol[j] * 4) : OOB;
+    }
+    auto run = [&](auto res_c, auto relu_c, auto mask_c) {
+      constexpr bool RES = decltype(res_c)::value != 0, RELU = decltype(relu_c)::value != 0, MASK = decltype(mask_c)::value != 0;
+      // Without a mask all residual rows of the tile are requested before the first is used (one memory round trip per
+      // tile); a data-gradient launch (mask rows on top) works in halves of 32 rows per wave so that the requested rows
+      // stay inside the two-workgroups-per-CU register budget.
+      constexpr int HI = (MASK || HALVES) ? 1 : TM;  // accumulator tile rows (i) per pass (HALVES: a kernel on a three-
+                                                     // workgroups-per-CU register budget requests 32 residual values at a time)
+#pragma unroll
+      for (int i0 = 0; i0 < TM; i0 += HI) {
+        float res[RES ? HI : 1][TN][16], msk[MASK ? HI : 1][TN][16];
+#pragma unroll
+        for (int ii = 0; ii < HI; ++ii)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rt = (i0 + ii) * 32 + (r & 3) + 8 * (r >> 2);
+              if constexpr (RES)
+                res[ii][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc_res, (int)(vo_r[j] + (unsigned)(rt * ldr4)), 0, 0));
+              if constexpr (MASK)
+                msk[ii][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc_msk, (int)(vo_m[j] + (unsigned)(rt * ldm4)), 0, 0));
+            }
+#pragma unroll
+        for (int ii = 0; ii < HI; ++ii)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rt = (i0 + ii) * 32 + (r & 3) + 8 * (r >> 2);
+              float v = acc[i0 + ii][j][r] * scv[j] + shv[j];
+              if constexpr (RES) v += res[ii][j][r];
+              if constexpr (RELU) v = fmaxf(v, 0.f);
+              if constexpr (MASK) v = msk[ii][j][r] > 0.f ? v : 0.f;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc_dst, (int)(vo_c[j] + (unsigned)(rt * ldc4)), 0, 0);
+            }
+      }
+    };
+    if (WITH_MASK && p.mask) {  // (data gradients)
+      if (p.residual) {
+        if (p.relu) run(IC<1>{}, IC<1>{}, IC<1>{});
+        else run(IC<1>{}, IC<0>{}, IC<1>{});
+      } else {
+        if (p.relu) run(IC<0>{}, IC<1>{}, IC<1>{});
+        else run(IC<0>{}, IC<0>{}, IC<1>{});
+      }
+    } else if (p.residual) {
+      if (p.relu) run(IC<1>{}, IC<1>{}, IC<0>{});
+      else run(IC<1>{}, IC<0>{}, IC<0>{});
+    } else {
+      if (p.relu) run(IC<0>{}, IC<1>{}, IC<0>{});
+      else run(IC<0>{}, IC<0>{}, IC<0>{});
+    }
+  } else {
+    // the one tile row that straddles M0: every row picks its segment's output / residual rows (64-bit addresses)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M && ncol[j] < p.N) {
+            const bool s1 = m >= p.M0;
+            float v = acc[i][j][r] * scv[j] + shv[j];
+            if (p.residual) v += s1 ? p.residual1[(long)(m - p.M0) * p.ldr1 + ncol[j]] : p.residual[(long)m * p.ldr + ncol[j]];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.mask && !(p.mask[(long)m * p.ldm + ncol[j]] > 0.f)) v = 0.f;
+            (s1 ? p.C1 + (long)(m - p.M0) * p.ldc1 : Cb + (long)m * p.ldc)[ncol[j]] = v;
+          }
+        }
+  }
+}
+
 // BPRE: the B operand is a WEIGHT that was split once per weight version (dana_split_weight: three bf16 planes per
 // K-step, [Kp / 16][3][N][16], Kp = K rounded up to 16, zero padded): its chunks of 8 bf16 go from HBM to the LDS planes as loaded, and
 // the K loop splits the activation rows only -- half the VALU work of the step.
-template <int BM, int BN, int STEM, int BPRE = 0, int FUSE = 0>
+template <int BM, int BN, int STEM, int BPRE = 0, int FUSE = 0, int ELDS = 0>
 __device__ __forceinline__ void igemm_split_body(const IgemmParams& p) {
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
   constexpr int RA = BM / 64;                // float4 loads of A per thread per K-step (64 rows per pass)
@@ -833,7 +952,7 @@ __device__ __forceinline__ void igemm_split_body(const IgemmParams& p) {
     k_step(0, fa0, fb0, fa1, fb1, ra0, rb0, ra1, rb1);
     k_step(1, fa1, fb1, fa0, fb0, ra1, rb1, ra0, rb0);
   }
-  __syncthreads();  // (the last steps' staging writes / fragment reads vs the epilogue's use of the same LDS)
+  if constexpr (FUSE || ELDS) __syncthreads();  // (the last steps' staging writes / fragment reads vs the epilogue's use of the same LDS)
   const unsigned long long t_loop_end = p.trace ? __builtin_readcyclecounter() : 0ull;
 
   if constexpr (FUSE) {
@@ -938,6 +1057,23 @@ __device__ __forceinline__ void igemm_split_body(const IgemmParams& p) {
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc_dst,
                                                 vc + (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4, 0, 0);
         }
+    }
+    return;
+  }
+
+  // ---- epilogue on the accumulator registers (default): epilogue_regs above
+  if constexpr (!ELDS) {
+    epilogue_regs<BM, BN>(p, acc, m0, n0, Cb, wm, wn, li, lh);
+    if (p.trace && tid == 0) {
+      unsigned long long* tr = p.trace + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+      tr[0] = t_start;
+      tr[1] = t_loop;
+      tr[2] = t_loop_end;
+      tr[3] = __builtin_readcyclecounter();
+      tr[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID | XCC_ID
+      tr[5] = wall_clock64();
+      tr[6] = w_start;
+      tr[7] = 0;
     }
     return;
   }
@@ -1148,16 +1284,301 @@ __device__ __forceinline__ void igemm_split_body(const IgemmParams& p) {
 // The kernels proper. The 128 x 128 tile is compiled for TWO workgroups per CU: 192 arch VGPRs beside its 64 accumulator
 // registers (the compiler, left alone with the one-block bound, spends 200+ on the epilogue's prefetches and halves the
 // occupancy of the whole K loop).
-template <int BM, int BN, int STEM, int BPRE = 0, int FUSE = 0>
+template <int BM, int BN, int STEM, int BPRE = 0, int FUSE = 0, int ELDS = 0>
 __global__ void __launch_bounds__(256, 2) igemm_split_kernel(IgemmParams p) {
-  igemm_split_body<BM, BN, STEM, BPRE, FUSE>(p);
+  igemm_split_body<BM, BN, STEM, BPRE, FUSE, ELDS>(p);
 }
-template <int STEM, int BPRE>
+template <int STEM, int BPRE, int ELDS>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) igemm_split_kernel_128(IgemmParams p) {
-  igemm_split_body<128, 128, STEM, BPRE, 0>(p);
+  igemm_split_body<128, 128, STEM, BPRE, 0, ELDS>(p);
 }
 
-#include "igemm_ws.h"
+// ---- the three-workgroups-per-CU contraction kernel (igemm_dma_kernel): weights by LDS-DMA, single fragment set --------------
+// Round 5. igemm_split_kernel_128 keeps two fragment sets and two staging register sets per operand in flight (224 registers:
+// two workgroups per CU) and its tiles spend as long in prologue + epilogue as in a short K loop. This kernel gives the
+// registers back to occupancy:
+//  * the pre-split WEIGHT planes go from L2 straight into the LDS planes by LDS-DMA (buffer_load_dwordx4 ... lds: a wave
+//    instruction moves 32 rows x 32 bytes = 1 KB of one plane; the LDS image is lane-linear, so the 16-byte halves of a row
+//    are swizzled on the SOURCE address): no staging registers, no staging writes for B;
+//  * ONE fragment set: a step reads its 12 fragments behind the barrier that publishes the tile, then issues its 24 MFMAs
+//    -- with three waves per SIMD the other workgroups' MFMAs run in that shadow;
+//  * the activation rows (APRE = 0: fp32 rows, any conv geometry of igemm_split_body) keep ONE staging register set: tile
+//    t + 2's rows, requested a step ago, are split and written behind step t's second barrier, then tile t + 3's are requested;
+//  * APRE = 1: the activation rows arrive as the three bf16 planes of their exact split ([Kp/16][3][rows][16], the weight
+//    layout: written by a producer's epilogue or by dana_split_weight) and take the DMA path as well: no fp32 operand left
+//    to split, no VALU between the matrix instructions, and the pipeline depth is a template parameter (NST stages).
+//  * epilogue on the accumulator registers (epilogue_regs), residual rows requested in halves.
+//  NST = 2: 49.2 KB of LDS, <= 168 registers: THREE workgroups per CU; two barriers per K-step (tile published / stage free).
+//  NST >= 3 (APRE only): one barrier per K-step, NST - 1 tiles in flight (3: two workgroups per CU, 6: one -- tile-starved
+//  long-K launches are bound by the depth of their request pipeline, not by the matrix pipe).
+// Same K-step order, same split, the same six products in the same order as igemm_split_kernel -> the same bits.
+template <int BN, int NST, int APRE>
+__global__ void __launch_bounds__(256, NST == 2 ? 3 : (NST == 3 ? 2 : 1)) igemm_dma_kernel(IgemmParams p) {
+  static_assert(APRE || NST == 2, "fp32 activation rows: two stages");
+  constexpr int BM = 128, TM = 2, TN = BN / 64;
+  constexpr int STAGE_B = 3 * (BM + BN) * 32;            // bytes per stage
+  constexpr int NPB = 3 * BN / 32, PB = (NPB + 3) / 4;   // B pieces per step, per wave
+  constexpr int NDMA = (APRE ? 3 : 0) + PB;              // DMA instructions per wave and K-step
+  constexpr int AHEAD = NST == 2 ? 2 : NST - 1;          // tiles requested ahead of the one being multiplied
+  constexpr int RA = BM / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const unsigned long long t_start = p.trace ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long w_start = p.trace ? wall_clock64() : 0ull;
+  const int vid = xcd_remap((int)(blockIdx.z * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.z));
+  const int zb = vid / (int)gridDim.x;
+  const int tile = vid - zb * (int)gridDim.x;
+  const int tm_idx = tile / p.tiles_n, tn_idx = tile % p.tiles_n;
+  const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+  float* Cb = p.C + (long)zb * p.batch_c;
+  __amdgpu_buffer_rsrc_t ra_src =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)zb * p.batch_a), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_src =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.Bw + (long)zb * p.batch_b), 0, (int)p.b_bytes, 0x00020000);
+  const int nk = (p.K + SBK - 1) / SBK;
+
+  // ---- DMA pieces of this wave: B pieces q = wave + 4 j -> (plane, row group) (64-wide tiles: six pieces on eight slots -- a
+  // slot past the end repeats the wave's first piece: same bytes, same place); APRE: A rows 32 * wave .. + 31 of the three
+  // planes. Lane i of a piece holds the 16-byte slot i & 1 of row i >> 1, i.e. the half (i & 1) ^ swz(row) of its 32 bytes.
+  const int prow = lane >> 1, phalf = (lane & 1) ^ ((lane >> 4) & 1);
+  const int arow = m0 + 32 * wave + prow;
+  const unsigned a_vo = arow < p.M ? (unsigned)(arow * 32 + phalf * 16) : OOB;
+  const unsigned a_pstride = (unsigned)p.a_rows * 32u, b_pstride = (unsigned)p.N * 32u;  // bytes between planes / K-step thirds
+  unsigned b_vo[PB];
+  int b_pl[PB], b_lds[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    int q = wave + 4 * j;
+    if (q >= NPB) q -= 4;
+    const int pl = q / (BN / 32), rg = q % (BN / 32);
+    const int n = n0 + 32 * rg + prow;
+    b_vo[j] = n < p.N ? (unsigned)(n * 32 + phalf * 16) : OOB;
+    b_pl[j] = pl;
+    b_lds[j] = 3 * BM * 32 + (pl * BN + 32 * rg) * 32;
+  }
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lds0 = (lds_char*)(lds_void*)smem;
+  auto issue = [&](int t, int stage) {  // tile t -> stage (all pieces out of range past the last K-step: zeros, never read)
+    const bool live = t < nk;
+    lds_char* base = lds0 + stage * STAGE_B;
+    if constexpr (APRE) {
+      const unsigned av = live ? a_vo : OOB;
+      const unsigned sa = (unsigned)t * 3u * a_pstride;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_src, (lds_void*)(base + (pl * BM + 32 * wave) * 32), 16, (int)av,
+                                                 (int)(sa + pl * a_pstride), 0, 0);
+    }
+    const unsigned sb = (unsigned)t * 3u * b_pstride;
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, (lds_void*)(base + b_lds[j]), 16, (int)(live ? b_vo[j] : OOB),
+                                               (int)(sb + b_pl[j] * b_pstride), 0, 0);
+  };
+
+  // ---- fp32 activation rows (APRE = 0): igemm_split_body's K walk -- "taps" of cin_t channels, one 32-bit byte offset and a
+  // tap-validity mask per staged row, a per-lane K limit that is DEAD for padding taps / missing rows / the K tail (the load
+  // then takes an out-of-range offset: zeros), optional second geometry segment and second K segment (A2)
+  int cin_t = p.Cin;
+  const int kw_t = p.KW, kh_t = p.KH;
+  const int lda4 = p.lda * 4;
+  const int c4 = tid & 3, r0 = tid >> 2;
+  const int wcol = ((c4 >> 1) ^ swz(r0)) * 4 + (c4 & 1) * 2;
+  const int klim = p.K - c4 * 4;
+  constexpr int DEAD = (int)0x80000000;
+  unsigned a_off[RA], a_mask[RA], a_off2[RA];
+  int a_dseg[RA];
+  int lt_k0 = 0, lt_cin = 0, lt_kh = 0, lt_kw = 0;
+  unsigned lt_bit = 1u;
+  unsigned a_cur[RA];
+  int a_lim[RA];
+  if constexpr (!APRE) {
+    const bool lin = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const int m = m0 + r0 + 64 * j;
+      const bool ok = m < p.M;
+      const bool s1 = ok && m >= p.M0;
+      const int mm = ok ? (s1 ? m - p.M0 : m) : 0;
+      if (lin && !p.A2) {
+        a_off[j] = (unsigned)(((s1 ? p.pix1 : 0) + mm) * lda4 + c4 * 16);
+        a_mask[j] = ok ? 1u : 0u;
+        a_dseg[j] = 0;
+        a_off2[j] = OOB;
+      } else {
+        const int IH = s1 ? p.IH1 : p.IH, IW = s1 ? p.IW1 : p.IW, OW = s1 ? p.OW1 : p.OW;
+        const int ohw = (s1 ? p.OH1 : p.OH) * OW;
+        const int img = mm / ohw, rem = mm - img * ohw;
+        const int oh = rem / OW, ow = rem - oh * OW;
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+        const int pix = (s1 ? p.pix1 : 0) + (img * IH + ih0) * IW;
+        unsigned mask = 0;
+        if (ok) {
+          unsigned colbits = 0;
+          for (int kw = 0; kw < kw_t; ++kw)
+            if (iw0 + kw >= 0 && iw0 + kw < IW) colbits |= 1u << kw;
+          for (int kh = 0; kh < kh_t; ++kh)
+            if (ih0 + kh >= 0 && ih0 + kh < IH) mask |= colbits << (kh * kw_t);
+        }
+        a_off[j] = (unsigned)((pix + iw0) * lda4 + c4 * 16);
+        a_mask[j] = mask;
+        a_dseg[j] = s1 ? (p.IW1 - p.IW) * lda4 : 0;
+        a_off2[j] = (p.A2 && ok) ? (unsigned)(((s1 ? p.pix21 : 0) + ((long)img * (s1 ? p.IH21 : p.IH2) + oh * p.stride2) * (s1 ? p.IW21 : p.IW2) +
+                                              ow * p.stride2) * p.lda2 * 4 + c4 * 16)
+                                 : OOB;
+      }
+      a_cur[j] = a_off[j];
+      a_lim[j] = (a_mask[j] & 1u) ? klim : DEAD;
+    }
+  }
+  auto next_tap = [&]() {  // rare: the tap's channels are used up
+    if (lt_cin >= cin_t) {
+      lt_cin = 0;
+      if (p.A2) {
+        // the second K segment: another tensor (own descriptor, own pixel map), K1 channels; nothing after it
+        ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes, 0x00020000);
+        cin_t = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+          a_cur[j] = a_off2[j];
+          a_lim[j] = a_off2[j] != OOB ? klim : DEAD;
+        }
+        return;
+      }
+      lt_bit <<= 1;
+      if (++lt_kw == kw_t) {
+        lt_kw = 0;
+        ++lt_kh;
+      }
+      const int d0 = lt_kh * p.IW * lda4 + lt_kw * lda4;
+#pragma unroll
+      for (int j = 0; j < RA; ++j) {
+        a_cur[j] = a_off[j] + (unsigned)(d0 + lt_kh * a_dseg[j]);
+        a_lim[j] = (a_mask[j] & lt_bit) ? klim : DEAD;
+      }
+    }
+  };
+  float4 ra[RA];
+  auto load_a = [&]() {  // the next K-step's rows of this lane -> ra
+    next_tap();
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      unsigned off = lt_k0 < a_lim[j] ? a_cur[j] : OOB;
+      asm volatile("" : "+v"(off));
+      ra[j] = ldg_b128(ra_src, off);
+      a_cur[j] += SBK * 4;
+    }
+    lt_k0 += SBK;
+    lt_cin += SBK;
+  };
+  auto split_a = [&](int stage) {  // ra -> the three bf16 planes of A in `stage`
+    unsigned* as = (unsigned*)smem + stage * (STAGE_B / 4) + r0 * SLD + wcol;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      uint2 h, m, l;
+      split3(ra[j], h, m, l);
+      *(uint2*)(as + (0 * BM + 64 * j) * SLD) = h;
+      *(uint2*)(as + (1 * BM + 64 * j) * SLD) = m;
+      *(uint2*)(as + (2 * BM + 64 * j) * SLD) = l;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+  if constexpr (APRE) {
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) issue(a, a % NST);
+  } else {
+    load_a();  // tile 0
+    issue(0, 0);
+    issue(1, 1);
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if constexpr (!APRE) {
+    split_a(0);  // (the compiler waits for tile 0's rows here)
+    load_a();    // tile 1
+    split_a(1);
+    load_a();    // tile 2: split in step 0
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA) : "memory");  // both tiles' B pieces landed (older than tile 2's row loads)
+  } else {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NDMA) : "memory");  // tile 0 landed (this wave's pieces)
+  }
+  // fragment addresses (dwords): row li of the wave's rows, 16-byte half lh (swizzled like the staging image)
+  const int rcol = (lh ^ swz(li)) * 4;
+  const unsigned* const a_rd = (const unsigned*)smem + (wm * (BM / 2) + li) * SLD + rcol;
+  const unsigned* const b_rd = (const unsigned*)smem + 3 * BM * SLD + (wn * (BN / 2) + li) * SLD + rcol;
+  constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
+  constexpr int PBp[6] = {0, 1, 0, 1, 2, 0};
+  const unsigned long long t_loop = p.trace ? __builtin_readcyclecounter() : 0ull;
+  for (int t0 = 0; t0 < nk; t0 += NST) {
+    static_for<0, NST>([&](auto sc_) {
+      constexpr int st = decltype(sc_)::value;
+      const int t = t0 + st;
+      if (t < nk) {  // (uniform)
+        if constexpr (!APRE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's staging writes of tile t)
+        __builtin_amdgcn_s_barrier();  // tile t is in LDS for every wave; every wave is past its reads of tile t - 1
+        if constexpr (NST >= 3) issue(t + AHEAD, (st + AHEAD) % NST);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 fa[3][TM], fb[3][TN];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[pc][i] = *(const u32x4*)(a_rd + st * (STAGE_B / 4) + (pc * BM + i * 32) * SLD);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[pc][j] = *(const u32x4*)(b_rd + st * (STAGE_B / 4) + (pc * BN + j * 32) * SLD);
+        }
+        if constexpr (NST == 2) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();  // every wave holds its fragments of tile t: the stage is free for tile t + 2
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!APRE) {
+            // tile t + 2's rows were requested a step ago, behind the B pieces of tile t + 1: the wait for them (vmcnt 0:
+            // nothing younger is in flight) also retires those pieces. Then this step's requests: B pieces, next rows.
+            split_a(st);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(t + 2, st);
+            load_a();  // tile t + 3
+          } else {
+            issue(t + 2, st);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pq = 0; pq < 6; ++pq)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[pq]][i]),
+                                                                  __builtin_bit_cast(bf16x8, fb[PBp[pq]][j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (APRE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NDMA) : "memory");  // tile t + 1 landed
+      }
+    });
+  }
+  const unsigned long long t_loop_end = p.trace ? __builtin_readcyclecounter() : 0ull;
+  epilogue_regs<BM, BN, (NST == 2 && BN == 128) ? 1 : 0, 0>(p, acc, m0, n0, Cb, wm, wn, li, lh);
+  if (p.trace && tid == 0) {
+    unsigned long long* tr = p.trace + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    tr[0] = t_start;
+    tr[1] = t_loop;
+    tr[2] = t_loop_end;
+    tr[3] = __builtin_readcyclecounter();
+    tr[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    tr[5] = wall_clock64();
+    tr[6] = w_start;
+    tr[7] = 0;
+  }
+}
 
 // ---- skinny GEMM (N <= 8): one wave per output row, lanes split K (RCNN_bbox_pred 2048->4,
 // output_score_layer.linear2 1024->2: dana.py:246,304). HBM-bound on reading A once. ------------
@@ -1224,6 +1645,12 @@ split_weight_kernel(const float* __restrict__ w, long ldw, long batch_w, int n, 
   *(uint2*)(o + 2 * (long)n * SBK) = l;
 }
 
+// Epilogue form of the split kernel (dana_set_epilogue_mode): 0 = on the accumulator registers (default), 1 = LDS C tile.
+std::atomic<int>& epilogue_mode_cell() {
+  static std::atomic<int> cell(getenv("DANA_EPILOGUE_LDS") ? atoi(getenv("DANA_EPILOGUE_LDS")) : 0);
+  return cell;
+}
+
 template <int BM, int BN, int STEM>
 int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   IgemmParams p = p0;
@@ -1232,46 +1659,58 @@ int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
   const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds_c > lds) lds = lds_c;
-  static bool attr_set = false;  // >64 KiB of dynamic LDS needs the opt-in once per process
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_f32_kernel<BM, BN, STEM>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static DeviceOnce attr;  // >64 KiB of dynamic LDS needs the opt-in once per device
+  if (attr.need())
+    (void)hipFuncSetAttribute((const void*)igemm_f32_kernel<BM, BN, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
   igemm_f32_kernel<BM, BN, STEM><<<grid, 256, lds, s>>>(p);
   return 0;
 }
 
-template <int BM, int BN, int STEM = 0, int BPRE = 0, int FUSE = 0>
+template <int BM, int BN, int STEM = 0, int BPRE = 0, int FUSE = 0, int ELDS = 0>
 int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
   if constexpr (BPRE == 0 && FUSE == 0) {
-    if (p0.bpre) return launch_split<BM, BN, STEM, 1>(p0, batch, s);
+    if (p0.bpre) return launch_split<BM, BN, STEM, 1, 0, ELDS>(p0, batch, s);
+  }
+  if constexpr (ELDS == 0 && FUSE == 0) {
+    if (epilogue_mode_cell().load(std::memory_order_relaxed)) return launch_split<BM, BN, STEM, BPRE, 0, 1>(p0, batch, s);
   }
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   size_t lds = (size_t)2 * 3 * (BM + BN) * SLD * sizeof(unsigned);
   const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
-  if (lds_c > lds && !FUSE) lds = lds_c;
+  if (lds_c > lds && ELDS) lds = lds_c;
   if (FUSE && lds < (size_t)4 * 3 * BM * 16 * 2) lds = (size_t)4 * 3 * BM * 16 * 2;  // the tile as four K-steps of A
+  const char* pad_env = getenv("DANA_LDS_PAD");  // (experiment, tools/occupancy_probe.py: fewer workgroups per CU)
+  const size_t lds_attr = pad_env ? 160 * 1024 : lds;
+  if (pad_env) lds += (size_t)atoi(pad_env);
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-  static bool attr_set = false;
+  static DeviceOnce attr;
   if constexpr (BM * BN >= 128 * 128) {
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)igemm_split_kernel_128<STEM, BPRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-      attr_set = true;
-    }
-    igemm_split_kernel_128<STEM, BPRE><<<grid, 256, lds, s>>>(p);
+    if (attr.need())
+      (void)hipFuncSetAttribute((const void*)igemm_split_kernel_128<STEM, BPRE, ELDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_attr);
+    igemm_split_kernel_128<STEM, BPRE, ELDS><<<grid, 256, lds, s>>>(p);
   } else {
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE, FUSE>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
-    igemm_split_kernel<BM, BN, STEM, BPRE, FUSE><<<grid, 256, lds, s>>>(p);
+    if (attr.need())
+      (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE, FUSE, ELDS>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr);
+    igemm_split_kernel<BM, BN, STEM, BPRE, FUSE, ELDS><<<grid, 256, lds, s>>>(p);
   }
+  return 0;
+}
+
+template <int BN, int NST, int APRE>
+int launch_dma(const IgemmParams& p0, int batch, hipStream_t s) {
+  IgemmParams p = p0;
+  p.tiles_m = (p.M + 127) / 128;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const size_t lds = (size_t)NST * 3 * (128 + BN) * 32;
+  static DeviceOnce attr;
+  if (attr.need()) (void)hipFuncSetAttribute((const void*)igemm_dma_kernel<BN, NST, APRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
+  igemm_dma_kernel<BN, NST, APRE><<<grid, 256, lds, s>>>(p);
   return 0;
 }
 
@@ -1290,46 +1729,6 @@ std::atomic<int>& mfma_mode_cell() {
 }
 unsigned long long* g_trace = nullptr;  // debug: per-block timestamps of the next split launches (dana_set_igemm_trace)
 
-// The warp-specialised persistent kernel (igemm_ws.h) for GEMM-type launches -- EXPERIMENTAL, off by default (round 4: same
-// bits as igemm_split_kernel on every shape, 1.03-1.9x its duration). DANA_WS / dana_set_ws_mode: 0 off (default), 1 the
-// launches with >= 100 128 x 128 tiles and N > 64, 2 every eligible launch.
-std::atomic<int>& ws_mode_cell() {
-  static std::atomic<int> cell(getenv("DANA_WS") ? atoi(getenv("DANA_WS")) : 0);
-  return cell;
-}
-int ws_mode() { return ws_mode_cell().load(std::memory_order_relaxed); }
-bool ws_eligible(const IgemmParams& p, int batch, int stem) {
-  return !stem && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.A2 && p.M0 == p.M && !p.mask && p.vec_io &&
-         p.K >= 64 && p.K % 4 == 0 && p.N % 4 == 0 && (!p.residual || batch == 1);
-}
-int launch_ws(const IgemmParams& p0, int batch, hipStream_t s) {
-  IgemmParams p = p0;
-  p.tiles_m = (p.M + 127) / 128;
-  p.tiles_n = (p.N + 127) / 128;
-  const int total = p.tiles_m * p.tiles_n * batch;
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
-  const int grid = total < cus ? total : cus;
-  static bool attr_set[2] = {false, false};
-  if (p.bpre) {
-    if (!attr_set[1]) {
-      (void)hipFuncSetAttribute((const void*)igemm_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
-      attr_set[1] = true;
-    }
-    igemm_ws_kernel<1><<<grid, 768, WS_LDS_BYTES, s>>>(p, total);
-  } else {
-    if (!attr_set[0]) {
-      (void)hipFuncSetAttribute((const void*)igemm_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
-      attr_set[0] = true;
-    }
-    igemm_ws_kernel<0><<<grid, 768, WS_LDS_BYTES, s>>>(p, total);
-  }
-  return 0;
-}
-
 int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   if (stem) {
     const int smode = mfma_mode_cell().load(std::memory_order_relaxed);
@@ -1339,9 +1738,24 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   // dana_set_mfma_mode(0) / DANA_MFMA_SPLIT=0 selects the f32-MFMA kernel. 128x128 blocks amortise the split best; a
   // launch that cannot give most CUs one of those falls back to 64x64 blocks (measured: tools/conv_sweep.py).
   const int mode = mfma_mode_cell().load(std::memory_order_relaxed);
-  if (mode == 1 && ws_mode() && ws_eligible(p, batch, stem)) {
-    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-    if (ws_mode() == 2 || (p.N > 64 && t128 >= 100)) return launch_ws(p, batch, s);
+  if (p.apre) {
+    const int stages = getenv("DANA_PP_STAGES") ? atoi(getenv("DANA_PP_STAGES")) : 3;  // (per call: tools/pp_probe.py)
+    if (p.N <= 64) return stages == 2 ? launch_dma<64, 2, 1>(p, batch, s) : launch_dma<64, 3, 1>(p, batch, s);
+    if (stages == 2) return launch_dma<128, 2, 1>(p, batch, s);
+    if (stages == 4) return launch_dma<128, 4, 1>(p, batch, s);
+    if (stages == 6) return launch_dma<128, 6, 1>(p, batch, s);
+    return launch_dma<128, 3, 1>(p, batch, s);
+  }
+  // pre-split weights, no ReLU-adjoint mask: the three-workgroups-per-CU kernel for the launches that took 128 x 128 tiles
+  // (DANA_DMA_KERNEL=0: the round-4 kernel, for A/Bs; 2: wherever it can run, 64-wide tiles for N <= 64 -- tests)
+  if (mode == 1 && p.bpre && !p.mask && p.KH * p.KW <= 32) {
+    const char* e = getenv("DANA_DMA_KERNEL");
+    const int dm = e ? atoi(e) : 1;
+    if (dm == 2) return p.N <= 64 ? launch_dma<64, 2, 0>(p, batch, s) : launch_dma<128, 2, 0>(p, batch, s);
+    if (dm == 1 && p.N > 64) {
+      const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+      if (t128 >= 100 && !(p.N <= 256 && p.N % 128 != 0 && p.N % 128 <= 32)) return launch_dma<128, 2, 0>(p, batch, s);
+    }
   }
   if (mode && p.KH * p.KW <= 32) {
     if (mode == 2) return launch_split<128, 64>(p, batch, s);
@@ -1398,12 +1812,12 @@ int run(IgemmParams& p, int batch, int stem, hipStream_t s) {
 
 extern "C" {
 
-int dana_set_ws_mode(int mode) {
-  DANA_CHECK_ARG(mode >= 0 && mode <= 2, "dana_set_ws_mode: 0 (off), 1 (where it measured faster) or 2 (every eligible launch)");
-  ws_mode_cell().store(mode, std::memory_order_relaxed);
+int dana_set_epilogue_mode(int mode) {
+  DANA_CHECK_ARG(mode == 0 || mode == 1, "dana_set_epilogue_mode: 0 (accumulator registers) or 1 (LDS C tile)");
+  epilogue_mode_cell().store(mode, std::memory_order_relaxed);
   return DANA_OK;
 }
-int dana_get_ws_mode(void) { return ws_mode(); }
+int dana_get_epilogue_mode(void) { return epilogue_mode_cell().load(std::memory_order_relaxed); }
 
 int dana_set_mfma_mode(int mode) {
   DANA_CHECK_ARG(mode >= 0 && mode <= 5, "dana_set_mfma_mode: mode must be 0 (f32 MFMA) or 1 (bf16x6 split; 2-5: forced tiles)");
@@ -1720,6 +2134,9 @@ int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, c
   const int bpre = (flags & DANA_W_SPLIT3) ? 1 : 0;  // b = bf16 planes [3][n][ldb], ldb (and batch_b) in bf16 elements
   DANA_CHECK_ARG(!bpre || (dana_get_mfma_mode() != 0 && ldb % SBK == 0 && ldb >= k && batch_b % 8 == 0 && n > 8),
                  "dana_gemm_nt: DANA_W_SPLIT3 needs the split kernel, ldb = k rounded up to 16, n > 8");
+  const int apre = (flags & DANA_A_SPLIT3) ? 1 : 0;  // a = bf16 planes [lda / 16][3][m][16], lda = k rounded up to 16 (batch_a in bf16 elements)
+  DANA_CHECK_ARG(!apre || (bpre && lda % SBK == 0 && lda >= k && batch_a % 8 == 0),
+                 "dana_gemm_nt: DANA_A_SPLIT3 needs DANA_W_SPLIT3 too, lda = k rounded up to 16");
   DANA_CHECK_ARG(lda >= k && ldb >= k && ldc >= n, "dana_gemm_nt: leading dimension smaller than the row");
   DANA_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "dana_gemm_nt: a/b must be 16-byte aligned");
   DANA_CHECK_ARG(!residual || batch == 1, "dana_gemm_nt: residual only with batch == 1");
@@ -1730,7 +2147,8 @@ int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, c
     DANA_CHECK_LAUNCH("dana_gemm_nt(skinny)");
     return DANA_OK;
   }
-  const long a_bytes = ((long)(m - 1) * lda + k) * 4, b_bytes = bpre ? (long)3 * n * ldb * 2 : ((long)(n - 1) * ldb + k) * 4;
+  const long a_bytes = apre ? (long)3 * m * lda * 2 : ((long)(m - 1) * lda + k) * 4;
+  const long b_bytes = bpre ? (long)3 * n * ldb * 2 : ((long)(n - 1) * ldb + k) * 4;
   DANA_CHECK_ARG(a_bytes < (long)OOB && b_bytes < (long)OOB, "dana_gemm_nt: operand slice >= 2 GiB; split it");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -1758,8 +2176,10 @@ int dana_gemm_nt(const float* a, const float* b, float* c, const float* scale, c
   p.b_bytes = (unsigned)b_bytes;
   p.ldc = ldc;
   p.ldr = ldr > 0 ? ldr : ldc;
-  p.batch_a = batch_a;
+  p.batch_a = apre ? batch_a / 2 : batch_a;
   p.batch_b = bpre ? batch_b / 2 : batch_b;  // (the kernel steps the filter pointer in floats)
+  p.apre = apre;
+  p.a_rows = m;
   p.batch_c = batch_c;
   p.bpre = bpre;
   p.alpha = alpha;

@@ -10,12 +10,13 @@
 //
 // Compiled with -ffp-contract=off (decode rounds like the reference's unfused torch ops).
 #include "common.h"
+#include <atomic>
 #include "../../include/dana_hip.h"
 #include <rocprim/rocprim.hpp>
 
 namespace {
 
-int g_sort_mode = 0;  // dana_set_library_sort: 0 = measured dispatch, 1 = always the library sort, 2 = the hand-written kernel wherever it can run
+std::atomic<int> g_sort_mode{0};  // dana_set_library_sort: 0 = measured dispatch, 1 = always the library sort, 2 = the hand-written kernel wherever it can run
 
 // one lane per (image, cell k=h*W+w, anchor a); output index i = k*A + a (proposal_layer.py:98-103)
 __global__ void __launch_bounds__(256)
@@ -417,12 +418,11 @@ bool topk_preferred(int n, int topn) {
 
 int topk_launch(const float* scores, int B, int n, int topn, int* order, int order_stride, float* sorted_scores,
                 hipStream_t s) {
-  static const hipError_t a24 = hipFuncSetAttribute((const void*)topk_sort_kernel<24>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
-  static const hipError_t a40 = hipFuncSetAttribute((const void*)topk_sort_kernel<TK_MAXR>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
-  (void)a24;
-  (void)a40;
+  static DeviceOnce attr;  // (per device: common.h)
+  if (attr.need()) {
+    (void)hipFuncSetAttribute((const void*)topk_sort_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
+    (void)hipFuncSetAttribute((const void*)topk_sort_kernel<TK_MAXR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
+  }
   if (n <= 24 * TK_THREADS)
     topk_sort_kernel<24><<<B, TK_THREADS, sizeof(TopkSmem), s>>>(scores, n, topn, order, order_stride, sorted_scores);
   else
@@ -484,17 +484,9 @@ size_t dana_sort_desc_workspace_bytes(int B, int n) {
   return sort_plan(B, n).total;  // (also for rows the hand-written kernel takes: dana_set_library_sort may switch back)
 }
 
-// Stable descending sort of each row of scores[B][n]; order[B][n] = source index within the row.
-int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_scores, void* workspace,
-                   size_t workspace_bytes, dana_stream_t stream) {
-  DANA_CHECK_ARG(B >= 0 && n >= 0, "dana_sort_desc: bad shape");
-  if (B == 0 || n == 0) return DANA_OK;
-  DANA_CHECK_ARG(scores && order, "dana_sort_desc: null pointer");
-  if (topk_preferred(n, n)) {  // short rows: the hand-written select + LDS sort, one launch
-    topk_launch(scores, B, n, n, order, n, sorted_scores, (hipStream_t)stream);
-    DANA_CHECK_LAUNCH("dana_sort_desc(topk)");
-    return DANA_OK;
-  }
+// the library path: one device-wide stable radix sort over (row, score) keys
+static int sort_desc_library(const float* scores, int B, int n, int* order, float* sorted_scores, void* workspace,
+                             size_t workspace_bytes, dana_stream_t stream) {
   SortPlan p = sort_plan(B, n);
   if (!workspace || workspace_bytes < p.total) {
     dana_set_error("dana_sort_desc: workspace %zu < %zu", workspace_bytes, p.total);
@@ -523,6 +515,20 @@ int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_
   return DANA_OK;
 }
 
+// Stable descending sort of each row of scores[B][n]; order[B][n] = source index within the row.
+int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_scores, void* workspace,
+                   size_t workspace_bytes, dana_stream_t stream) {
+  DANA_CHECK_ARG(B >= 0 && n >= 0, "dana_sort_desc: bad shape");
+  if (B == 0 || n == 0) return DANA_OK;
+  DANA_CHECK_ARG(scores && order, "dana_sort_desc: null pointer");
+  if (topk_preferred(n, n)) {  // short rows: the hand-written select + LDS sort, one launch
+    topk_launch(scores, B, n, n, order, n, sorted_scores, (hipStream_t)stream);
+    DANA_CHECK_LAUNCH("dana_sort_desc(topk)");
+    return DANA_OK;
+  }
+  return sort_desc_library(scores, B, n, order, sorted_scores, workspace, workspace_bytes, stream);
+}
+
 int dana_set_library_sort(int on) {
   g_sort_mode = on;
   return DANA_OK;
@@ -548,10 +554,7 @@ int dana_topk_desc(const float* scores, int B, int n, int topn, int* order, int 
   const size_t ob = dana_align_up((size_t)B * n * 4, 256);
   int* full = (int*)ws;
   float* fulls = (float*)(ws + ob);
-  const int saved = g_sort_mode;
-  g_sort_mode = 1;
-  const int rc = dana_sort_desc(scores, B, n, full, sorted_scores ? fulls : nullptr, ws + 2 * ob, workspace_bytes - 2 * ob, stream);
-  g_sort_mode = saved;
+  const int rc = sort_desc_library(scores, B, n, full, sorted_scores ? fulls : nullptr, ws + 2 * ob, workspace_bytes - 2 * ob, stream);
   if (rc) return rc;
   const int m = topn < n ? topn : n;
   for (int b = 0; b < B; ++b) {

@@ -779,20 +779,14 @@ WgradShape wgrad_shape(int N, int K, int M, int planes = 1) {
 void launch_wgrad_128(const WgradParams& p, dim3 grid, hipStream_t s) {
   if (dana_get_mfma_mode() != 0) {
     constexpr int lds = 2 * 2 * 3 * 128 * WSLD * (int)sizeof(unsigned);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)wgrad_split_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
-    }
+    static DeviceOnce attr;
+    if (attr.need()) (void)hipFuncSetAttribute((const void*)wgrad_split_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     // rows of both operands are pixel rows (1x1 / stride 1 / no padding: every Linear, most convs, the Winograd-domain
     // planes): the software-pipelined kernel; strided / multi-tap launches: the general one
     static const bool pipelined = !getenv("DANA_WGRAD_PIPELINED") || atoi(getenv("DANA_WGRAD_PIPELINED")) != 0;
     if (pipelined && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {
-      static bool attr_set_p = false;
-      if (!attr_set_p) {
-        (void)hipFuncSetAttribute((const void*)wgrad_split_128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set_p = true;
-      }
+      static DeviceOnce attr_p;
+      if (attr_p.need()) (void)hipFuncSetAttribute((const void*)wgrad_split_128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       wgrad_split_128p_kernel<<<grid, 256, lds, s>>>(p);
     } else {
       wgrad_split_128_kernel<<<grid, 256, lds, s>>>(p);

@@ -13,7 +13,7 @@ from ._lib import lib, DanaError  # noqa: F401
 HOST_WAIT = [0.0]  # seconds the host spent blocked in the training forward's one D2H read (bench.py / tools/hosttime.py)
 
 NCHW, NHWC = 0, 1
-EPI_RELU, CONV_STEM7, W_SPLIT3 = 1, 2, 256
+EPI_RELU, CONV_STEM7, W_SPLIT3, A_SPLIT3 = 1, 2, 256, 512
 
 # bench.py sets this to a list to time every MFMA contraction launch with HIP events recorded on the
 # stream the kernel is launched on; entries are (tag, algorithmic_flops, start_event, end_event).
@@ -901,16 +901,16 @@ def set_mfma_mode(mode):
     return prev
 
 
-def set_ws_mode(mode):
-    """0 / 1 / 2: which GEMM-type launches take the warp-specialised persistent kernel (dana_set_ws_mode). Returns the
-    previous mode."""
-    prev = lib().query("dana_get_ws_mode")
-    lib().call("dana_set_ws_mode", int(mode))
-    return prev
-
-
 def get_mfma_mode():
     return lib().query("dana_get_mfma_mode")
+
+
+def set_epilogue_mode(mode):
+    """0 (default): the split kernel's epilogue runs on the accumulator registers; 1: through an LDS C tile (the round-1..4
+    form, kept as the bit-identity reference: include/dana_hip.h dana_set_epilogue_mode). Returns the previous mode."""
+    prev = lib().query("dana_get_epilogue_mode")
+    lib().call("dana_set_epilogue_mode", int(mode))
+    return prev
 
 
 SPLIT_K = __import__("os").environ.get("DANA_SPLIT_K", "1") != "0"  # split-K for tile-starved GEMMs (few tiles, long K)
@@ -932,9 +932,22 @@ def _splitk_slices(m, n, k, batch):
 
 def gemm_nt(a, b, m, n, k, lda=0, ldb=0, out=None, ldc=0, scale=None, shift=None, residual=None, ldr=0, batch=1,
             batch_a=0, batch_b=0, batch_c=0, alpha=1.0, relu=False, k_true=0, force_slices=0):
-    """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous."""
-    _chk(a, "a")
+    """c[z][m][n] = epi(alpha * a[z][m][:k] . b[z][n][:k]); both operands K-contiguous. `a` may be a W3 too (the activation
+    rows as split planes, ops.split_weight(x, m, k): planes x planes kernel, no split in the K loop; needs b as a W3)."""
     bp, wfl = _wf(b)
+    if isinstance(a, W3):
+        if not wfl or a.n != m or a.k != k or batch != a.batch:
+            raise ValueError("gemm_nt: split activation planes need split weights and matching m / k / batch")
+        out = torch.empty((batch, m, n) if batch > 1 else (m, n), dtype=torch.float32, device=a.t.device) if out is None else out
+        ldc = ldc or n
+        e0 = _prof_begin()
+        lib().call("dana_gemm_nt", _p(a.t), bp, _p(out), _p(scale), _p(shift), _p(residual), m, n, k, a.kp, b.kp, ldc,
+                   ldr, batch, 3 * m * a.kp, 3 * n * b.kp, batch_c or m * n, float(alpha), (EPI_RELU if relu else 0) | wfl | A_SPLIT3,
+                   _stream())
+        _prof_end(e0, ("gemm M=%d N=%d K=%d b%d", (m, n, k, batch)), 2.0 * batch * m * n * (k_true or k),
+                  batch * (6.0 * (m * k + n * k) + 4.0 * m * n * (2 if residual is not None else 1)))
+        return out
+    _chk(a, "a")
     lda = lda or k
     if wfl:
         if ldb not in (0, k) or batch != 1 or b.n != n or b.k != k:

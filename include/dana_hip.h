@@ -32,6 +32,7 @@ typedef void* dana_stream_t; /* hipStream_t */
  * batch_b = bf16 elements between the slices' first K-steps). Split kernel only (dana_set_mfma_mode != 0);
  * results are bit-identical to the fp32-weight call, the K loop just does not repeat the split per tile and step. */
 #define DANA_W_SPLIT3 256
+#define DANA_A_SPLIT3 512 /* dana_gemm_nt: `a` holds the activation rows as split planes too (see dana_gemm_nt) */
 
 const char* dana_last_error(void);
 int dana_abi_version(void);
@@ -43,14 +44,13 @@ int dana_abi_version(void);
  * Replaces nothing in the reference: cuDNN picks its own algorithm / math mode there (lib/model/framework/resnet.py). */
 int dana_set_mfma_mode(int mode);
 int dana_get_mfma_mode(void);
-/* EXPERIMENTAL (round 4), off by default: which GEMM-type launches of the split kernel (1x1 / stride 1 / no padding
- * contractions over one row range: every nn.Linear / bmm of dana.py:124-147,266-290 and the 1x1 convs of resnet.py:84-100)
- * take the warp-specialised persistent form (csrc/igemm_ws.h: consumer waves multiply, stager waves load / split / stage the
- * next K-steps and tiles, finisher waves run the previous tile's epilogue). 0 = none (default; environment DANA_WS), 1 = the
- * launches with >= 100 tiles of 128 x 128 and n > 64, 2 = every eligible launch. Same results bit for bit; measured
- * 1.03-1.9x the split kernel's duration, which is why it is off. A configuration call like dana_set_mfma_mode. */
-int dana_set_ws_mode(int mode);
-int dana_get_ws_mode(void);
+/* Epilogue form of the split kernel (a configuration call like dana_set_mfma_mode; environment DANA_EPILOGUE_LDS=1 sets the
+ * initial value). 0 (default): scale / shift / residual / ReLU / ReLU-adjoint mask run on the accumulator registers and the
+ * results leave as dword buffer stores (a 32x32 accumulator row = 32 consecutive channels = one 128-byte segment per row and
+ * half-wave): no LDS C tile, 49 instead of 67.6 KB of LDS per 128x128 tile. 1: the round-1..4 form through an LDS C tile
+ * (float4 rows). Same arithmetic in the same order -> the same bits (tests/test_gpu_contractions.py). */
+int dana_set_epilogue_mode(int mode);
+int dana_get_epilogue_mode(void);
 /* debug / profiling aid (tools/igemm_trace.py, gemm_power.py): while `buffer` is non-null every split-kernel block writes
  * eight 64-bit words {shader-clock at start, at the first K-step, after the K loop, at the end, HW_ID, 100 MHz wall clock
  * at the end, wall clock at the start, 0} at buffer[(z * grid + block) * 8]. The caller sizes the buffer for the launches it traces; null switches it off. */

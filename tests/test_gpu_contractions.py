@@ -431,15 +431,16 @@ def test_presplit_weights_are_bit_identical_to_fp32_weights(dev, mfma_mode):
 
 
 @pytest.mark.parametrize("shape", [(9576, 1024, 256, True, 1, True), (1000, 200, 100, True, 1, False), (2394, 1200, 256, False, 4, False),
-                                   (640, 256, 256, False, 9, True), (300, 128, 64, False, 1, True), (25088, 128, 1024, True, 1, True)],
-                         ids=["l3-expand+res", "ragged-fp32B", "bmm-b4", "planes-b9", "one-round", "roi-proj+res"])
-def test_warp_specialised_kernel_gives_the_split_kernels_bits(dev, shape):
-    """csrc/igemm_ws.h (experimental, off by default: dana_set_ws_mode): consumer / stager / finisher waves and a persistent
-    walk over the tiles, but the same K-step order, the same six products in the same order, the same split and the same
-    epilogue arithmetic -> bit-identical to igemm_split_kernel, on full, ragged, batched, fp32-B and pre-split-B launches"""
+                                   (640, 256, 256, False, 9, True), (300, 128, 64, False, 1, True), (25088, 128, 1024, True, 1, True),
+                                   (77, 30, 64, True, 1, False)],
+                         ids=["l3-expand+res", "ragged-fp32B", "bmm-b4", "planes-b9", "one-round", "roi-proj+res", "tiny-ragged"])
+def test_register_epilogue_gives_the_lds_epilogues_bits(dev, shape):
+    """the split kernel's epilogue on the accumulator registers (dword buffer accesses, no LDS C tile: the default) against
+    the round-1..4 form through an LDS C tile (dana_set_epilogue_mode(1)): the same arithmetic in the same order -> the same
+    bits, on full, ragged (rows past M, channels past N, unaligned row strides), batched, fp32-B and pre-split-B launches"""
     from dana_amd import ops
     if ops.get_mfma_mode() == 0:
-        pytest.skip("the warp-specialised form exists for the split kernel only")
+        pytest.skip("the f32-MFMA kernel has one epilogue form")
     m, n, k, res, batch, pre = shape
     g = torch.Generator().manual_seed(m + n + k)
     a = torch.randn(batch, m, k, generator=g).to(dev)
@@ -448,10 +449,10 @@ def test_warp_specialised_kernel_gives_the_split_kernels_bits(dev, shape):
     r = torch.randn(m, n, generator=g).to(dev) if res else None
     b3 = ops.split_weight(w.view(-1), n, k, batch=batch) if pre else None
     outs = []
-    prev = ops.set_ws_mode(0)
+    prev = ops.set_epilogue_mode(0)
     try:
-        for mode in (0, 2):
-            ops.set_ws_mode(mode)
+        for mode in (1, 0):
+            ops.set_epilogue_mode(mode)
             out = torch.full((batch, m, n), float("nan"), device=dev)
             if batch > 1 and pre:
                 ops.lib().call("dana_gemm_nt", a.data_ptr(), b3.t.data_ptr(), out.data_ptr(), None, None, None, m, n, k, k, b3.kp, n,
@@ -463,5 +464,134 @@ def test_warp_specialised_kernel_gives_the_split_kernels_bits(dev, shape):
             outs.append(out)
         torch.cuda.synchronize()
     finally:
-        ops.set_ws_mode(prev)
+        ops.set_epilogue_mode(prev)
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+
+
+def _with_env(name, value, fn):
+    import os
+    prev = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if prev is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = prev
+
+
+@pytest.mark.parametrize("case", CONV_CASES + [(1, 40, 50, 64, 64, 3, 1, 1, True, False), (2, 31, 33, 128, 160, 3, 2, 1, True, True)])
+def test_dma_kernel_gives_the_split_kernels_bits_on_convs(dev, case):
+    """igemm_dma_kernel (round 5: weights by LDS-DMA, one fragment set, one staging register set, three workgroups per CU)
+    against igemm_split_kernel on pre-split weights: same K-step order, same split, same six products -> the same bits on
+    every conv geometry (taps, stride, padding, ragged M / N, residual, ReLU), plain and written into a wider buffer"""
+    from dana_amd import ops
+    if ops.get_mfma_mode() == 0:
+        pytest.skip("split kernel only")
+    N, H, W, Cin, Cout, k, stride, pad, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    xd = torch.randn(N * H * W, Cin, generator=g).to(dev)
+    wp = (torch.randn(Cout, k * k * Cin, generator=g) / np.sqrt(Cin * k * k)).to(dev)
+    w3 = ops.split_weight(wp, Cout, k * k * Cin)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(dev), torch.randn(Cout, generator=g).to(dev)
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    resd = torch.randn(N * oh * ow, Cout, generator=g).to(dev) if use_res else None
+
+    def run():
+        o1, _, _ = ops.conv2d_nhwc(xd, N, H, W, Cin, w3, Cout, k, k, stride, pad, scale=sc, shift=sh, residual=resd, relu=relu)
+        wide = torch.full((N * oh * ow, Cout + 32), -7.0, device=dev)
+        ops.conv2d_nhwc(xd, N, H, W, Cin, w3, Cout, k, k, stride, pad, scale=sc, shift=sh, residual=resd, relu=relu,
+                        out=wide.view(-1)[8:], out_stride=Cout + 32)
+        torch.cuda.synchronize()
+        return o1, wide
+
+    old = _with_env("DANA_DMA_KERNEL", "0", run)
+    new = _with_env("DANA_DMA_KERNEL", "2", run)
+    assert torch.isfinite(new[0]).all()
+    assert torch.equal(old[0], new[0]) and torch.equal(old[1], new[1])
+
+
+@pytest.mark.parametrize("shape", [(9576, 1024, 256, True, 1), (1000, 200, 100, True, 1), (640, 256, 256, False, 9), (300, 128, 64, False, 1),
+                                   (25088, 128, 1024, True, 1), (77, 30, 64, True, 1), (150000, 64, 64, False, 1), (513, 72, 512, False, 1)],
+                         ids=["l3-expand+res", "ragged", "planes-b9", "one-round", "roi-proj+res", "tiny-ragged", "n64", "n72"])
+def test_dma_kernel_gives_the_split_kernels_bits_on_gemms(dev, shape):
+    """... and on GEMM-type launches: fp32 activation rows (APRE = 0) AND the activation rows as split planes (APRE = 1, two /
+    three / four / six stages), batched and ragged"""
+    import os
+    from dana_amd import ops
+    if ops.get_mfma_mode() == 0:
+        pytest.skip("split kernel only")
+    m, n, k, res, batch = shape
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(batch * m, k, generator=g).to(dev)
+    w = (torch.randn(batch * n, k, generator=g) * 0.05).to(dev)
+    sc, sh = (torch.rand(n, generator=g) + 0.5).to(dev), torch.randn(n, generator=g).to(dev)
+    r = torch.randn(m, n, generator=g).to(dev) if res else None
+    w3 = ops.split_weight(w, n, k, batch=batch)
+    a3 = ops.split_weight(a, m, k, batch=batch)
+
+    def run(planes=False):
+        out = torch.full((batch * m, n), float("nan"), device=dev)
+        if planes:
+            if batch > 1:
+                ops.gemm_nt(a3, w3, m, n, k, out=out, ldc=n, batch=batch, batch_c=m * n)
+            else:
+                ops.gemm_nt(a3, w3, m, n, k, out=out, ldc=n, scale=sc, shift=sh, residual=r, relu=True)
+        elif batch > 1:
+            ops.lib().call("dana_gemm_nt", a.data_ptr(), w3.t.data_ptr(), out.data_ptr(), None, None, None, m, n, k, k, w3.kp, n,
+                           0, batch, m * k, 3 * n * w3.kp, m * n, 1.0, ops.W_SPLIT3, ops._stream())
+        else:
+            ops.gemm_nt(a, w3, m, n, k, out=out, ldc=n, scale=sc, shift=sh, residual=r, relu=True, force_slices=1)
+        torch.cuda.synchronize()
+        return out
+
+    old = _with_env("DANA_DMA_KERNEL", "0", run)
+    new = _with_env("DANA_DMA_KERNEL", "2", run)
+    assert torch.isfinite(new).all() and torch.equal(old, new)
+    for st in ("2", "3", "4", "6"):
+        pp = _with_env("DANA_PP_STAGES", st, lambda: run(True))
+        assert torch.equal(old, pp), "planes x planes, %s stages" % st
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_register_epilogue_bits_on_every_conv_case(dev, case):
+    """... and on every CONV_CASES shape (strided / padded convs, residual, ReLU, N not a tile multiple), plus the same conv
+    written into a wider buffer (row stride > channels) and with a ReLU-adjoint mask (the data-gradient form)"""
+    from dana_amd import ops
+    if ops.get_mfma_mode() == 0:
+        pytest.skip("the f32-MFMA kernel has one epilogue form")
+    N, H, W, Cin, Cout, k, stride, pad, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    xd = torch.randn(N * H * W, Cin, generator=g).to(dev)
+    wp = (torch.randn(Cout, k * k * Cin, generator=g) / np.sqrt(Cin * k * k)).to(dev)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(dev), torch.randn(Cout, generator=g).to(dev)
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    resd = torch.randn(N * oh * ow, Cout, generator=g).to(dev) if use_res else None
+    ldo = Cout + 32
+    maskd = torch.randn(N * oh * ow, Cout, generator=g).to(dev) if Cout % 4 == 0 else None
+    got = []
+    prev = ops.set_epilogue_mode(0)
+    try:
+        for mode in (1, 0):
+            ops.set_epilogue_mode(mode)
+            o1, _, _ = ops.conv2d_nhwc(xd, N, H, W, Cin, wp, Cout, k, k, stride, pad, scale=sc, shift=sh, residual=resd, relu=relu)
+            wide = torch.full((N * oh * ow, ldo), -7.0, device=dev)
+            ops.conv2d_nhwc(xd, N, H, W, Cin, wp, Cout, k, k, stride, pad, scale=sc, shift=sh, residual=resd, relu=relu,
+                            out=wide.view(-1)[8:], out_stride=ldo)
+            o3 = None
+            if maskd is not None:
+                o3 = torch.empty(N * oh * ow, Cout, device=dev)
+                ops.lib().call("dana_conv2d_nhwc_masked", xd.data_ptr(), wp.data_ptr(), o3.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                               resd.data_ptr() if use_res else None, maskd.data_ptr(), N, H, W, Cin, Cout, k, k, stride, pad, 0, 0, 0, 0,
+                               ops.EPI_RELU if relu else 0, ops._stream())
+            got.append((o1, wide, o3))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_epilogue_mode(prev)
+    assert torch.equal(got[0][0], got[1][0])
+    assert torch.equal(got[0][1], got[1][1]) and (got[1][1][:, :8] == -7).all() and (got[1][1][:, 8 + Cout:] == -7).all()
+    assert torch.equal(got[1][1][:, 8:8 + Cout], got[1][0])
+    if maskd is not None:
+        assert torch.equal(got[0][2], got[1][2])
+        assert torch.equal(got[1][2], torch.where(maskd > 0, got[1][0], torch.zeros_like(got[1][0])))
