@@ -1309,12 +1309,15 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) 
 //    to split, no VALU between the matrix instructions, and the pipeline depth is a template parameter (NST stages).
 //  * epilogue on the accumulator registers (epilogue_regs), residual rows requested in halves.
 //  NST = 2: 49.2 KB of LDS, <= 168 registers: THREE workgroups per CU; two barriers per K-step (tile published / stage free).
-//  NST >= 3 (APRE only): one barrier per K-step, NST - 1 tiles in flight (3: two workgroups per CU, 6: one -- tile-starved
-//  long-K launches are bound by the depth of their request pipeline, not by the matrix pipe).
+//  NST >= 3 (APRE only): one barrier per K-step, NST - 1 tiles in flight (3: two workgroups per CU).
+//  DF (APRE, NST >= 3): TWO fragment sets -- a tile-starved launch has one workgroup per CU and nothing to run in the shadow
+//  of a step's fragment reads (a lone workgroup walks K at ~1 200 cycles per step either way: 768 of MFMA + the read round
+//  trip); with the next tile's fragments read between this tile's MFMAs the step is the MFMA time. ~190 registers.
 // Same K-step order, same split, the same six products in the same order as igemm_split_kernel -> the same bits.
-template <int BN, int NST, int APRE>
+template <int BN, int NST, int APRE, int DF = 0>
 __global__ void __launch_bounds__(256, NST == 2 ? 3 : (NST == 3 ? 2 : 1)) igemm_dma_kernel(IgemmParams p) {
   static_assert(APRE || NST == 2, "fp32 activation rows: two stages");
+  static_assert(!DF || (APRE && NST >= 3), "two fragment sets: planes x planes, three or more stages");
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   constexpr int STAGE_B = 3 * (BM + BN) * 32;            // bytes per stage
   constexpr int NPB = 3 * BN / 32, PB = (NPB + 3) / 4;   // B pieces per step, per wave
@@ -1518,6 +1521,56 @@ __global__ void __launch_bounds__(256, NST == 2 ? 3 : (NST == 3 ? 2 : 1)) igemm_
   constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
   constexpr int PBp[6] = {0, 1, 0, 1, 2, 0};
   const unsigned long long t_loop = p.trace ? __builtin_readcyclecounter() : 0ull;
+  if constexpr (DF) {
+    // two fragment sets: step t multiplies tile t (set t & 1) while it reads tile t + 1 (published by the step's barrier) into
+    // the other set; the barrier also retires every wave's reads of tile t (issued during step t - 1), whose stage takes tile
+    // t + NST. In flight behind the barrier: tiles t + 2 .. t + NST.
+    constexpr int U = (NST % 2) ? 2 * NST : NST;  // steps per loop trip: stage and fragment-set indices are static
+    u32x4 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+    issue(NST - 1, NST - 1);  // (the prologue issued tiles 0 .. NST - 2)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * NDMA) : "memory");  // tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa0[pc][i] = *(const u32x4*)(a_rd + (pc * BM + i * 32) * SLD);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb0[pc][j] = *(const u32x4*)(b_rd + (pc * BN + j * 32) * SLD);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NDMA) : "memory");  // tile 1 landed
+    auto step = [&](auto uc, const u32x4(&fa)[3][TM], const u32x4(&fb)[3][TN], u32x4(&na)[3][TM], u32x4(&nb)[3][TN], int t) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int st_next = (u + 1) % NST, st_free = u % NST;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's reads of tile t: its stage is refilled below)
+      __builtin_amdgcn_s_barrier();
+      issue(t + NST, st_free);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int NM = 6 * TM * TN, NR = 3 * (TM + TN);
+      static_for<0, NM>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int pq = q / (TM * TN), ti = (q / TN) % TM, tj = q % TN;
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[pq]][ti]),
+                                                              __builtin_bit_cast(bf16x8, fb[PBp[pq]][tj]), acc[ti][tj], 0, 0, 0);
+        // one fragment read of tile t + 1 behind every second MFMA (planes in order h, m, l; A then B)
+        if constexpr (q % 2 == 0 && q / 2 < NR) {
+          constexpr int r = q / 2, pc = r / (TM + TN), x = r % (TM + TN);
+          if constexpr (x < TM) na[pc][x < TM ? x : 0] = *(const u32x4*)(a_rd + st_next * (STAGE_B / 4) + (pc * BM + x * 32) * SLD);
+          else nb[pc][x < TM ? 0 : x - TM] = *(const u32x4*)(b_rd + st_next * (STAGE_B / 4) + (pc * BN + (x - TM) * 32) * SLD);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NDMA) : "memory");  // tile t + 2 landed
+    };
+    for (int t0 = 0; t0 < nk; t0 += U) {
+      static_for<0, U>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if (t0 + u < nk) {  // (uniform)
+          if constexpr (u % 2 == 0) step(uc, fa0, fb0, fa1, fb1, t0 + u);
+          else step(uc, fa1, fb1, fa0, fb0, t0 + u);
+        }
+      });
+    }
+  } else
   for (int t0 = 0; t0 < nk; t0 += NST) {
     static_for<0, NST>([&](auto sc_) {
       constexpr int st = decltype(sc_)::value;
@@ -1701,16 +1754,16 @@ int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
   return 0;
 }
 
-template <int BN, int NST, int APRE>
+template <int BN, int NST, int APRE, int DF = 0>
 int launch_dma(const IgemmParams& p0, int batch, hipStream_t s) {
   IgemmParams p = p0;
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NST * 3 * (128 + BN) * 32;
   static DeviceOnce attr;
-  if (attr.need()) (void)hipFuncSetAttribute((const void*)igemm_dma_kernel<BN, NST, APRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr.need()) (void)hipFuncSetAttribute((const void*)igemm_dma_kernel<BN, NST, APRE, DF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-  igemm_dma_kernel<BN, NST, APRE><<<grid, 256, lds, s>>>(p);
+  igemm_dma_kernel<BN, NST, APRE, DF><<<grid, 256, lds, s>>>(p);
   return 0;
 }
 
@@ -1744,6 +1797,8 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
     if (stages == 2) return launch_dma<128, 2, 1>(p, batch, s);
     if (stages == 4) return launch_dma<128, 4, 1>(p, batch, s);
     if (stages == 6) return launch_dma<128, 6, 1>(p, batch, s);
+    if (stages == 13) return launch_dma<128, 3, 1, 1>(p, batch, s);  // (1x: two fragment sets)
+    if (stages == 14) return launch_dma<128, 4, 1, 1>(p, batch, s);
     return launch_dma<128, 3, 1>(p, batch, s);
   }
   // pre-split weights, no ReLU-adjoint mask: the three-workgroups-per-CU kernel for the launches that took 128 x 128 tiles
@@ -1753,8 +1808,11 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
     const int dm = e ? atoi(e) : 1;
     if (dm == 2) return p.N <= 64 ? launch_dma<64, 2, 0>(p, batch, s) : launch_dma<128, 2, 0>(p, batch, s);
     if (dm == 1 && p.N > 64) {
+      // measured (profiles/r5_dma_kernel_probe.md, each launch alone): with fp32 activation rows the third workgroup per CU
+      // pays on short K walks over many tiles (K = 64 / 128: -4 .. -10 %), is even at K = 256 and loses where a launch is
+      // tile-starved or K is long (one staging register set, the split in front of the step's MFMAs: +10 .. +30 %)
       const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-      if (t128 >= 100 && !(p.N <= 256 && p.N % 128 != 0 && p.N % 128 <= 32)) return launch_dma<128, 2, 0>(p, batch, s);
+      if (t128 >= 600 && p.K <= 192) return launch_dma<128, 2, 0>(p, batch, s);
     }
   }
   if (mode && p.KH * p.KW <= 32) {

@@ -549,7 +549,7 @@ def test_dma_kernel_gives_the_split_kernels_bits_on_gemms(dev, shape):
     old = _with_env("DANA_DMA_KERNEL", "0", run)
     new = _with_env("DANA_DMA_KERNEL", "2", run)
     assert torch.isfinite(new).all() and torch.equal(old, new)
-    for st in ("2", "3", "4", "6"):
+    for st in ("2", "3", "4", "6", "13", "14"):  # (1x: two fragment sets)
         pp = _with_env("DANA_PP_STAGES", st, lambda: run(True))
         assert torch.equal(old, pp), "planes x planes, %s stages" % st
 

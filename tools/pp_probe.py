@@ -55,7 +55,7 @@ for name, m, n, k, b, res in SHAPES:
         else:
             ops.gemm_nt(a3, w3, m, n, k, out=o_pp, ldc=n, scale=sc, shift=sh, residual=r, relu=True)
 
-    STAGES = ("2", "3", "4", "6")
+    STAGES = ("2", "3", "4", "6", "13", "14")
     t = {"split": [], "dma": []}
     t.update({"pp" + st: [] for st in STAGES})
     same = {}
@@ -84,11 +84,11 @@ for name, m, n, k, b, res in SHAPES:
             t["pp" + st].append(bracket(run_pp))
     med = {k_: sorted(v)[len(v) // 2] for k_, v in t.items()}
     rows.append((name, m, n, k, b, 2.0 * b * m * n * k / 1e9, med, same))
-L = ["| shape | GF | round-4 split kernel (2/CU) us | dma kernel, fp32 rows (3/CU) us | planes x planes 2 stages (3/CU) | 3 stages (2/CU) | 4 stages (1/CU) | 6 stages (1/CU) | dma / split | best planes / split | same bits |", "|---|---|---|---|---|---|---|---|---|---|---|"]
+L = ["| shape | GF | round-4 split kernel (2/CU) us | dma kernel, fp32 rows (3/CU) us | planes x planes 2 stages (3/CU) | 3 stages (2/CU) | 4 stages (1/CU) | 6 stages (1/CU) | 3 stages + 2 fragment sets | 4 stages + 2 fragment sets | dma / split | best planes / split | same bits |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for name, m, n, k, b, gf, med, same in rows:
-    best = min(med["pp2"], med["pp3"], med["pp4"], med["pp6"])
-    L.append("| %s M=%d N=%d K=%d b%d | %.2f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2f | %.2f | %s |" % (
-        name, m, n, k, b, gf, med["split"], med["dma"], med["pp2"], med["pp3"], med["pp4"], med["pp6"], med["dma"] / med["split"],
+    best = min(med["pp" + st_] for st_ in STAGES)
+    L.append("| %s M=%d N=%d K=%d b%d | %.2f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2f | %.2f | %s |" % (
+        name, m, n, k, b, gf, med["split"], med["dma"], med["pp2"], med["pp3"], med["pp4"], med["pp6"], med["pp13"], med["pp14"], med["dma"] / med["split"],
         best / med["split"], "yes" if all(same.values()) else "NO %s" % same))
 text = "\n".join(L) + "\n"
 print(text)
