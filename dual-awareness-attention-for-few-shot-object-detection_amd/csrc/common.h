@@ -52,3 +52,28 @@ static inline size_t dana_align_up(size_t x, size_t a) { return (x + a - 1) / a 
 size_t dana_wgrad_tn_batched_workspace(int planes, int M, int N, int K);
 int dana_wgrad_tn_batched(const float* dY, const float* X, float* out, int planes, int M, int N, int K, long batch_y,
                           long batch_x, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __HIPCC__
+// The exact three-way bf16 split of four fp32 values (igemm.hip: x = h + m + l, each a bf16 taken by truncation), packed
+// as the planes store them: 4 bf16 = 8 bytes per plane. Shared by the contraction kernels' staging path, dana_split_weight
+// and the producers that write an activation as split planes (winograd.hip).
+__device__ __forceinline__ void dana_split3(const float4& v, uint2& h, uint2& m, uint2& l) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    hb[q] = __float_as_uint(x[q]) & 0xffff0000u;
+    const float r1 = x[q] - __uint_as_float(hb[q]);  // exact
+    mb[q] = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb[q]);    // exact; <= 8 significant bits left
+    lb[q] = __float_as_uint(r2);
+  }
+  // pack the upper halves of two dwords: bytes {S1.2, S1.3, S0.2, S0.3}
+  h.x = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
+  h.y = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+  m.x = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+  m.y = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+  l.x = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+  l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+}
+#endif

@@ -382,25 +382,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-__device__ __forceinline__ void split3(const float4& v, uint2& h, uint2& m, uint2& l) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  unsigned hb[4], mb[4], lb[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    hb[q] = __float_as_uint(x[q]) & 0xffff0000u;
-    const float r1 = x[q] - __uint_as_float(hb[q]);  // exact
-    mb[q] = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mb[q]);    // exact; <= 8 significant bits left
-    lb[q] = __float_as_uint(r2);
-  }
-  // pack the upper halves of two dwords: bytes {S1.2, S1.3, S0.2, S0.3}
-  h.x = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
-  h.y = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
-  m.x = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
-  m.y = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
-  l.x = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
-  l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
-}
+__device__ __forceinline__ void split3(const float4& v, uint2& h, uint2& m, uint2& l) { dana_split3(v, h, m, l); }
 
 // Issue schedule of one K-step of the split kernel. Everything that is not an MFMA is cut into micro-items of one or two
 // INDEPENDENT instructions and dealt out over the NM gaps between the step's MFMAs so that every gap carries about the
@@ -1792,12 +1774,17 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   // launch that cannot give most CUs one of those falls back to 64x64 blocks (measured: tools/conv_sweep.py).
   const int mode = mfma_mode_cell().load(std::memory_order_relaxed);
   if (p.apre) {
-    const int stages = getenv("DANA_PP_STAGES") ? atoi(getenv("DANA_PP_STAGES")) : 3;  // (per call: tools/pp_probe.py)
+    // planes x planes. DANA_PP_STAGES forces a form (tools/pp_probe.py, tests): 2 / 3 / 4 / 6 stages, 13 / 14 = 3 / 4 stages
+    // with two fragment sets. Default (profiles/r5_dma_kernel_probe.md): many tiles and a short K walk -> two stages, three
+    // workgroups per CU; tile-starved or long-K launches -> three stages, two fragment sets.
+    const char* e = getenv("DANA_PP_STAGES");
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+    const int stages = e ? atoi(e) : ((t128 < 400 || p.K >= 1024) ? 13 : 2);
     if (p.N <= 64) return stages == 2 ? launch_dma<64, 2, 1>(p, batch, s) : launch_dma<64, 3, 1>(p, batch, s);
     if (stages == 2) return launch_dma<128, 2, 1>(p, batch, s);
     if (stages == 4) return launch_dma<128, 4, 1>(p, batch, s);
     if (stages == 6) return launch_dma<128, 6, 1>(p, batch, s);
-    if (stages == 13) return launch_dma<128, 3, 1, 1>(p, batch, s);  // (1x: two fragment sets)
+    if (stages == 13) return launch_dma<128, 3, 1, 1>(p, batch, s);
     if (stages == 14) return launch_dma<128, 4, 1, 1>(p, batch, s);
     return launch_dma<128, 3, 1>(p, batch, s);
   }

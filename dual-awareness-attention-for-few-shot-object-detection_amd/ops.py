@@ -871,12 +871,12 @@ def conv3x3_winograd(x, batch, h, w, cin, u, cout, scale=None, shift=None, relu=
     transform V, which conv3x3_wgrad_winograd(v=...) takes instead of transforming the input again."""
     _chk(x, "x")
     up, wfl = _wf(u)
-    if out is None:
-        out = torch.empty((batch * h * w, cout), dtype=torch.float32, device=x.device)
-        out_stride = cout
     m = 2 if (u.batch if isinstance(u, W3) else u.size(0)) == 16 else 4
     if wfl and m != 4:
         raise ValueError("conv3x3_winograd: split filters with F(4x4,3x3) only")
+    if out is None:
+        out = torch.empty((batch * h * w, cout), dtype=torch.float32, device=x.device)
+        out_stride = cout
     sfx = "" if m == 2 else "4"
     ws = _ws(lib().query("dana_conv3x3_winograd%s_workspace_bytes" % sfx, batch, h, w, cin, cout), x.device)
     e0 = _prof_begin()

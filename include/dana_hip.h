@@ -32,7 +32,12 @@ typedef void* dana_stream_t; /* hipStream_t */
  * batch_b = bf16 elements between the slices' first K-steps). Split kernel only (dana_set_mfma_mode != 0);
  * results are bit-identical to the fp32-weight call, the K loop just does not repeat the split per tile and step. */
 #define DANA_W_SPLIT3 256
-#define DANA_A_SPLIT3 512 /* dana_gemm_nt: `a` holds the activation rows as split planes too (see dana_gemm_nt) */
+/* dana_gemm_nt only: `a` holds the activation rows as split planes as well, [lda / 16][3][m][16] with lda = k rounded up to
+ * 16 and batch_a in bf16 elements (the layout of dana_split_weight with n = m): planes x planes form of igemm_dma_kernel -- both
+ * operands by LDS-DMA, no split and no staging registers in the K loop. Needs DANA_W_SPLIT3. Bit-identical to the fp32-rows
+ * call on the values the planes were split from. (Measured in round 5, profiles/r5_activation_planes.md: the GEMM itself is
+ * 6-19 % faster, a PRODUCER that writes planes pays 1.5x the bytes -- not used on the model's path.) */
+#define DANA_A_SPLIT3 512
 
 const char* dana_last_error(void);
 int dana_abi_version(void);

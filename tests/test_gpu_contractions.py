@@ -595,3 +595,4 @@ def test_register_epilogue_bits_on_every_conv_case(dev, case):
     if maskd is not None:
         assert torch.equal(got[0][2], got[1][2])
         assert torch.equal(got[1][2], torch.where(maskd > 0, got[1][0], torch.zeros_like(got[1][0])))
+
