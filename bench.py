@@ -887,6 +887,7 @@ def main():
         torch.cuda.empty_cache()
         return {"workload": label, "value": round(batch / best * 1e3, 3), "unit": "query-images/sec",
                 "ms_per_step": round(best, 3), "steps": k, "batch": batch,
+                "timing": "median GPU-side interval between consecutive steps (trial()), not the wall-clock mean of the headline",
                 "launch": "hipGraph replay" if (t_graph is not None and t_graph <= t_eager) else "eager",
                 "eager_ms_per_step": round(t_eager, 3), "graph_ms_per_step": None if t_graph is None else round(t_graph, 3),
                 "roofline": {"bound": "mfma", "achieved": round(f2 / t2 / 1e12, 2), "peak": pk, "unit": "TFLOP/s",

@@ -680,8 +680,14 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     ops.linear_backward(d_trq, q_pe, wt, n_roi * P2, rd, 1024, ldw=2048, dx_out=d_q_pe, dx_ld=1024, need_dw=False)
     main.wait_event(box_done)
     ops.axpy_rows_(d_pooled, d_q_pe, n_roi * P2, 1024)
-    d_bf = ops.roi_align_backward(d_pooled.view(n_roi, 7, 7, 1024), ctx["rois"].view(-1, 5), 1.0 / 16.0, 7, 7, B, 1024,
-                                  fh, fw, 0, layout=ops.NHWC)  # [B][fh][fw][1024]
+    if ctx.get("roi_argmax") is not None:
+        # cfg.POOLING_MODE == 'pool' (dana.py:183-184): every bin's gradient goes to its argmax element (ROIPool_cuda.cu:79-108)
+        g_nchw = ops.roi_pool_backward(ops.nhwc_to_nchw(d_pooled, n_roi, 1024, 7, 7), None, ctx["rois"].view(-1, 5),
+                                       ctx["roi_argmax"], 1.0 / 16.0, 7, 7, B, 1024, fh, fw)
+        d_bf = ops.nchw_to_nhwc(g_nchw).view(B * fh * fw, 1024)
+    else:
+        d_bf = ops.roi_align_backward(d_pooled.view(n_roi, 7, 7, 1024), ctx["rois"].view(-1, 5), 1.0 / 16.0, 7, 7, B, 1024,
+                                      fh, fw, 0, layout=ops.NHWC)  # [B][fh][fw][1024]
 
     # -- RoI-level support side: K projection, unary term, PE, 14x14 average pool (dana.py:105-108,271-277) --
     ops.colmean_sub_(d_k2, Ns, P2, dq)

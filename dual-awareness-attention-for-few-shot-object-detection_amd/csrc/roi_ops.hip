@@ -22,16 +22,6 @@
 
 namespace {
 
-// NHWC forward kernel choice (process-wide, like dana_set_mfma_mode): 1 (default) the per-sample loop whose fp32 summation
-// order is the reference's (bit-exact against cpu/ROIAlign_cpu.cpp), 0 the separable per-cell accumulation. Measured on
-// the bench's 512 rois (tools/roi_bench.py): 80.3 vs 83.9 us -- the launch is bound by WRITING its two 103 MB outputs
-// (pooled and pooled + PE: 205 of its 245 algorithmic MB), not by the taps, so halving the loads buys nothing and the
-// bit-exact kernel stays the default.
-std::atomic<int>& roi_exact_cell() {
-  static std::atomic<int> cell(getenv("DANA_ROI_ALIGN_EXACT") ? atoi(getenv("DANA_ROI_ALIGN_EXACT")) : 1);
-  return cell;
-}
-
 struct AxisSample {  // one bilinear sample position along one axis
   int lo, hi;
   float l, h;  // l = frac toward hi, h = 1 - l
@@ -119,6 +109,12 @@ roi_align_fwd_nchw(const float* __restrict__ in, const float* __restrict__ rois,
 
 // ---------------------------------------------------------------------------------
 // NHWC forward: workgroup = (roi, bin); lane = 4 consecutive channels (float4), stride 256*4.
+// (Round 5 built the verdict's alternative -- one workgroup per roi and bin ROW, sample geometry once per workgroup in LDS,
+// every feature column fetched once per sample row through a two-column register window, bit-exact -- and measured it SLOWER:
+// 120.8 vs ~85 us at the bench's 512 rois with two outputs. A bin row's samples form ONE dependent chain per wave (table
+// read -> window decision -> column fetch -> FMAs, up to 9 x 63 samples for the large proposals of this workload), where
+// 25 088 one-bin workgroups give the chip 7x as many short independent chains and the L1 absorbs the taps samples share.
+// Removed again; the separable non-exact kernel of rounds 3-4 is gone as well.)
 // in pixel (b,y,x) lives at in + ((b*H+y)*W+x)*in_pix_stride; out[n][bin][C] (+ optional second
 // output out2 = out + add2[bin][C], used to emit the positional-encoded copy in the same pass).
 __global__ void __launch_bounds__(256)
@@ -167,16 +163,7 @@ roi_align_fwd_nhwc(const float* __restrict__ in, const float* __restrict__ rois,
   }
 }
 
-// ---------------------------------------------------------------------------------
-// NHWC forward, separable form (dana_set_roi_align_exact(0)). The bilinear samples of one bin form a grid_h x grid_w
-// lattice, and the sum over it factorises:  sum_ij (h_i v[lo_i] + l_i v[hi_i]) (x) (h_j .. + l_j ..)
-//                                         = sum_r sum_c Wy[r] Wx[c] v[r][c]
-// with Wy[r] = the total weight the lattice's rows put on feature row r (Wx likewise). A bin then reads every feature
-// cell it touches ONCE -- (grid_h + 1)(grid_w + 1) float4 loads per lane instead of 4 grid_h grid_w: about half, and the
-// kernel is bound by exactly those loads (the L1 / TA path, not HBM). Same samples, same weights, same empty-sample rule
-// (ROIAlign_cuda.cu:22-47,81-101); only the order of the fp32 additions differs from the per-sample loop above, i.e. the
-// result agrees to ~1e-7 relative instead of bit for bit (dana_set_roi_align_exact(1) selects the per-sample kernel).
-constexpr int AXMAX = 32;  // feature rows / columns one bin may touch in the separable kernel (else: per-sample loop)
+// total weight the sample lattice of one bin puts on feature row / column `cell` (the gather backward below)
 
 __device__ __forceinline__ float axis_weight(int cell, int n_samples, float start, float bin, int idx, int size) {
   float w = 0.f;
@@ -188,96 +175,6 @@ __device__ __forceinline__ float axis_weight(int cell, int n_samples, float star
     if (s.hi == cell) w += s.l;
   }
   return w;
-}
-
-__global__ void __launch_bounds__(256)
-roi_align_fwd_nhwc_sep(const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out,
-                       float* __restrict__ out2, const float* __restrict__ add2,
-                       int C, int H, int W, int PH, int PW, float scale, int sr, long in_pix_stride,
-                       long out_pix_stride, long out2_pix_stride, int per_wg, int total_items) {
-  __shared__ float wy[AXMAX], wx[AXMAX];
-  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;  // (XCD-aware order, as above)
-  const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin % 8;
-  const int v0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin / 8;
-  const int bins = PH * PW;
-  // a workgroup walks `per_wg` consecutive (roi, bin) items (1 by default: the launch is not dispatch-bound)
-  for (int item = 0; item < per_wg; ++item) {
-  const int v = v0 * per_wg + item;
-  if (v >= total_items) break;
-  if (item) __syncthreads();  // (the previous item's weight tables are still being read)
-  const int n = v / bins;
-  const int bin = v % bins;
-  const int ph = bin / PW, pw = bin % PW;
-  const RoiGeom g = roi_geom(rois + (long)n * 5, scale, PH, PW, sr);
-  const float* img = in + (long)g.batch * H * W * in_pix_stride;
-  // rows / columns the lattice can touch: from the first sample's lower cell to the last sample's upper cell (monotone)
-  const AxisSample y0 = axis_sample(g.start_h + ph * g.bin_h + .5f * g.bin_h / (float)g.grid_h, H);
-  const AxisSample y1 = axis_sample(g.start_h + ph * g.bin_h + ((float)(g.grid_h - 1) + .5f) * g.bin_h / (float)g.grid_h, H);
-  const AxisSample x0 = axis_sample(g.start_w + pw * g.bin_w + .5f * g.bin_w / (float)g.grid_w, W);
-  const AxisSample x1 = axis_sample(g.start_w + pw * g.bin_w + ((float)(g.grid_w - 1) + .5f) * g.bin_w / (float)g.grid_w, W);
-  const int rmin = y0.lo, ny = y1.hi - y0.lo + 1, cmin = x0.lo, nx = x1.hi - x0.lo + 1;
-  const bool sep = ny <= AXMAX && nx <= AXMAX;  // (uniform)
-  if (sep) {
-    const int t = threadIdx.x;
-    if (t < AXMAX) wy[t] = t < ny ? axis_weight(rmin + t, g.grid_h, g.start_h, g.bin_h, ph, H) : 0.f;
-    else if (t < 2 * AXMAX) wx[t - AXMAX] = t - AXMAX < nx ? axis_weight(cmin + t - AXMAX, g.grid_w, g.start_w, g.bin_w, pw, W) : 0.f;
-    __syncthreads();
-  }
-  for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (sep) {
-      // two feature rows x four cells per pass, branch-free (a row / cell past the footprint is re-read with weight 0):
-      // eight independent 16-byte loads in flight per lane -- a typical 3 x 3-cell bin is two passes, where the per-sample
-      // loop walks four samples of four dependent-issue taps each
-      const float* base = img + ((long)rmin * W + cmin) * in_pix_stride + c;
-      const long rstep = (long)W * in_pix_stride;
-      for (int r = 0; r < ny; r += 2) {
-        const bool two = r + 1 < ny;
-        const float b0 = wy[r], b1 = two ? wy[r + 1] : 0.f;
-        const float* p0 = base + (long)r * rstep;
-        const float* p1 = two ? p0 + rstep : p0;
-        for (int cc = 0; cc < nx; cc += 4) {
-          const int i1 = cc + 1 < nx ? cc + 1 : cc, i2 = cc + 2 < nx ? cc + 2 : cc, i3 = cc + 3 < nx ? cc + 3 : cc;
-          const float a0 = wx[cc], a1 = cc + 1 < nx ? wx[cc + 1] : 0.f, a2 = cc + 2 < nx ? wx[cc + 2] : 0.f,
-                      a3 = cc + 3 < nx ? wx[cc + 3] : 0.f;
-          const float4 v0 = *(const float4*)(p0 + (long)cc * in_pix_stride), v1 = *(const float4*)(p0 + (long)i1 * in_pix_stride);
-          const float4 v2 = *(const float4*)(p0 + (long)i2 * in_pix_stride), v3 = *(const float4*)(p0 + (long)i3 * in_pix_stride);
-          const float4 u0 = *(const float4*)(p1 + (long)cc * in_pix_stride), u1 = *(const float4*)(p1 + (long)i1 * in_pix_stride);
-          const float4 u2 = *(const float4*)(p1 + (long)i2 * in_pix_stride), u3 = *(const float4*)(p1 + (long)i3 * in_pix_stride);
-          acc.x += b0 * (a0 * v0.x + a1 * v1.x + a2 * v2.x + a3 * v3.x) + b1 * (a0 * u0.x + a1 * u1.x + a2 * u2.x + a3 * u3.x);
-          acc.y += b0 * (a0 * v0.y + a1 * v1.y + a2 * v2.y + a3 * v3.y) + b1 * (a0 * u0.y + a1 * u1.y + a2 * u2.y + a3 * u3.y);
-          acc.z += b0 * (a0 * v0.z + a1 * v1.z + a2 * v2.z + a3 * v3.z) + b1 * (a0 * u0.z + a1 * u1.z + a2 * u2.z + a3 * u3.z);
-          acc.w += b0 * (a0 * v0.w + a1 * v1.w + a2 * v2.w + a3 * v3.w) + b1 * (a0 * u0.w + a1 * u1.w + a2 * u2.w + a3 * u3.w);
-        }
-      }
-    } else {
-      for (int iy = 0; iy < g.grid_h; ++iy) {
-        float y = g.start_h + ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
-        AxisSample sy = axis_sample(y, H);
-        for (int ix = 0; ix < g.grid_w; ++ix) {
-          float x = g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
-          AxisSample sx = axis_sample(x, W);
-          if (sy.empty || sx.empty) continue;
-          const float4 v1 = *(const float4*)(img + ((long)sy.lo * W + sx.lo) * in_pix_stride + c);
-          const float4 v2 = *(const float4*)(img + ((long)sy.lo * W + sx.hi) * in_pix_stride + c);
-          const float4 v3 = *(const float4*)(img + ((long)sy.hi * W + sx.lo) * in_pix_stride + c);
-          const float4 v4 = *(const float4*)(img + ((long)sy.hi * W + sx.hi) * in_pix_stride + c);
-          float w1 = sy.h * sx.h, w2 = sy.h * sx.l, w3 = sy.l * sx.h, w4 = sy.l * sx.l;
-          acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-          acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-          acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-          acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
-        }
-      }
-    }
-    float4 r = make_float4(acc.x / g.count, acc.y / g.count, acc.z / g.count, acc.w / g.count);
-    *(float4*)(out + ((long)n * PH * PW + bin) * out_pix_stride + c) = r;
-    if (out2) {
-      const float4 a = *(const float4*)(add2 + (long)bin * C + c);
-      *(float4*)(out2 + ((long)n * PH * PW + bin) * out2_pix_stride + c) =
-          make_float4(r.x + a.x, r.y + a.y, r.z + a.z, r.w + a.w);
-    }
-  }  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -570,30 +467,14 @@ int dana_roi_align_forward(const float* input, const float* rois, float* output,
                    "dana_roi_align_forward: NHWC needs C and pixel strides %% 4 == 0");
     DANA_CHECK_ARG(!output2 || add2, "dana_roi_align_forward: output2 needs add2");
     dim3 grid(num_rois, pooled_h * pooled_w);
-    if (roi_exact_cell().load(std::memory_order_relaxed))
-      roi_align_fwd_nhwc<<<grid, 256, 0, s>>>(input, rois, output, output2, add2, channels, height, width, pooled_h,
-                                              pooled_w, spatial_scale, sampling_ratio, in_pix_stride,
-                                              out_pix_stride, out2_pix_stride);
-    else
-    {
-      // (items per workgroup: measured 92.9 / 90.6 / 99.6 / 128 / 253 us at 1 / 3 / 7 / 14 / 49 -- more workgroups win)
-      static const int per = getenv("DANA_ROI_PER_WG") ? atoi(getenv("DANA_ROI_PER_WG")) : 1;
-      const int per_wg = per > 0 ? per : 1, total_items = num_rois * pooled_h * pooled_w;
-      roi_align_fwd_nhwc_sep<<<dana_ceil_div(total_items, per_wg), 256, 0, s>>>(
-          input, rois, output, output2, add2, channels, height, width, pooled_h, pooled_w, spatial_scale, sampling_ratio,
-          in_pix_stride, out_pix_stride, out2_pix_stride, per_wg, total_items);
-    }
+    roi_align_fwd_nhwc<<<grid, 256, 0, s>>>(input, rois, output, output2, add2, channels, height, width, pooled_h,
+                                            pooled_w, spatial_scale, sampling_ratio, in_pix_stride,
+                                            out_pix_stride, out2_pix_stride);
   } else {
     DANA_CHECK_ARG(false, "dana_roi_align_forward: unknown layout %d", layout);
   }
   DANA_CHECK_LAUNCH("dana_roi_align_forward");
   return DANA_OK;
-}
-
-int dana_set_roi_align_exact(int exact) {
-  const int prev = roi_exact_cell().load(std::memory_order_relaxed);
-  roi_exact_cell().store(exact ? 1 : 0, std::memory_order_relaxed);
-  return prev;
 }
 
 int dana_roi_align_backward(const float* grad_out, const float* rois, float* grad_in, int batch, int channels,

@@ -421,18 +421,23 @@ class DAnARCNN(nn.Module):
         weight version (the contraction of the table is one 49-row GEMM on the same kernels)"""
         lq, lt = self.rcnn_adapt_q_layer, self.rcnn_transform_layer
         sig = tuple((t.data_ptr(), t._version) for t in (lq.weight, lq.bias, lt.weight, lt.bias)) + (
-            self._epoch, ops.get_mfma_mode(), self.presplit_weights, n_roi)
+            self._epoch, ops.get_mfma_mode(), self.presplit_weights)
         e = self._conv_cache.get("roi_query_fold")
         if e is None or e[0] != sig:
             wcat = torch.cat([lq.weight.detach(), lt.weight.detach()[:, :1024]], 0).contiguous()
             bcat = torch.cat([lq.bias.detach(), lt.bias.detach()]).contiguous()
             n = wcat.size(0)
             table = ops.gemm_nt(plan["pe49"], wcat, 49, n, 1024, shift=bcat)
-            tfull = table.repeat(n_roi, 1).contiguous()
             b3 = ops.split_weight(wcat, n, 1024) if (self.presplit_weights and ops.get_mfma_mode() != 0) else None
-            e = self._conv_cache["roi_query_fold"] = (sig, (b3 if b3 is not None else wcat, 0 if b3 is not None else 1024,
-                                                            tfull))
-        return e[1]
+            e = self._conv_cache["roi_query_fold"] = (sig, b3 if b3 is not None else wcat, 0 if b3 is not None else 1024, table, {})
+        # the row-periodic residual operand, expanded per RoI count (train / eval / secondary workloads alternate: each count
+        # keeps its own expansion instead of rebuilding the one entry on every switch)
+        tfull = e[4].get(n_roi)
+        if tfull is None:
+            if len(e[4]) >= 4:
+                e[4].clear()
+            tfull = e[4][n_roi] = e[3].repeat(n_roi, 1).contiguous()
+        return e[1], e[2], tfull
 
     # ---- trunk -----------------------------------------------------------------------------------
     @staticmethod
@@ -991,6 +996,12 @@ class DAnARCNN(nn.Module):
         if inter is not None:
             inter["rpn_heads"] = heads
             inter["rpn_rois"] = rois
+        inj_rois = getattr(self, "_inject_rpn_rois", None)
+        if inj_rois is not None:
+            # stage-wise parity hook (tests only): an EXTERNAL proposal list (the oracle's) replaces this forward's, so that
+            # this build's own proposal-target sampling runs on an identical candidate list and its picks can be compared
+            # position by position at the full size (one near-tie among 12 000 sorted scores otherwise shifts every slot)
+            rois = inj_rois.to(dev).float().contiguous()
 
         if tl is not None:
             tl.append(("enqueued trunk..proposals", _time.perf_counter()))
@@ -1062,11 +1073,12 @@ class DAnARCNN(nn.Module):
                                                       pe=plan["pe49"])  # pooled [n,49,1024] and pooled + PE (dana.py:259)
         elif cfg.POOLING_MODE == "pool":
             # dana.py:183-184 (a resumed checkpoint's cfg may ask for it, train.py:100-101): the RoIPool operator of the
-            # `_C` boundary on base_feat (the first 1024 channels of the [.. | attended] buffer), forward only
+            # `_C` boundary on base_feat (the first 1024 channels of the [.. | attended] buffer); the saving forward keeps
+            # the argmax indices for the backward's scatter (ROIPool_cuda.cu:79-108, dana_roi_pool_backward)
+            pooled_nchw, roi_argmax = ops.roi_pool_forward(ops.nhwc_to_nchw(corr, B, 1024, fh, fw, in_stride=2048),
+                                                           rois.view(-1, 5).contiguous(), 1.0 / 16.0, P, P)
             if ctx is not None:
-                raise NotImplementedError("the HIP backward of DAnA covers POOLING_MODE 'align' (cfgs/res50.yml:35)")
-            pooled_nchw, _ = ops.roi_pool_forward(ops.nhwc_to_nchw(corr, B, 1024, fh, fw, in_stride=2048),
-                                                  rois.view(-1, 5).contiguous(), 1.0 / 16.0, P, P)
+                ctx["roi_argmax"] = roi_argmax
             pooled = ops.nchw_to_nhwc(pooled_nchw).view(n_roi, P * P, 1024)
             q_pe = ops.add_pe(pooled, plan["pe49"], n_roi * P * P, P * P, 1024).view(n_roi, P * P, 1024)
         else:

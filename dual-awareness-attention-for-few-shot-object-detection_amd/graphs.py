@@ -56,6 +56,9 @@ class GraphedDAnA:
         torch.cuda.synchronize(dev)
         if getattr(model, "device_rng", False):
             model._rng_counter(dev).fill_(2 * model._rng_calls)  # continues the eager call sequence
+        # the forward that runs DURING capture bumps the host-side call count but draws nothing (its kernels only run in the
+        # replays, which advance the device counter themselves): the count is put back behind the capture
+        calls0 = model._rng_calls
         torch.cuda.synchronize(dev)
         self.side = torch.cuda.Stream(device=dev)  # the anchor-target graph replays here, beside the trunk
         self.g0 = None
@@ -86,6 +89,7 @@ class GraphedDAnA:
                     except StopIteration as done:
                         out = done.value
         self.outputs = out
+        model._rng_calls = calls0
         cur.wait_stream(self.stream)
 
     def __call__(self, *inputs):
@@ -157,7 +161,6 @@ class GraphedTrainer:
             self.model._epoch += 1
             torch.cuda.synchronize(dev)
         cur.wait_stream(self.stream)
-        self._captured_once = False
         self._capture()
 
     def recapture(self):
@@ -193,12 +196,11 @@ class GraphedTrainer:
             seen.extend(fresh)
             return fresh
 
-        if getattr(model, "device_rng", False) and not getattr(self, "_captured_once", False):
-            # first capture: the device counter continues the eager call sequence. A RE-capture (learning-rate change)
-            # keeps the counter where the replays left it -- refilling it from the host count, which replays do not
-            # advance, would rewind the Philox stream and repeat the draws of earlier iterations
+        # the device counter continues the host-side call sequence (eager forwards and replays both advance the host count;
+        # the capture's own forward does not draw: its count is put back below), on the first capture and on a re-capture
+        if getattr(model, "device_rng", False):
             model._rng_counter(dev).fill_(2 * model._rng_calls)
-        self._captured_once = True
+        calls0 = model._rng_calls
         torch.cuda.synchronize(dev)
         try:
             with torch.no_grad():
@@ -247,6 +249,7 @@ class GraphedTrainer:
                         self._sgd()
         finally:
             model.save_for_backward = prev_save
+            model._rng_calls = calls0  # (the capture's forward drew nothing)
             for fb, _, _ in tr.groups:
                 fb.capture_only = False
                 fb.zero_grad_bookkeeping()

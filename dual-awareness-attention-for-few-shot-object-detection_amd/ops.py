@@ -208,12 +208,6 @@ def roi_align_forward_nhwc(feat, B, H, W, C, pix_stride, rois, spatial_scale, po
     return out, out_pe
 
 
-def set_roi_align_exact(exact):
-    """NHWC RoIAlign forward: False (default) = separable per-cell accumulation (~1e-7 relative of the reference's
-    summation), True = the per-sample loop, bit-identical to cpu/ROIAlign_cpu.cpp. Returns the previous setting."""
-    return bool(lib().query("dana_set_roi_align_exact", 1 if exact else 0))
-
-
 def roi_align_backward(grad, rois, spatial_scale, pooled_h, pooled_w, batch, channels, height, width,
                        sampling_ratio, layout=NCHW):
     grad = _chk(grad.contiguous(), "grad")

@@ -69,13 +69,8 @@ int dana_set_igemm_trace(unsigned long long* buffer);
  * input + ((b*H+y)*W+x)*in_pix_stride (stride 0 => C) -> output [R][PH*PW][out_pix_stride];
  * optional output2 = output + add2[PH*PW][C] written in the same pass (fused positional
  * encoding, dana.py:258-259).
- * NHWC arithmetic: by default the per-sample loop, bit-identical to cpu/ROIAlign_cpu.cpp. dana_set_roi_align_exact(0)
- * (or DANA_ROI_ALIGN_EXACT=0) selects a separable form -- every feature cell a bin touches read once and weighted by
- * the summed row x column weights of the bin's sample lattice: the same samples and weights as ROIAlign_cuda.cu:64-122,
- * about half the loads, ~1e-7 relative of the per-sample summation -- which is NOT faster on MI355X (the launch is bound
- * by writing its outputs). Returns the previous setting. NCHW (the reference contract of `model._C.roi_align_forward`)
- * is always the per-sample loop. */
-int dana_set_roi_align_exact(int exact);
+ * Arithmetic: the reference's per-sample loop in the reference's order -- bit-identical to cpu/ROIAlign_cpu.cpp in both
+ * layouts. */
 int dana_roi_align_forward(const float* input, const float* rois, float* output, int batch, int channels,
                            int height, int width, int num_rois, float spatial_scale, int pooled_h,
                            int pooled_w, int sampling_ratio, int layout, long in_pix_stride,

@@ -530,9 +530,17 @@ def forward(sd, im_data, im_info, gt_boxes, num_boxes, support_ims, training, n_
     if inter is not None:
         inter["rois"] = rois
     if pooling == "pool":  # dana.py:183-184: cfg.POOLING_MODE == 'pool' -> RCNN_roi_pool (ROIPool.h)
-        assert not differentiable
-        pooled = torch.from_numpy(native.roi_pool_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(),
-                                                          1.0 / 16.0, 7, 7)[0])
+        out_np, arg_np = native.roi_pool_forward(base_feat.detach().numpy(), rois.view(-1, 5).numpy(), 1.0 / 16.0, 7, 7)
+        pooled = torch.from_numpy(out_np)
+        if differentiable:
+            # ROIPool_cuda.cu:79-108: the gradient of a bin goes to ITS argmax element (-1: empty bin, no gradient) -- a
+            # gather through the forward's argmax, not torch.amax (which splits ties, and post-ReLU maps are full of them)
+            r5 = rois.view(-1, 5)
+            arg = torch.from_numpy(arg_np).long()
+            Bf, Cf, Hf, Wf = base_feat.shape
+            src = base_feat.reshape(Bf, Cf, Hf * Wf)[r5[:, 0].long()]
+            pooled = (torch.gather(src, 2, arg.clamp(min=0).reshape(arg.size(0), Cf, 49)) * (arg.reshape(arg.size(0), Cf, 49) >= 0)
+                      ).reshape(arg.size(0), Cf, 7, 7)
     elif differentiable:
         pooled = roi_align_torch(base_feat, rois.view(-1, 5), 1.0 / 16.0, 7)
     else:

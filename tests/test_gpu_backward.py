@@ -115,6 +115,22 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba, mfma_mode):
     """every trainable parameter's gradient of (rpn_cls + rpn_box + rcnn_cls + rcnn_box), HIP backward vs autograd
     through the oracle (same weights, inputs and np.random stream -> same sampled anchors / rois), with the
     contractions on the bf16 matrix cores (exact split, the default) and on the f32 MFMA"""
+    _model_backward_vs_oracle(dev, use_ba, "align")
+
+
+def test_model_backward_in_roi_pool_mode_vs_oracle_autograd(dev):
+    """cfg.POOLING_MODE = 'pool' (dana.py:183-184; a resumed checkpoint may set it, train.py:100-101) through the HIP
+    backward: RoIPool's argmax scatter (ROIPool_cuda.cu:79-108, dana_roi_pool_backward) in place of RoIAlign's gather"""
+    from dana_amd.config import cfg
+    prev = cfg.POOLING_MODE
+    cfg.POOLING_MODE = "pool"
+    try:
+        _model_backward_vs_oracle(dev, True, "pool")
+    finally:
+        cfg.POOLING_MODE = prev
+
+
+def _model_backward_vs_oracle(dev, use_ba, pooling):
     import dana_amd
     from dana_amd import synthetic as S, backward as BW
     from oracle import model_ref as O
@@ -145,7 +161,8 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba, mfma_mode):
             res = m(*[t.to(dev) for t in inputs])
         np.random.seed(33)
         with torch.no_grad():
-            probe = O.forward(sd, *inputs, training=True, n_way=way, n_shot=shot, use_ba=use_ba, nms_inclusive=True)
+            probe = O.forward(sd, *inputs, training=True, n_way=way, n_shot=shot, use_ba=use_ba, nms_inclusive=True,
+                              pooling=pooling)
         if np.array_equal(res[7].cpu().numpy(), probe[7].numpy()) and \
                 (res[0].cpu() - probe[0]).abs().max().item() < 0.05:
             break
@@ -156,7 +173,7 @@ def test_model_backward_vs_oracle_autograd(dev, use_ba, mfma_mode):
            for k, v in sd.items()}
     np.random.seed(33)
     out = O.forward(osd, *inputs, training=True, n_way=way, n_shot=shot, use_ba=use_ba, nms_inclusive=True,
-                    differentiable=True)
+                    differentiable=True, pooling=pooling)
     loss = sum(wt * l for wt, l in zip(weights, out[3:7]))
     loss.backward()
     assert np.array_equal(res[7].cpu().numpy(), out[7].numpy()), "different sampled rois: cannot compare gradients"

@@ -312,6 +312,16 @@ def _train_vs_oracle(dev, B, way, shot, H, W, ba, wseed=11, iseed=1996, nseed=5,
     m._inject_sampled = None
     assert np.array_equal(out2[0].cpu().numpy(), ref[0].numpy())
     _assert_train_outputs(out2, [t.numpy() if torch.is_tensor(t) else t for t in ref])
+    # (e) this build's OWN proposal-target sampling (targets.hip / sampling on 2 000 + n_gt candidates per image) at this size,
+    # position by position: the oracle's proposal LIST goes in (not its sampled batch), the same np.random stream draws ->
+    # the same picks in the same order, the same labels, and everything downstream within the train-output bars
+    m._inject_rpn_rois = inter["rpn_rois"]
+    np.random.seed(nseed)
+    with torch.no_grad():
+        out3 = m(*din)
+    m._inject_rpn_rois = None
+    assert np.array_equal(out3[0].cpu().numpy(), ref[0].numpy()), "own sampling on the oracle's proposal list picks other rois"
+    _assert_train_outputs(out3, [t.numpy() if torch.is_tensor(t) else t for t in ref])
     return float(matched.mean()), flip_free
 
 

@@ -47,41 +47,27 @@ def test_roi_align_nhwc_matches_nchw_and_pe(G, dev):
     pooled, pooled_pe = ops.roi_align_forward_nhwc(buf, B, H, W, C, stride, rois, 1.0 / 16, 7, 0, pe=pe)
     assert torch.equal(pooled, ref)
     assert torch.equal(pooled_pe, ref + pe.unsqueeze(0))
-    # dana_set_roi_align_exact(0): separable per-cell accumulation -- the same samples and weights, another order of the
-    # fp32 additions. Tolerance 1e-6 of the feature scale (north_star's bar is 1e-4 on scores / 1e-3 IoU on boxes)
-    prev = ops.set_roi_align_exact(False)
-    assert prev
-    try:
-        pooled, pooled_pe = ops.roi_align_forward_nhwc(buf, B, H, W, C, stride, rois, 1.0 / 16, 7, 0, pe=pe)
-    finally:
-        ops.set_roi_align_exact(prev)
-    scale = float(ref.abs().max())
-    assert float((pooled - ref).abs().max()) <= 1e-6 * scale
-    assert float((pooled_pe - (ref + pe.unsqueeze(0))).abs().max()) <= 1e-6 * (scale + float(pe.abs().max()))
 
 
-def test_roi_align_nhwc_separable_vs_oracle_large(dev):
-    """the separable NHWC kernel (dana_set_roi_align_exact(0)) on 300 random rois (degenerate, out of bounds, bins of 0.1 .. 30 cells -- the widest ones
-    take the kernel's per-sample fallback) against the oracle's restatement of cpu/ROIAlign_cpu.cpp: 1e-6 of the scale"""
+def test_roi_align_nhwc_is_bit_exact_on_wild_rois(dev):
+    """the NHWC kernel on 300 random rois -- degenerate, out of bounds, bins of 0.1 .. 30 cells, sampling_ratio 0 and 2,
+    channel counts that are not a multiple of the workgroup -- against the oracle's restatement of cpu/ROIAlign_cpu.cpp:
+    array_equal"""
     ops, orc = _ops(), _oracle()
     rng = np.random.default_rng(6)
-    B, C, H, W = 2, 64, 50, 84
-    feat = rng.normal(size=(B, C, H, W)).astype(np.float32)
-    rois = np.zeros((300, 5), np.float32)
-    x1 = rng.uniform(-40, 1300, 300); y1 = rng.uniform(-40, 780, 300)
-    rois[:, 0] = rng.integers(0, B, 300)
-    rois[:, 1], rois[:, 2] = x1, y1
-    rois[:, 3], rois[:, 4] = x1 + rng.uniform(0, 1400, 300), y1 + rng.uniform(0, 800, 300)
-    rois[:8, 3:] = rois[:8, 1:3]  # zero-size boxes
-    nhwc = torch.from_numpy(feat).to(dev).permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
-    prev = ops.set_roi_align_exact(False)
-    try:
-        got, _ = ops.roi_align_forward_nhwc(nhwc, B, H, W, C, C, torch.from_numpy(rois).to(dev), 1 / 16., 7, 0)
-    finally:
-        ops.set_roi_align_exact(prev)
-    ref = orc.roi_align_forward(feat, rois, 1 / 16., 7, 7, 0)  # [R][C][7][7]
-    ref = np.transpose(ref, (0, 2, 3, 1)).reshape(300, 49, C)
-    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+    for (B, C, H, W), sr in (((2, 64, 50, 84), 0), ((2, 1028, 12, 20), 0), ((1, 8, 200, 320), 0), ((2, 64, 50, 84), 2)):
+        feat = rng.normal(size=(B, C, H, W)).astype(np.float32)
+        rois = np.zeros((300, 5), np.float32)
+        x1 = rng.uniform(-40, 16 * W, 300); y1 = rng.uniform(-40, 16 * H, 300)
+        rois[:, 0] = rng.integers(0, B, 300)
+        rois[:, 1], rois[:, 2] = x1, y1
+        rois[:, 3], rois[:, 4] = x1 + rng.uniform(0, 17 * W, 300), y1 + rng.uniform(0, 17 * H, 300)
+        rois[:8, 3:] = rois[:8, 1:3]  # zero-size boxes
+        nhwc = torch.from_numpy(feat).to(dev).permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+        got, _ = ops.roi_align_forward_nhwc(nhwc, B, H, W, C, C, torch.from_numpy(rois).to(dev), 1 / 16., 7, sr)
+        ref = orc.roi_align_forward(feat, rois, 1 / 16., 7, 7, sr)  # [R][C][7][7]
+        ref = np.transpose(ref, (0, 2, 3, 1)).reshape(300, 49, C)
+        assert np.array_equal(got.cpu().numpy(), ref), (B, C, H, W, sr)
 
 
 def test_roi_align_large_random_vs_oracle(dev):
