@@ -16,25 +16,6 @@ from . import ops
 from .config import cfg
 
 
-USE_WINOGRAD_WGRAD = __import__("os").environ.get("DANA_WINO_WGRAD", "1") != "0"
-SAVED_WINOGRAD_V = __import__("os").environ.get("DANA_WGRAD_SAVED_V", "1") != "0"  # weight gradients reuse the forward's V planes
-PREFETCH_DGRAD_W = __import__("os").environ.get("DANA_PREFETCH_DGRAD_W", "1") != "0"  # trunk dgrad weights derived on a side stream
-# 1 (default): everything on the side stream from the backward's start (round 3); 3: the RPN conv's and layer4's copies derived
-# on their own chains, the trunk's on a side stream issued BEHIND the heads' backward; 2: the trunk's from the start; 0: all lazy.
-# Which is fastest depends on what the PROCESS did before (profiles/r4_graph_handover.md 3): in a process that only trains,
-# mode 3 wins by 0.3 ms (17.15 -> 16.86); behind bench.py's forward runs and graph captures mode 1 wins by 1.6 ms (18.47 -> 16.88).
-PREFETCH_MODE = int(__import__("os").environ.get("DANA_PREFETCH_MODE", "1"))
-# Linear dW / db off the dgrad chain, on the weight-gradient stream: "1" always, "0" never, "auto" (default) only under stream
-# capture. Round 3 measured -0.5 ms for the side stream; since the RPN chain runs beside the box branch and the heads from the
-# backward's start (round 4), the eager iteration is 0.3 ms FASTER with these launches on the heads' own chain (17.40 -> 17.08 ms,
-# three interleaved pairs), while the graph replay -- box branch on the caller's stream there -- still prefers the side stream.
-LINEAR_WGRAD_ON_SIDE = __import__("os").environ.get("DANA_LINEAR_WGRAD_SIDE", "auto")
-GATHER_STRIDED_WGRAD = __import__("os").environ.get("DANA_WGRAD_GATHER", "1") != "0"
-MERGED_WINO_DGRAD = __import__("os").environ.get("DANA_MERGED_WINO_DGRAD", "1") != "0"  # merged blocks: one dual-group 3x3 dgrad
-RPN_CHAIN_ORDER = int(__import__("os").environ.get("DANA_RPN_CHAIN_ORDER", "0"))  # host issue order: 0 first, 1 behind the box branch, 2 behind the heads
-RPN_CHAIN_EARLY = __import__("os").environ.get("DANA_RPN_CHAIN_EARLY", "1") != "0"  # RPN adjoints beside the RoI stage's
-
-
 class WeightGrads:
     """Accumulates packed weight gradients per conv (query and support passes share the weights).
     With `stream`, the weight-gradient launches go to that side stream: they only consume (g, x) and nothing on the
@@ -106,15 +87,17 @@ class WeightGrads:
 
     def linear(self, g, x, m, n, k, then, ldx=0, ldg=0):
         """dW / db of a Linear (ops.linear_wgrad) on the side stream; then(dw, db) accumulates them there"""
-        side = LINEAR_WGRAD_ON_SIDE == "1" or (LINEAR_WGRAD_ON_SIDE == "auto" and torch.cuda.is_current_stream_capturing())
-        if not side:
+        # eager issue: on the caller's chain (with the RPN chain, the box branch and the heads running from the backward's
+        # start the side stream costs 0.3 ms, round 4); under stream capture the side stream (the box branch shares the
+        # caller's stream there)
+        if not torch.cuda.is_current_stream_capturing():
             then(*ops.linear_wgrad(g, x, m, n, k, ldx=ldx, ldg=ldg))
             return
         self.side_run(lambda: then(*ops.linear_wgrad(g, x, m, n, k, ldx=ldx, ldg=ldg)), g, x)
 
     def _launch(self, key, g, x, n, h, w, c, in_stride, grad_stride, v=None):
         view = self._direct_view(key)
-        if c["k"] == 1 and c["stride"] > 1 and c["pad"] == 0 and GATHER_STRIDED_WGRAD:
+        if c["k"] == 1 and c["stride"] > 1 and c["pad"] == 0:
             # a strided 1x1 conv (first block of layer2-4: conv1 and the downsample conv read the same pixels): gather those
             # pixels once into plain rows -- both weight gradients then run on the software-pipelined plain-row kernel
             ck = (x.data_ptr(), n, h, w, c["cin"], c["stride"], in_stride, ops.cur_stream().cuda_stream)
@@ -124,13 +107,13 @@ class WeightGrads:
             (x, h, w), in_stride = ent[0], 0
             c = dict(c, stride=1)
         u = c.get("u")
-        if u is not None and u.size(0) == 36 and c["cin"] % 64 == 0 and USE_WINOGRAD_WGRAD:
+        if u is not None and u.size(0) == 36 and c["cin"] % 64 == 0:
             # the conv ran in the F(4x4,3x3) domain forward: so does its weight gradient (4x fewer multiplies)
             out = view if view is not None else self.packed.get(key)
             res = ops.conv3x3_wgrad_winograd(g, x, n, h, w, c["cin"], c["cout"], in_stride=in_stride,
                                              grad_stride=grad_stride, out=out,
                                              row_scale=c.get("scale") if view is not None else None,
-                                             v=v if SAVED_WINOGRAD_V else None)
+                                             v=v)
             if out is None:
                 self.packed[key] = res
             return
@@ -251,7 +234,7 @@ def bottleneck_backward_merged(g, sq, ss, sm, bp, grads, key):
     g2 = conv_dgrad(g, 1, mt, 1, c3, mask=sm["o2"])
     g1 = torch.empty((mt, c2["cin"]), dtype=torch.float32, device=g.device)
     ud = _dgrad_weights(c2)[1]
-    dual = MERGED_WINO_DGRAD and ud is not None and ud.size(0) == 36
+    dual = ud is not None and ud.size(0) == 36
     for part, s_ in ((slice(0, mq), sq), (slice(mq, mt), ss)):
         grads.add_conv(key + ".conv2", g2[part], sm["o1"][part], s_["n"], s_["h1"], s_["w1"], c2, v=s_.get("v2"))
         if not dual:
@@ -499,12 +482,13 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     # -- the trunk's data-gradient weights (flipped / transposed / BN-scaled copies, Winograd-domain filters: ~45 small
     #    launches that depend on the weights only) are derived on a stream of their own instead of one by one in front of
     #    the trunk's data-gradient launches that need them (the chain every other launch of the trunk's backward waits
-    #    for); joined into the caller's stream before the pause below. (PREFETCH_MODE 3 issues that stream behind the
-    #    heads' backward instead: faster in a process that only trains, much slower behind other work -- see above) --
+    #    for); joined into the caller's stream before the pause below. (Issuing that stream behind the heads' backward
+    #    instead is 0.3 ms faster in a process that only trains and 1.6 ms slower behind other work -- HIP spreads a process's
+    #    streams over four hardware queues in creation order, profiles/r4_graph_handover.md 3: the robust order stays) --
     rpn = model.RCNN_rpn
     c_rpn = _rpn_conv_plan(model, ctx)
     dgw_ready = l4w_ready = rpnw_ready = None
-    pmode = PREFETCH_MODE if (PREFETCH_DGRAD_W and not getattr(model, "_single_stream", False)) else 0
+    prefetch = not getattr(model, "_single_stream", False)
     seen = set()
 
     def derive(saved):
@@ -515,14 +499,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
                     seen.add(id(c))
                     _dgrad_weights(c)
 
-    def prefetch_trunk():
-        prep = model._stream("dgradw", dev)
-        prep.wait_event(ops.record_event())
-        with ops.on_stream(prep):
-            derive(ctx["q_saved"])
-            return ops.record_event()
-
-    if pmode == 1:
+    if prefetch:
         prep = model._stream("dgradw", dev)
         ev0 = ops.record_event()
         prep.wait_event(ev0)
@@ -534,8 +511,6 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
             l4w_ready = ops.record_event()
             derive(ctx["q_saved"])
             dgw_ready = ops.record_event()
-    elif pmode == 2:
-        dgw_ready = prefetch_trunk()
 
     # -- RPN chain (_rpn_chain). It depends on the forward's saved tensors only and meets the RoI stage's gradients in
     #    base_feat / the support maps, so it runs on a stream of its own FROM THE START of the backward, beside the box
@@ -549,7 +524,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     main = ops.cur_stream()
     single = getattr(model, "_single_stream", False)
     capturing = torch.cuda.is_current_stream_capturing()
-    rpn_early = RPN_CHAIN_EARLY and not single
+    rpn_early = not single
     rpn_out = rpn_done = None
     rpn_start = ops.record_event() if rpn_early else None
 
@@ -563,7 +538,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
                 t_.record_stream(main)
             return out, ops.record_event()
 
-    if rpn_early and RPN_CHAIN_ORDER == 0:
+    if rpn_early:  # (issued FIRST: its two 300 us launches buy the host the time to issue the other chains; round 4: 1.2 ms)
         rpn_out, rpn_done = launch_rpn_chain()
 
     # -- seeds: d RCNN losses / d (scores, bbox_pred) were written by the fused loss kernel (dana_rcnn_loss);
@@ -604,8 +579,6 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
         grads.finish_all(model, "RCNN_top")
         _ready(model, stages[0][1])
         box_done = ops.record_event()
-    if rpn_early and RPN_CHAIN_ORDER == 1:
-        rpn_out, rpn_done = launch_rpn_chain()
 
     # -- RoI-level attention heads (dana.py:248-292), positive then negative supports --
     q_pe, q2, sp_pe, k2, un2 = ctx["q_pe"], ctx["q2"], ctx["sp_pe"], ctx["k2"], ctx["un2"]
@@ -701,10 +674,6 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     _acc(model.rcnn_unary_layer.bias, ops.colsum(d_un2, Ns * P2, 1))
     (sh_, sw_), pool = ctx["sup_map"], ctx["sup_pool"]
     d_sup = ops.avgpool_backward(d_sp_pe, Ns, sh_, sw_, 1024, pool[0], pool[1])  # [Ns][L][1024]
-    if rpn_early and RPN_CHAIN_ORDER == 2:
-        rpn_out, rpn_done = launch_rpn_chain()
-    if pmode == 3:
-        dgw_ready = prefetch_trunk()
     grads.join()  # (the heads' Linear weight / bias gradients were accumulated on the weight-gradient stream)
     _ready(model, stages[1][1])
 

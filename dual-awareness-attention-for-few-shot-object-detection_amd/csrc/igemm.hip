@@ -1682,7 +1682,7 @@ split_weight_kernel(const float* __restrict__ w, long ldw, long batch_w, int n, 
 
 // Epilogue form of the split kernel (dana_set_epilogue_mode): 0 = on the accumulator registers (default), 1 = LDS C tile.
 std::atomic<int>& epilogue_mode_cell() {
-  static std::atomic<int> cell(getenv("DANA_EPILOGUE_LDS") ? atoi(getenv("DANA_EPILOGUE_LDS")) : 0);
+  static std::atomic<int> cell(0);
   return cell;
 }
 
@@ -1717,20 +1717,17 @@ int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
   const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds_c > lds && ELDS) lds = lds_c;
   if (FUSE && lds < (size_t)4 * 3 * BM * 16 * 2) lds = (size_t)4 * 3 * BM * 16 * 2;  // the tile as four K-steps of A
-  const char* pad_env = getenv("DANA_LDS_PAD");  // (experiment, tools/occupancy_probe.py: fewer workgroups per CU)
-  const size_t lds_attr = pad_env ? 160 * 1024 : lds;
-  if (pad_env) lds += (size_t)atoi(pad_env);
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
   static DeviceOnce attr;
   if constexpr (BM * BN >= 128 * 128) {
     if (attr.need())
       (void)hipFuncSetAttribute((const void*)igemm_split_kernel_128<STEM, BPRE, ELDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_attr);
+                                (int)lds);
     igemm_split_kernel_128<STEM, BPRE, ELDS><<<grid, 256, lds, s>>>(p);
   } else {
     if (attr.need())
       (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE, FUSE, ELDS>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     igemm_split_kernel<BM, BN, STEM, BPRE, FUSE, ELDS><<<grid, 256, lds, s>>>(p);
   }
   return 0;
@@ -1815,26 +1812,13 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
     // tile four; tools/tile_sweep.py). Launch by launch, ALONE on the chip, smaller tiles win more often now: fewer than
     // ~230 128x128 tiles -> 64x64 (layer3's reduce convs, the Q / K projections: -5 %), a short K walk with one to two
     // rounds of tiles or a residual epilogue behind K <= 256 -> 128x64 (layer2 / layer3 expand convs -7 %); that rule set
-    // (DANA_TILE_RULE=2) is worth -1 % of the summed launch durations (roofline 0.4175 -> 0.4215) -- and COSTS 3 % of the
+    // (removed in round 5) was worth -1 % of the summed launch durations (roofline 0.4175 -> 0.4215) -- and COST 3 % of the
     // step's wall clock (639-643 -> 619-621 query-images/s, same box): the step runs two kernel streams, and many small
     // workgroups of one kernel crowd out the other stream's blocks that would have filled its tail. The default keeps
     // 128x128 wherever the grid can give ~100 CUs one tile.
-    if (mode == 1) {
-      static const int rule = getenv("DANA_TILE_RULE") ? atoi(getenv("DANA_TILE_RULE")) : 0;
-      if (rule == 2) {
-        if (t128 < 230) return launch_split<64, 64>(p, batch, s);
-        if ((p.K <= 512 && t128 < 400) || (p.residual && p.K <= 256 && p.K >= 128)) return launch_split<128, 64>(p, batch, s);
-      } else if (t128 < 100) {
-        return launch_split<64, 64>(p, batch, s);
-      }
-    }
+    if (mode == 1 && t128 < 100) return launch_split<64, 64>(p, batch, s);
     return launch_split<128, 128>(p, batch, s);
   }
-  static const int force = getenv("DANA_IGEMM_TILE") ? atoi(getenv("DANA_IGEMM_TILE")) : 0;
-  if (force == 1 && p.N > 64) return launch<128, 128, 0>(p, batch, s);
-  if (force == 2) return launch<128, 64, 0>(p, batch, s);
-  if (force == 4 && p.N > 64) return launch<64, 128, 0>(p, batch, s);
-  if (force == 5 && p.N > 128) return launch<64, 256, 0>(p, batch, s);
   return launch<64, 64, 0>(p, batch, s);
 }
 

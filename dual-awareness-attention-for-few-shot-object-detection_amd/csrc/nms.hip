@@ -303,25 +303,11 @@ int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, 
   int* state = (int*)(remv_g + (size_t)problems * cb);
   unsigned long long* diag_t = (unsigned long long*)(state + 2 * (size_t)problems + 2 * ((size_t)problems & 1));
   unsigned long long* prev_t = diag_t + (size_t)problems * n;
-  // Band edges in units of max_keep boxes x 100 (DANA_NMS_BANDS="250,500": the first pass covers 2.5 x max_keep boxes,
-  // the second up to 5 x, the last the rest; "0": a single pass). An edge that would leave less than a quarter of the
-  // problem for the later bands is dropped.
-  struct Bands {
-    int pct[8], n;
-    Bands() : n(0) {  // (parsed once, under the thread-safe initialisation of the function-local static below)
-      const char* e = getenv("DANA_NMS_BANDS");
-      if (!e) e = "250,500";
-      while (*e && n < 8) {
-        const int v = atoi(e);
-        if (v > 0) pct[n++] = v;
-        while (*e && *e != ',') ++e;
-        if (*e == ',') ++e;
-      }
-    }
-  };
-  static const Bands bands;
-  const int* edges_pct = bands.pct;
-  const int n_edges = bands.n;
+  // Band edges in units of max_keep boxes x 100: the first pass covers 2.5 x max_keep boxes, the second up to 5 x, the last
+  // the rest (measured best on the proposal layer's 12 000 -> 2 000 problems; a single pass is what "0" edges give). An
+  // edge that would leave less than a quarter of the problem for the later bands is dropped.
+  static const int edges_pct[2] = {250, 500};
+  const int n_edges = 2;
   int edge[10], nb = 0;  // band i = column blocks [edge[i], edge[i+1])
   edge[nb++] = 0;
   // (worth it only when the full triangle is a real cost: a band that turns out to be needed adds ~25 us of restart)

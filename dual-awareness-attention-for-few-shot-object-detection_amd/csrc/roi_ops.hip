@@ -483,8 +483,7 @@ int dana_roi_align_backward(const float* grad_out, const float* rois, float* gra
   DANA_CHECK_ARG(batch >= 0 && channels > 0 && height > 0 && width > 0 && num_rois >= 0,
                  "dana_roi_align_backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  static const bool gather = !getenv("DANA_ROI_BWD_GATHER") || atoi(getenv("DANA_ROI_BWD_GATHER")) != 0;
-  if (gather && layout == DANA_LAYOUT_NHWC && num_rois > 0 && batch > 0 && channels % 4 == 0 && pooled_h <= GB_MAXP &&
+  if (layout == DANA_LAYOUT_NHWC && num_rois > 0 && batch > 0 && channels % 4 == 0 && pooled_h <= GB_MAXP &&
       pooled_w <= GB_MAXP && ((uintptr_t)grad_out & 15) == 0 && ((uintptr_t)grad_in & 15) == 0) {
     // gather form: writes every cell once (no memset), deterministic
     DANA_CHECK_ARG(grad_out && rois && grad_in, "dana_roi_align_backward: null pointer");

@@ -745,18 +745,15 @@ WgradShape wgrad_shape(int N, int K, int M, int planes = 1) {
   // Pick (tile, S) by a small cost model: `rounds` of workgroups over the chip's slots (2 per CU for the 128x128
   // tile, 4 for 64x64), each doing chunk/32 slabs, plus the HBM round trip of the S partial tiles. The 128x128
   // tile sustains ~0.75 of the per-CU MFMA peak (one LDS read per MFMA), the 64x64 tile ~0.5 (two).
-  static const int forced = [] { const char* e = getenv("DANA_WGRAD_TILE"); return e ? atoi(e) : 0; }();
   WgradShape best = {64, 1, 1, 1};
   double best_t = 1e30;
   for (int tile = 64; tile <= 128; tile += 64) {
-    if (forced && tile != forced) continue;
     const int tn = (N + tile - 1) / tile, tk = (K + tile - 1) / tile;
     const long tiles = (long)tn * tk * planes;
     const int slots = tile == 128 ? 512 : 1024;
     // the 128 x 128 tile runs on the bf16x6 split kernel (419.4 TFLOP/s ceiling, ~0.5 of it sustained) unless
     // dana_set_mfma_mode(0); the 64 x 64 tile is always the f32-MFMA kernel (157.3)
-    static const int old_model = getenv("DANA_WGRAD_MODEL_R1") ? 1 : 0;
-    const bool split = tile == 128 && dana_get_mfma_mode() != 0 && !old_model;
+    const bool split = tile == 128 && dana_get_mfma_mode() != 0;
     const double cu_flops = split ? 419.4e12 / 256.0 * 0.5 : 157.3e12 / 256.0 * (tile == 128 ? 0.75 : 0.5);
     const double wg_flops = cu_flops / (tile == 128 ? 2 : 4);
     const int maxS = (M + 255) / 256 < 64 ? (M + 255) / 256 : 64;
@@ -783,8 +780,7 @@ void launch_wgrad_128(const WgradParams& p, dim3 grid, hipStream_t s) {
     if (attr.need()) (void)hipFuncSetAttribute((const void*)wgrad_split_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     // rows of both operands are pixel rows (1x1 / stride 1 / no padding: every Linear, most convs, the Winograd-domain
     // planes): the software-pipelined kernel; strided / multi-tap launches: the general one
-    static const bool pipelined = !getenv("DANA_WGRAD_PIPELINED") || atoi(getenv("DANA_WGRAD_PIPELINED")) != 0;
-    if (pipelined && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {
+    if (p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {
       static DeviceOnce attr_p;
       if (attr_p.need()) (void)hipFuncSetAttribute((const void*)wgrad_split_128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       wgrad_split_128p_kernel<<<grid, 256, lds, s>>>(p);

@@ -26,11 +26,10 @@ class FasterRCNN(DAnARCNN):
         self.class_agnostic = True
         self.semantic_enhance = False
         self.use_winograd = True
-        self.winograd_tile = int(__import__("os").environ.get("DANA_WINO_TILE", 4))
-        self.winograd_min_cin = int(__import__("os").environ.get("DANA_WINO_MIN_CIN",
-                                                                 128 if self.winograd_tile == 4 else 256))
-        self.query_streams, self.query_sequential, self.merge_trunk = 1, False, False
-        self.presplit_weights = __import__("os").environ.get("DANA_PRESPLIT", "1") != "0"
+        self.winograd_tile = 4
+        self.winograd_min_cin = 128
+        self.merge_trunk = False
+        self.presplit_weights = True
         self.nms_inclusive = False
         self.device_rng, self.rng_seed, self._rng_calls = False, 1996, 0
         self.RCNN_rpn = _RPNParams(self.dout_base_model)

@@ -46,8 +46,6 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 _get_cur = getattr(torch._C, "_cuda_getCurrentStream", None)
 _set_cur = getattr(torch._C, "_cuda_setStream", None)
-if __import__("os").environ.get("DANA_FAST_STREAMS", "1") == "0":  # (A/B aid: the torch.cuda calls)
-    _get_cur = _set_cur = None
 
 
 # Stream bookkeeping without torch.cuda's Python layers. torch.cuda.current_stream(), `with torch.cuda.stream(s)` and
@@ -907,7 +905,7 @@ def set_epilogue_mode(mode):
     return prev
 
 
-SPLIT_K = __import__("os").environ.get("DANA_SPLIT_K", "1") != "0"  # split-K for tile-starved GEMMs (few tiles, long K)
+SPLIT_K = True  # split-K for tile-starved GEMMs (few tiles, long K); tools flip it for A/Bs
 
 
 def _splitk_slices(m, n, k, batch):

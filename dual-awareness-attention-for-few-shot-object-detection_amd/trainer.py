@@ -139,9 +139,6 @@ class FlatBuckets:
             dist.broadcast(self.params, src, group=self.group)
 
 
-DIRECT_BACKWARD = __import__("os").environ.get("DANA_TRAINER_DIRECT", "1") != "0"
-
-
 class Trainer:
     def __init__(self, model, lr, momentum=None, weight_decay=None, double_bias=None, bias_decay=None,
                  process_group=None, bucket_bytes=32 << 20, optimizer="sgd", always_reduce=False):
@@ -171,14 +168,12 @@ class Trainer:
         self.bufs = [torch.zeros_like(fb.params) for fb, _, _ in self.groups]  # SGD momentum / Adam exp_avg
         self.bufs2 = [torch.zeros_like(fb.params) for fb, _, _ in self.groups] if optimizer == "adam" else None
         self.steps = 0
-        env = __import__("os").environ
-        if (type(model).__name__ == "DAnARCNN" and env.get("DANA_TRAIN_MERGED", "1") != "0"
-                and "DANA_MERGE_TRUNK" not in env and "DANA_MERGE_FROM" not in env):
+        if type(model).__name__ == "DAnARCNN" and not model.merge_trunk and getattr(model, "train_merged", True):
             # the training iteration keeps the query and the support batch in ONE set of activation buffers (the trunk's
             # launches stay two per conv on two streams: merge_from 3), so that the backward's 1x1 weight / data gradients
             # run once over both batches (backward.bottleneck_backward_merged). A preference for the forwards that save
-            # for THIS trainer's backward only: the model's configured path (merge_trunk / merge_from, or an explicit
-            # DANA_MERGE_TRUNK / DANA_MERGE_FROM) stays what every eval / inference / bench forward takes.
+            # for THIS trainer's backward only: the model's configured path (merge_trunk / merge_from) stays what every
+            # eval / inference / bench forward takes; model.train_merged = False keeps the two-buffer form here as well.
             model._train_merge = (True, 3)
         model._plan = None  # parameter storage moved: re-pack on the next forward
         model._grad_ready_cb = self._on_ready
@@ -223,7 +218,7 @@ class Trainer:
         support_ims; frcnn: without the supports); returns the model's 8-tuple (losses detached)"""
         self.zero_grad()
         model = self.model
-        if DIRECT_BACKWARD and type(model).__name__ == "DAnARCNN":
+        if type(model).__name__ == "DAnARCNN":
             # train.py:138-143 differentiates the plain sum of the four (scalar) losses: upstream gradients (1, 1, 1, 1).
             # Calling the HIP backward directly instead of through the autograd bridge (four .mean() launches, three adds,
             # the engine's thread hop) keeps the host ahead of the GPU at the forward -> backward hand-over, where the eager
@@ -243,113 +238,6 @@ class Trainer:
             loss.backward()
         self.optimizer_step()
         return out
-
-    # ---- checkpoint / resume (train.py:92-101,181-189 save and restore model + optimizer state) -----------------
-    def _views(self, flat_of):
-        """name -> logical-shape view of a flat buffer (conv weights are stored [O][KH][KW][I])"""
-        out = {}
-        params = dict(self.model.named_parameters())
-        for fb, flat in flat_of:
-            for n in fb.names:
-                o, k = fb.offsets[n]
-                p = params[n]
-                if p.dim() == 4:
-                    O, I, KH, KW = p.shape
-                    out[n] = flat[o:o + k].view(O, KH, KW, I).permute(0, 3, 1, 2)
-                else:
-                    out[n] = flat[o:o + k].view(p.shape)
-        return out
-
-    def state_dict(self):
-        """optimizer state in the parameters' logical (OIHW) shapes, like torch.optim.SGD's momentum_buffer entries"""
-        mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
-        out = {"lr": self.lr, "momentum": self.momentum, "steps": self.steps, "optimizer": self.optimizer,
-               "momentum_buffer": {n: v.detach().clone().contiguous() for n, v in mom.items()}}
-        if self.optimizer == "adam":
-            sq = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs2)])
-            out["exp_avg_sq"] = {n: v.detach().clone().contiguous() for n, v in sq.items()}
-        return out
-
-    def _trainable_names(self):
-        """the order train.py:76-85 builds its one-parameter groups in: named_parameters(), requires_grad only"""
-        return [n for n, p in self.model.named_parameters() if p.requires_grad]
-
-    def torch_optim_state_dict(self):
-        """the same state in torch.optim's format (`checkpoint['optimizer']` of train.py:181-189): index-keyed
-        `state[i]['momentum_buffer']` (SGD) or `exp_avg` / `exp_avg_sq` / `step` (Adam) and one param group per
-        parameter with its lr / weight decay, indices in the reference's parameter order"""
-        names = self._trainable_names()
-        mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
-        sq = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs2)]) if self.optimizer == "adam" else {}
-        mult = {n: (lr_mult, wd) for fb, lr_mult, wd in self.groups for n in fb.names}
-        state, groups = {}, []
-        for i, n in enumerate(names):
-            if self.optimizer == "adam":
-                state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": mom[n].detach().clone().contiguous(),
-                            "exp_avg_sq": sq[n].detach().clone().contiguous()}
-            else:
-                state[i] = {"momentum_buffer": mom[n].detach().clone().contiguous()}
-            # full torch.optim groups (every key SGD / Adam's step() reads), so that the reference's resume path
-            # (train.py:92-101: optimizer.load_state_dict(checkpoint['optimizer'])) can step on the exported dict
-            g = {"params": [i], "lr": self.lr * mult[n][0], "weight_decay": mult[n][1], "maximize": False, "foreach": None,
-                 "differentiable": False, "fused": None}
-            if self.optimizer == "sgd":
-                g.update(momentum=self.momentum, dampening=0, nesterov=False)
-            else:
-                g.update(betas=(0.9, 0.999), eps=1e-8, amsgrad=False, capturable=False, decoupled_weight_decay=False)
-            groups.append(g)
-        return {"state": state if self.steps else {}, "param_groups": groups}
-
-    def load_state_dict(self, state):
-        """accepts this class's own `state_dict()` or a torch.optim SGD / Adam state_dict (the reference's
-        `checkpoint['optimizer']`, train.py:92-101): indices are mapped through the reference's parameter order, the
-        base learning rate is read from a weight's group (biases carry lr * (DOUBLE_BIAS + 1), train.py:79-84)"""
-        if "param_groups" in state:
-            names = self._trainable_names()
-            groups = state["param_groups"]
-            idx_of = {i: n for i, n in enumerate(names)}
-            if sum(len(g["params"]) for g in groups) != len(names):
-                raise ValueError("optimizer state has %d parameters, the model %d trainable ones"
-                                 % (sum(len(g["params"]) for g in groups), len(names)))
-            st = state.get("state", {})
-            is_adam = any("exp_avg" in v for v in st.values())
-            if st and is_adam != (self.optimizer == "adam"):
-                raise ValueError("checkpoint holds %s state, this trainer runs %s" % ("Adam" if is_adam else "SGD", self.optimizer))
-            mult = {n: lr_mult for fb, lr_mult, _ in self.groups for n in fb.names}
-            for g in groups:  # base lr from the first weight (non-bias) group
-                n = idx_of[g["params"][0]]
-                if "bias" not in n:
-                    self.lr = float(g["lr"]) / mult[n]
-                    if "momentum" in g:
-                        self.momentum = float(g["momentum"])
-                    break
-            mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
-            sq = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs2)]) if self.optimizer == "adam" else {}
-            steps = 0
-            for i, n in idx_of.items():
-                e = st.get(i, st.get(str(i)))
-                if e is None:
-                    mom[n].zero_()
-                    continue
-                if self.optimizer == "adam":
-                    mom[n].copy_(e["exp_avg"])
-                    sq[n].copy_(e["exp_avg_sq"])
-                    steps = max(steps, int(float(e.get("step", 0))))
-                elif e.get("momentum_buffer") is not None:
-                    mom[n].copy_(e["momentum_buffer"])
-                    steps = max(steps, 1)
-            self.steps = steps
-            return
-        if state.get("optimizer", self.optimizer) != self.optimizer:
-            raise ValueError("checkpoint holds %s state, this trainer runs %s" % (state.get("optimizer"), self.optimizer))
-        self.lr, self.momentum, self.steps = float(state["lr"]), float(state["momentum"]), int(state["steps"])
-        mom = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs)])
-        for n, v in mom.items():
-            v.copy_(state["momentum_buffer"][n])
-        if self.optimizer == "adam":
-            sq = self._views([(fb, buf) for (fb, _, _), buf in zip(self.groups, self.bufs2)])
-            for n, v in sq.items():
-                v.copy_(state["exp_avg_sq"][n])
 
     def adjust_learning_rate(self, decay=0.1):
         """net_utils.adjust_learning_rate (train.py:118-120)"""

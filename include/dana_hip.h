@@ -49,8 +49,7 @@ int dana_abi_version(void);
  * Replaces nothing in the reference: cuDNN picks its own algorithm / math mode there (lib/model/framework/resnet.py). */
 int dana_set_mfma_mode(int mode);
 int dana_get_mfma_mode(void);
-/* Epilogue form of the split kernel (a configuration call like dana_set_mfma_mode; environment DANA_EPILOGUE_LDS=1 sets the
- * initial value). 0 (default): scale / shift / residual / ReLU / ReLU-adjoint mask run on the accumulator registers and the
+/* Epilogue form of the split kernel (a configuration call like dana_set_mfma_mode). 0 (default): scale / shift / residual / ReLU / ReLU-adjoint mask run on the accumulator registers and the
  * results leave as dword buffer stores (a 32x32 accumulator row = 32 consecutive channels = one 128-byte segment per row and
  * half-wave): no LDS C tile, 49 instead of 67.6 KB of LDS per 128x128 tile. 1: the round-1..4 form through an LDS C tile
  * (float4 rows). Same arithmetic in the same order -> the same bits (tests/test_gpu_contractions.py). */

@@ -261,115 +261,6 @@ def test_trainer_step_matches_reference_loop_with_torch_sgd(dev):
     assert len(moved) == sum(p.requires_grad for p in pa.values()) - 7
 
 
-def test_checkpoint_resume_reproduces_the_next_iteration(dev):
-    """train.py:92-101,181-189: save model + optimizer state after one iteration, restore into a FRESH model / trainer
-    (reference OIHW layout in, kernel layout inside), and the next iteration gives the same parameters"""
-    import io
-    import dana_amd
-    from dana_amd import synthetic as S
-    from dana_amd.trainer import Trainer
-
-    def build(seed):
-        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=2, shot=2, classes=["fg", "bg"])
-        m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=seed, profile="test"))
-        return m.to(dev).train()
-
-    inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=6)]
-    ma = build(5)
-    ta = Trainer(ma, 0.01)
-    np.random.seed(1)
-    ta.step(*inputs)
-    buf = io.BytesIO()
-    torch.save({"model": ma.state_dict(), "optimizer": ta.state_dict()}, buf)  # train.py:181-189
-    np.random.seed(2)
-    ta.step(*inputs)
-    buf.seek(0)
-    ck = torch.load(buf, map_location=dev)
-    mb = build(99)  # different initial weights: everything must come from the checkpoint
-    mb.load_state_dict(ck["model"])
-    tb = Trainer(mb, 0.5)
-    tb.load_state_dict(ck["optimizer"])
-    assert tb.lr == 0.01 and tb.steps == 1
-    np.random.seed(2)
-    tb.step(*inputs)
-    torch.cuda.synchronize()
-    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
-    for k in pa:  # (RoIAlign backward accumulates with float atomics, like the reference's: equal up to summation order)
-        d = (pa[k].detach() - pb[k].detach()).abs().max().item()
-        assert d <= 1e-6 + 1e-5 * pa[k].detach().abs().max().item(), (k, d)
-
-
-def test_trainer_resumes_from_a_torch_optim_checkpoint(dev):
-    """the reference's checkpoint['optimizer'] is a torch.optim.SGD state_dict (train.py:92-101,181-189: one param group
-    per trainable parameter, index-keyed momentum buffers): Trainer.load_state_dict maps it through the reference's
-    parameter order; Trainer.torch_optim_state_dict() exports the same format; a mismatching optimizer type is refused"""
-    import dana_amd
-    from dana_amd import synthetic as S
-    from dana_amd.config import cfg
-    from dana_amd.trainer import Trainer
-
-    def build():
-        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=2, shot=2, classes=["fg", "bg"])
-        m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=5, profile="test"))
-        return m.to(dev).train()
-
-    inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=6)]
-    lr = 0.01
-    ma = build()
-    params = []
-    for key, value in dict(ma.named_parameters()).items():  # train.py:76-85
-        if value.requires_grad:
-            if "bias" in key:
-                params += [{"params": [value], "lr": lr * (cfg.TRAIN.DOUBLE_BIAS + 1),
-                            "weight_decay": cfg.TRAIN.BIAS_DECAY and cfg.TRAIN.WEIGHT_DECAY or 0}]
-            else:
-                params += [{"params": [value], "lr": lr, "weight_decay": cfg.TRAIN.WEIGHT_DECAY}]
-    opt = torch.optim.SGD(params, momentum=cfg.TRAIN.MOMENTUM)
-    np.random.seed(1)
-    out = ma(*inputs)
-    loss = out[3].mean() + out[4].mean() + out[5].mean() + out[6].mean()
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
-    ck_model = {k: v.detach().clone() for k, v in ma.state_dict().items()}
-    import copy
-    ck_opt = copy.deepcopy(opt.state_dict())  # (state_dict() hands out references to the live momentum buffers)
-    np.random.seed(2)
-    out = ma(*inputs)
-    loss = out[3].mean() + out[4].mean() + out[5].mean() + out[6].mean()
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
-    mb = build()
-    mb.load_state_dict(ck_model)
-    tb = Trainer(mb, 0.5)
-    tb.load_state_dict(ck_opt)
-    assert abs(tb.lr - lr) < 1e-12 and tb.steps == 1 and abs(tb.momentum - cfg.TRAIN.MOMENTUM) < 1e-12
-    exported = tb.torch_optim_state_dict()
-    assert len(exported["param_groups"]) == len(ck_opt["param_groups"])
-    for i, g in enumerate(ck_opt["param_groups"]):
-        assert abs(exported["param_groups"][i]["lr"] - g["lr"]) < 1e-12
-        assert float((exported["state"][i]["momentum_buffer"] - ck_opt["state"][i]["momentum_buffer"]).abs().max()) == 0.0
-    # the export must be something torch.optim can load AND step on (train.py:92-101 resume path): full param groups
-    for kind, ex in (("sgd", exported), ("adam", Trainer(build(), 0.1, optimizer="adam").torch_optim_state_dict())):
-        ps = [torch.nn.Parameter(torch.zeros_like(p_)) for p_ in mb.parameters() if p_.requires_grad]
-        groups = [{"params": [p_]} for p_ in ps]
-        o2 = torch.optim.SGD(groups, lr=0.1, momentum=0.9) if kind == "sgd" else torch.optim.Adam(groups, lr=0.1)
-        o2.load_state_dict(ex)
-        for p_ in ps:
-            p_.grad = torch.ones_like(p_)
-        o2.step()
-    np.random.seed(2)
-    tb.step(*inputs)
-    torch.cuda.synchronize()
-    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
-    for k in pa:
-        d = (pa[k].detach() - pb[k].detach()).abs().max().item()
-        assert d <= 1e-6 + 1e-5 * pa[k].detach().abs().max().item(), (k, d)
-    with pytest.raises(ValueError, match="SGD"):
-        Trainer(build(), 0.1, optimizer="adam").load_state_dict(ck_opt)
-
-
 def test_trainer_adam_matches_torch_adam(dev):
     """train.py:84-85 (--o adam): two iterations through the autograd bridge + torch.optim.Adam vs Trainer(optimizer='adam')"""
     import dana_amd
