@@ -596,3 +596,36 @@ def test_register_epilogue_bits_on_every_conv_case(dev, case):
         assert torch.equal(got[0][2], got[1][2])
         assert torch.equal(got[1][2], torch.where(maskd > 0, got[1][0], torch.zeros_like(got[1][0])))
 
+
+
+def test_large_lds_kernels_launch_on_every_visible_device():
+    """hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one process driving several devices (nn.DataParallel's
+    thread per device, include/dana_hip.h) must opt in on each of them (csrc/common.h DeviceOnce). Runs a 128 x 128-tile
+    contraction (49 KB, LDS epilogue form 67.6 KB), the planes x planes kernel (73.7 KB) and a weight-gradient launch on
+    EVERY visible device; skips on a one-GPU box (the driver's 8-GPU node runs it)."""
+    from dana_amd import ops
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("one visible device")
+    if ops.get_mfma_mode() == 0:
+        pytest.skip("split kernels only")
+    g = torch.Generator().manual_seed(3)
+    a0, w0 = torch.randn(1024, 256, generator=g), torch.randn(384, 256, generator=g) * 0.05
+    ref = a0.double() @ w0.double().t()
+    for d in range(n_dev):
+        with torch.cuda.device(d):
+            dv = torch.device("cuda", d)
+            a, w = a0.to(dv), w0.to(dv)
+            w3, a3 = ops.split_weight(w, 384, 256), ops.split_weight(a, 1024, 256)
+            outs = [ops.gemm_nt(a, w, 1024, 384, 256, force_slices=1), ops.gemm_nt(a, w3, 1024, 384, 256, force_slices=1),
+                    ops.gemm_nt(a3, w3, 1024, 384, 256)]
+            prev = ops.set_epilogue_mode(1)
+            try:
+                outs.append(ops.gemm_nt(a, w, 1024, 384, 256, force_slices=1))
+            finally:
+                ops.set_epilogue_mode(prev)
+            dw = ops.linear_wgrad(outs[0], a, 1024, 384, 256)[0]
+            torch.cuda.synchronize(dv)
+            for o in outs:
+                _close(o.cpu(), ref.float())
+            _close(dw.cpu(), (outs[0].cpu().double().t() @ a0.double()).float(), 2e-4)
