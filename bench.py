@@ -248,11 +248,22 @@ def main():
         else:
             dist.barrier()
 
+    def flush_c_stdout():
+        """RCCL prints a version banner through C stdio when its first communicator comes up; on a pipe that buffer is
+        flushed at process exit, i.e. BEHIND rank 0's JSON line. Push it out now: the JSON line stays the last line."""
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+
     rccl_ranks_seen = None
     if world > 1:  # one tiny all_reduce before anything else: how many ranks does the collective backend really span?
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
         rccl_ranks_seen = int(one.item())
+        flush_c_stdout()
         if rccl_ranks_seen != world:
             raise SystemExit("bench.py: the %s process group spans %d ranks, %d were launched" % (backend, rccl_ranks_seen, world))
 
@@ -547,6 +558,8 @@ def main():
             set_coll(True)
             for _ in range(2):
                 eager_train_step()  # (communicator warm-up: the first collectives build RCCL's channels)
+            torch.cuda.synchronize()
+            flush_c_stdout()
             alone = []
             for _ in range(7):
                 barrier()
@@ -936,9 +949,11 @@ def main():
         if cb is not None:
             result["cpu_baseline"] = cb
         result["summary"] = summary
+        flush_c_stdout()
         print(json.dumps(result), flush=True)
     if world > 1:
         dist_barrier()  # the other ranks wait for rank 0's roofline pass before tearing down
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
