@@ -12,11 +12,10 @@
 #include "common.h"
 #include <atomic>
 #include "../../include/dana_hip.h"
-#include <rocprim/rocprim.hpp>
 
 namespace {
 
-std::atomic<int> g_sort_mode{0};  // dana_set_library_sort: 0 = measured dispatch, 1 = always the library sort, 2 = the hand-written kernel wherever it can run
+std::atomic<int> g_sort_mode{0};  // dana_set_sort_mode: 0 = measured dispatch, 1 = the sample sort for every row, 2 = the single-workgroup kernel wherever it can run
 
 // one lane per (image, cell k=h*W+w, anchor a); output index i = k*A + a (proposal_layer.py:98-103)
 __global__ void __launch_bounds__(256)
@@ -69,21 +68,6 @@ __device__ __forceinline__ unsigned monotone_bits(float f) {
 __device__ __forceinline__ float from_monotone_bits(unsigned m) {
   return __uint_as_float((m & 0x80000000u) ? (m & 0x7FFFFFFFu) : ~m);
 }
-__global__ void __launch_bounds__(256)
-sort_keys_kernel(const float* __restrict__ scores, unsigned long long* __restrict__ keys, int* __restrict__ vals,
-                 int B, int n, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int b = i / n;
-  keys[i] = ((unsigned long long)(unsigned)(B - 1 - b) << 32) | monotone_bits(scores[i]);
-  vals[i] = i - b * n;
-}
-__global__ void __launch_bounds__(256)
-sort_unkey_kernel(const unsigned long long* __restrict__ keys, float* __restrict__ out, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) out[i] = from_monotone_bits((unsigned)keys[i]);
-}
-
 __global__ void __launch_bounds__(256)
 gather_boxes_kernel(const float4* __restrict__ src, const int* __restrict__ order, int n, int order_stride, int topn,
                     float4* __restrict__ dst) {
@@ -168,9 +152,8 @@ detect_decode_kernel(const float* __restrict__ rois, const float* __restrict__ c
 //      its keys per digit with the same ballot match (no atomics), digit-major / wave-minor scan of the 16 x 256 counts,
 //      scatter to the other LDS buffer; a pass whose keys all share one digit is skipped;
 //   5. the indices (and optionally the scores) go out in order.
-// Same result as a stable descending sort cut at topn (ties in ascending index order) -- rocPRIM's device-wide radix sort
-// of all B x n 64-bit keys takes 8-10 launches. Can run when n <= 40 960 and min(topn, n) <= 12 288; WHERE it runs is
-// decided by measurement (topk_preferred below).
+// Same result as a stable descending sort cut at topn (ties in ascending index order). Can run when n <= 40 960 and
+// min(topn, n) <= 12 288; WHERE it runs is decided by measurement (topk_preferred below).
 constexpr int TK_THREADS = 1024, TK_WAVES = 16, TK_CAP = 12288, TK_MAXR = 40, TK_SEGR = TK_CAP / (TK_WAVES * 64);
 // (the kernel is instantiated for <= 24 and <= 40 register-resident keys per lane: rows of <= 24 576 / <= 40 960 scores)
 struct TopkSmem {
@@ -401,10 +384,250 @@ topk_sort_kernel(const float* __restrict__ scores, int n, int topn, int* __restr
   }
 }
 
-// Measured (tools/topk_bench.py, one MI355X): ONE workgroup per row is all of 4 SIMDs -- 19 us against the library's 27 us for
-// a row of 300 scores (detection post-processing), but 122 vs 102 us for 4 x 21 546 -> 12 000 and 177 vs 87 us for
-// 2 x 37 800 -> 12 000: the ballot matches of ~100 000 (key, pass) pairs serialise on one CU while rocPRIM spreads its passes
-// over the chip. So the hand-written kernel takes rows of <= 4 096 scores and the proposal layer keeps the library sort.
+// ---- multi-workgroup top-k + sort for long rows (round 5): a sample sort over the whole chip --------------------------------
+// The single-workgroup kernel above is four SIMDs: 122 us on the proposal layer's rows (4 x 21 546 -> 12 000), where a
+// device-wide library radix sort (rocPRIM, rounds 1-4: 8-10 launches) took 88 us. This one spreads ONE row over many CUs in
+// four short launches (45 us) and is the only sort of rows longer than 4 096 scores -- no library is linked:
+//   composite key  c = (~monotone(score)) << 32 | index   -- unique, and ascending c = descending score, ties in ascending
+//                                                            index order (the stable descending sort's order)
+//   1. ss_sample_kernel    (B workgroups)       1 024 (2 048) evenly spaced keys of the row, bitonic-sorted in registers ->
+//                                               every 8th is a splitter: NB = 128 (256 for rows of more than 32 768 scores) buckets of
+//                                               ~n / NB keys, +-25 % (unique keys: ties cannot pile up in one bucket; the
+//                                               bucket sort below is quadratic in the bucket size, so balance is speed)
+//   2. ss_classify_kernel  (G x B workgroups)   1 024 keys per workgroup (more for rows beyond 65 536 scores, so that the G x NB
+//                                               counters below fit LDS): bucket by binary search over the splitters (LDS),
+//                                               per-workgroup bucket histogram -> global
+//   3. ss_scatter_kernel   (G x B)              bucket bases from the histograms (every workgroup sums them itself: G x 128
+//                                               counters), keys scattered to their bucket's range; buckets that start at or
+//                                               behind rank topn are dropped
+//   4. ss_bucket_kernel    (128 x B)            each surviving bucket ranked by counting in LDS (unique keys -> a total order:
+//                                               the scatter's atomic order inside a bucket does not matter) and written out:
+//                                               order[start + rank], optionally the score
+// Buckets larger than SS_CAP keys (rows of more than ~400 000 scores, which this model never produces: its longest row is
+// 50 400) are ranked straight from global memory -- correct, slow.
+constexpr int SS_NBMAX = 256, SS_CHUNK = 1024, SS_CAP = 2048, SS_HMAX = 16384;  // (G * NB <= SS_HMAX histogram counters)
+__host__ __device__ inline int ss_nb(int n) { return n > 32768 ? 256 : 128; }
+// keys per classify / scatter workgroup: SS_CHUNK, or the multiple of it that keeps G * NB <= SS_HMAX
+inline int ss_chunk(int n) {
+  const int gmax = SS_HMAX / ss_nb(n);
+  return SS_CHUNK * (int)(((long)n + (long)SS_CHUNK * gmax - 1) / ((long)SS_CHUNK * gmax));
+}
+__device__ __forceinline__ unsigned long long ss_key(float score, int index) {
+  return ((unsigned long long)(~monotone_bits(score)) << 32) | (unsigned)index;
+}
+
+// how many of the n8 (a multiple of 8; padded with ~0) keys at `k` are smaller than c: eight broadcast keys per trip, the four
+// 16-byte LDS reads of a trip independent of each other (one read per trip behind its own wait was 20 us per launch)
+__device__ __forceinline__ unsigned ss_count_less(const unsigned long long* k, unsigned n8, unsigned long long c) {
+  unsigned cnt = 0;
+  for (unsigned j = 0; j < n8; j += 8) {
+    const ulonglong2 a = *(const ulonglong2*)&k[j], b = *(const ulonglong2*)&k[j + 2];
+    const ulonglong2 d = *(const ulonglong2*)&k[j + 4], e = *(const ulonglong2*)&k[j + 6];
+    cnt += (a.x < c ? 1u : 0u) + (a.y < c ? 1u : 0u) + (b.x < c ? 1u : 0u) + (b.y < c ? 1u : 0u) + (d.x < c ? 1u : 0u) +
+           (d.y < c ? 1u : 0u) + (e.x < c ? 1u : 0u) + (e.y < c ? 1u : 0u);
+  }
+  return cnt;
+}
+
+template <int S_>
+__global__ void __launch_bounds__(S_ / 2)
+ss_sample_kernel(const float* __restrict__ scores, int n, int NB, unsigned long long* __restrict__ splitters) {
+  __shared__ __attribute__((aligned(16))) unsigned long long smp[S_];
+  const int b = blockIdx.x, t = threadIdx.x, e0 = 2 * t;
+  // bitonic sort, ascending, with the keys in REGISTERS: lane t holds elements 2t and 2t + 1. A compare-exchange at distance
+  // j = 1 is between the lane's own two keys, at 2 <= j <= 64 between this lane and lane t ^ (j / 2) of the same wave (a
+  // shuffle per key), and only the steps with j >= 128 (10 of 66 at S = 2 048) cross waves and go through LDS (one 16-byte
+  // write and one 16-byte read per lane). The launch is VALU-bound on its ONE CU -- 66 steps x 16 waves x ~30 instructions --
+  // so the step's form (this, or every step through LDS) moved it by < 1 us and the sample count is what sets its time.
+  const int ia = (int)((long)e0 * n / S_), ib = (int)((long)(e0 + 1) * n / S_);
+  unsigned long long x = ss_key(scores[(long)b * n + ia], ia), y = ss_key(scores[(long)b * n + ib], ib);
+  for (int k = 2; k <= S_; k <<= 1) {
+    const bool up = (e0 & k) == 0;  // (bit k of 2t + 1 is the same: k >= 2)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j == 1) {
+        const unsigned long long lo = x < y ? x : y, hi = x < y ? y : x;
+        x = up ? lo : hi;
+        y = up ? hi : lo;
+        continue;
+      }
+      unsigned long long px, py;
+      if (j <= 64) {
+        px = __shfl_xor(x, j >> 1);
+        py = __shfl_xor(y, j >> 1);
+      } else {
+        *(ulonglong2*)&smp[e0] = make_ulonglong2(x, y);
+        __syncthreads();
+        const ulonglong2 pr = *(const ulonglong2*)&smp[e0 ^ j];
+        px = pr.x;
+        py = pr.y;
+        __syncthreads();
+      }
+      const bool keep_min = ((e0 & j) == 0) == up;
+      x = (px < x) == keep_min ? px : x;
+      y = (py < y) == keep_min ? py : y;
+    }
+  }
+  *(ulonglong2*)&smp[e0] = make_ulonglong2(x, y);
+  __syncthreads();
+  if (t < NB - 1) splitters[(long)b * SS_NBMAX + t] = smp[(t + 1) * (S_ / NB)];
+}
+
+__device__ __forceinline__ int ss_bucket(const unsigned long long* sp, int NB, unsigned long long c) {
+  // number of splitters <= c (sp[NB - 1 ..] hold ~0)
+  int lo = 0;
+#pragma unroll
+  for (int step = SS_NBMAX / 2; step > 0; step >>= 1)
+    if (lo + step <= NB - 1 && sp[lo + step - 1] <= c) lo += step;
+  return lo;
+}
+
+__global__ void __launch_bounds__(256)
+ss_classify_kernel(const float* __restrict__ scores, int n, int NB, int chunk, const unsigned long long* __restrict__ splitters,
+                   unsigned* __restrict__ hist) {
+  __shared__ unsigned long long sp[SS_NBMAX];
+  __shared__ unsigned cnt[SS_NBMAX];
+  const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
+  sp[t] = t < NB - 1 ? splitters[(long)b * SS_NBMAX + t] : ~0ull;
+  cnt[t] = 0;
+  __syncthreads();
+  for (int k = 0; k < chunk / 256; ++k) {
+    const int i = g * chunk + k * 256 + t;
+    if (i < n) atomicAdd(&cnt[ss_bucket(sp, NB, ss_key(scores[(long)b * n + i], i))], 1u);
+  }
+  __syncthreads();
+  if (t < NB) hist[((long)b * gridDim.x + g) * NB + t] = cnt[t];
+}
+
+__global__ void __launch_bounds__(256)
+ss_scatter_kernel(const float* __restrict__ scores, int n, int topn, int NB, int chunk, const unsigned long long* __restrict__ splitters,
+                  const unsigned* __restrict__ hist, unsigned* __restrict__ bucket_start,
+                  unsigned long long* __restrict__ bucketed) {
+  __shared__ unsigned long long sp[SS_NBMAX];
+  __shared__ unsigned base[SS_NBMAX], tot[SS_NBMAX], scan[SS_NBMAX], hs[SS_HMAX];
+  const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
+  // every workgroup sums the G x NB counters itself: one coalesced sweep into LDS (independent loads: one round trip)
+  for (int i = t; i < G * NB; i += 256) hs[i] = hist[(long)b * G * NB + i];
+  sp[t] = t < NB - 1 ? splitters[(long)b * SS_NBMAX + t] : ~0ull;
+  __syncthreads();
+  {
+    unsigned before = 0, total = 0;
+    if (t < NB)
+      for (int gg = 0; gg < G; ++gg) {
+        const unsigned h = hs[gg * NB + t];
+        before += gg < g ? h : 0u;
+        total += h;
+      }
+    base[t] = before;
+    tot[t] = total;
+  }
+  __syncthreads();
+  if (t < 64) {  // exclusive scan over the (up to 256) bucket totals: four per lane, one wave
+    const unsigned a0 = tot[4 * t], a1 = tot[4 * t + 1], a2 = tot[4 * t + 2], a3 = tot[4 * t + 3];
+    const unsigned sum = a0 + a1 + a2 + a3;
+    unsigned incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned v = __shfl_up(incl, o);
+      if (t >= o) incl += v;
+    }
+    const unsigned excl = incl - sum;
+    scan[4 * t] = excl;
+    scan[4 * t + 1] = excl + a0;
+    scan[4 * t + 2] = excl + a0 + a1;
+    scan[4 * t + 3] = excl + a0 + a1 + a2;
+  }
+  __syncthreads();
+  base[t] += scan[t];
+  if (g == 0 && t < NB) {
+    bucket_start[((long)b * SS_NBMAX + t) * 2] = scan[t];
+    bucket_start[((long)b * SS_NBMAX + t) * 2 + 1] = tot[t];
+  }
+  __syncthreads();
+  for (int k = 0; k < chunk / 256; ++k) {
+    const int i = g * chunk + k * 256 + t;
+    if (i < n) {
+      const unsigned long long c = ss_key(scores[(long)b * n + i], i);
+      const int bk = ss_bucket(sp, NB, c);
+      if (scan[bk] < (unsigned)topn) bucketed[(long)b * n + atomicAdd(&base[bk], 1u)] = c;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+ss_bucket_kernel(const unsigned long long* __restrict__ bucketed, int n, int topn, const unsigned* __restrict__ bucket_start,
+                 int* __restrict__ order, int order_stride, float* __restrict__ sorted_scores) {
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[SS_CAP + 8];
+  const int b = blockIdx.y, bk = blockIdx.x, t = threadIdx.x;
+  const unsigned start = bucket_start[((long)b * SS_NBMAX + bk) * 2], size = bucket_start[((long)b * SS_NBMAX + bk) * 2 + 1];
+  if (start >= (unsigned)topn || size == 0) return;
+  const unsigned long long* src = bucketed + (long)b * n + start;
+  const bool in_lds = size <= SS_CAP;
+  const unsigned n8 = (size + 7) & ~7u;
+  if (in_lds) {
+    for (unsigned i = t; i < n8; i += 256) keys[i] = i < size ? src[i] : ~0ull;
+    __syncthreads();
+  }
+  for (unsigned i = t; i < size; i += 256) {
+    const unsigned long long c = in_lds ? keys[i] : src[i];
+    unsigned rank = 0;
+    if (in_lds) {
+      rank = ss_count_less(keys, n8, c);
+    } else {
+      for (unsigned j = 0; j < size; ++j) rank += src[j] < c ? 1u : 0u;
+    }
+    const unsigned pos = start + rank;
+    if (pos < (unsigned)topn) {
+      order[(long)b * order_stride + pos] = (int)(unsigned)c;
+      if (sorted_scores) sorted_scores[(long)b * order_stride + pos] = from_monotone_bits(~(unsigned)(c >> 32));
+    }
+  }
+}
+
+struct SsPlan {
+  size_t splitters, hist, bucket_start, bucketed, total;
+  int G, chunk;
+};
+SsPlan ss_plan(int B, int n) {
+  SsPlan p;
+  p.chunk = ss_chunk(n);
+  p.G = (n + p.chunk - 1) / p.chunk;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += dana_align_up(bytes, 256);
+    return o;
+  };
+  p.splitters = take((size_t)B * SS_NBMAX * 8);
+  p.hist = take((size_t)B * p.G * SS_NBMAX * 4);
+  p.bucket_start = take((size_t)B * SS_NBMAX * 2 * 4);
+  p.bucketed = take((size_t)B * n * 8);
+  p.total = off;
+  return p;
+}
+
+int ss_launch(const float* scores, int B, int n, int topn, int* order, int order_stride, float* sorted_scores, void* workspace,
+              hipStream_t s) {
+  const SsPlan p = ss_plan(B, n);
+  char* ws = (char*)workspace;
+  unsigned long long* splitters = (unsigned long long*)(ws + p.splitters);
+  unsigned* hist = (unsigned*)(ws + p.hist);
+  unsigned* bstart = (unsigned*)(ws + p.bucket_start);
+  unsigned long long* bucketed = (unsigned long long*)(ws + p.bucketed);
+  const int m = topn < n ? topn : n, NB = ss_nb(n);
+  if (NB == 128)  // (measured: 12.5 vs 17 us for the launch; the 128 buckets stay balanced enough at 8 samples per splitter)
+    ss_sample_kernel<1024><<<B, 512, 0, s>>>(scores, n, NB, splitters);
+  else
+    ss_sample_kernel<2048><<<B, 1024, 0, s>>>(scores, n, NB, splitters);
+  ss_classify_kernel<<<dim3(p.G, B), 256, 0, s>>>(scores, n, NB, p.chunk, splitters, hist);
+  ss_scatter_kernel<<<dim3(p.G, B), 256, 0, s>>>(scores, n, m, NB, p.chunk, splitters, hist, bstart, bucketed);
+  ss_bucket_kernel<<<dim3(NB, B), 256, 0, s>>>(bucketed, n, m, bstart, order, order_stride, sorted_scores);
+  return 0;
+}
+
+// Measured (tools/topk_bench.py, one MI355X): ONE workgroup per row is all of 4 SIMDs -- 19 us for a row of 300 scores
+// (detection post-processing; the four launches of the sample sort are 30 us there), but 122 us for 4 x 21 546 -> 12 000 and
+// 177 us for 2 x 37 800 -> 12 000 against the sample sort's 45 us: the ballot matches of ~100 000 (key, pass) pairs serialise
+// on one CU. So the single-workgroup kernel takes rows of <= 4 096 scores and the sample sort every longer row.
 bool topk_preferred(int n, int topn);
 bool topk_supported(int n, int topn) {
   const int m = topn < n ? topn : n;
@@ -430,35 +653,6 @@ int topk_launch(const float* scores, int B, int n, int topn, int* order, int ord
   return 0;
 }
 
-int sort_end_bit(int B) {
-  int bits = 0;
-  while ((1 << bits) < B) ++bits;
-  return 32 + bits;
-}
-
-size_t sort_temp_bytes(int B, int n) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs_desc(nullptr, bytes, (const unsigned long long*)nullptr,
-                                       (unsigned long long*)nullptr, (const int*)nullptr, (int*)nullptr,
-                                       (size_t)B * n, 0, sort_end_bit(B), (hipStream_t)0);
-  return bytes;
-}
-
-struct SortPlan {
-  size_t temp, keys_in, keys_out, vals_in, total;
-};
-SortPlan sort_plan(int B, int n) {
-  SortPlan p;
-  const size_t t = dana_align_up(sort_temp_bytes(B, n), 256);
-  const size_t kb = dana_align_up((size_t)B * n * 8, 256);
-  p.temp = 0;
-  p.keys_in = t;
-  p.keys_out = t + kb;
-  p.vals_in = t + 2 * kb;
-  p.total = t + 2 * kb + dana_align_up((size_t)B * n * 4, 256);
-  return p;
-}
-
 }  // namespace
 
 extern "C" {
@@ -479,58 +673,18 @@ int dana_rpn_decode(const float* cls, long cls_sb, long cls_sc, long cls_sp, int
   return DANA_OK;
 }
 
-size_t dana_sort_desc_workspace_bytes(int B, int n) {
-  if (B <= 0 || n <= 0) return 0;
-  return sort_plan(B, n).total;  // (also for rows the hand-written kernel takes: dana_set_library_sort may switch back)
-}
-
-// the library path: one device-wide stable radix sort over (row, score) keys
-static int sort_desc_library(const float* scores, int B, int n, int* order, float* sorted_scores, void* workspace,
-                             size_t workspace_bytes, dana_stream_t stream) {
-  SortPlan p = sort_plan(B, n);
-  if (!workspace || workspace_bytes < p.total) {
-    dana_set_error("dana_sort_desc: workspace %zu < %zu", workspace_bytes, p.total);
-    return DANA_ERR_WORKSPACE;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  char* ws = (char*)workspace;
-  unsigned long long* keys_in = (unsigned long long*)(ws + p.keys_in);
-  unsigned long long* keys_out = (unsigned long long*)(ws + p.keys_out);
-  int* vals_in = (int*)(ws + p.vals_in);
-  const int total = B * n;
-  sort_keys_kernel<<<dana_ceil_div(total, 256), 256, 0, s>>>(scores, keys_in, vals_in, B, n, total);
-  DANA_CHECK_LAUNCH("dana_sort_desc(keys)");
-  size_t temp = p.keys_in;  // bytes available to rocprim
-  hipError_t e = rocprim::radix_sort_pairs_desc((void*)(ws + p.temp), temp, (const unsigned long long*)keys_in,
-                                                keys_out, (const int*)vals_in, order, (size_t)total, 0,
-                                                sort_end_bit(B), s);
-  if (e != hipSuccess) {
-    dana_set_error("dana_sort_desc: rocprim sort failed: %s", hipGetErrorString(e));
-    return DANA_ERR_HIP;
-  }
-  if (sorted_scores) {
-    sort_unkey_kernel<<<dana_ceil_div(total, 256), 256, 0, s>>>(keys_out, sorted_scores, total);
-    DANA_CHECK_LAUNCH("dana_sort_desc(unkey)");
-  }
-  return DANA_OK;
-}
+size_t dana_sort_desc_workspace_bytes(int B, int n) { return dana_topk_desc_workspace_bytes(B, n, n); }
 
 // Stable descending sort of each row of scores[B][n]; order[B][n] = source index within the row.
 int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_scores, void* workspace,
                    size_t workspace_bytes, dana_stream_t stream) {
   DANA_CHECK_ARG(B >= 0 && n >= 0, "dana_sort_desc: bad shape");
-  if (B == 0 || n == 0) return DANA_OK;
-  DANA_CHECK_ARG(scores && order, "dana_sort_desc: null pointer");
-  if (topk_preferred(n, n)) {  // short rows: the hand-written select + LDS sort, one launch
-    topk_launch(scores, B, n, n, order, n, sorted_scores, (hipStream_t)stream);
-    DANA_CHECK_LAUNCH("dana_sort_desc(topk)");
-    return DANA_OK;
-  }
-  return sort_desc_library(scores, B, n, order, sorted_scores, workspace, workspace_bytes, stream);
+  return dana_topk_desc(scores, B, n, n, order, n, sorted_scores, workspace, workspace_bytes, stream);
 }
 
-int dana_set_library_sort(int on) {
-  g_sort_mode = on;
+int dana_set_sort_mode(int mode) {
+  DANA_CHECK_ARG(mode >= 0 && mode <= 2, "dana_set_sort_mode: mode %d", mode);
+  g_sort_mode = mode;
   return DANA_OK;
 }
 
@@ -539,39 +693,25 @@ int dana_topk_desc(const float* scores, int B, int n, int topn, int* order, int 
   DANA_CHECK_ARG(B >= 0 && n >= 0 && topn >= 0 && order_stride >= (topn < n ? topn : n), "dana_topk_desc: bad shape");
   if (B == 0 || n == 0 || topn == 0) return DANA_OK;
   DANA_CHECK_ARG(scores && order, "dana_topk_desc: null pointer");
-  if (topk_preferred(n, topn)) {
+  if (topk_preferred(n, topn)) {  // short rows: the single-workgroup select + LDS sort, one launch
     topk_launch(scores, B, n, topn, order, order_stride, sorted_scores, (hipStream_t)stream);
     DANA_CHECK_LAUNCH("dana_topk_desc");
     return DANA_OK;
   }
-  // larger problems: the full library sort into the workspace, then the first topn of every row
-  const size_t need = dana_topk_desc_workspace_bytes(B, n, topn);
+  const size_t need = ss_plan(B, n).total;
   if (!workspace || workspace_bytes < need) {
     dana_set_error("dana_topk_desc: workspace %zu < %zu", workspace_bytes, need);
     return DANA_ERR_WORKSPACE;
   }
-  char* ws = (char*)workspace;
-  const size_t ob = dana_align_up((size_t)B * n * 4, 256);
-  int* full = (int*)ws;
-  float* fulls = (float*)(ws + ob);
-  const int rc = sort_desc_library(scores, B, n, full, sorted_scores ? fulls : nullptr, ws + 2 * ob, workspace_bytes - 2 * ob, stream);
-  if (rc) return rc;
-  const int m = topn < n ? topn : n;
-  for (int b = 0; b < B; ++b) {
-    if (hipMemcpyAsync(order + (long)b * order_stride, full + (long)b * n, (size_t)m * 4, hipMemcpyDeviceToDevice,
-                       (hipStream_t)stream) != hipSuccess ||
-        (sorted_scores && hipMemcpyAsync(sorted_scores + (long)b * order_stride, fulls + (long)b * n, (size_t)m * 4,
-                                         hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)) {
-      dana_set_error("dana_topk_desc: copy failed");
-      return DANA_ERR_HIP;
-    }
-  }
+  // long rows: the multi-workgroup sample sort, four launches
+  ss_launch(scores, B, n, topn, order, order_stride, sorted_scores, workspace, (hipStream_t)stream);
+  DANA_CHECK_LAUNCH("dana_topk_desc(sample sort)");
   return DANA_OK;
 }
 
 size_t dana_topk_desc_workspace_bytes(int B, int n, int topn) {
-  if (B <= 0 || n <= 0 || topn <= 0 || (topk_supported(n, topn) && g_sort_mode == 2)) return 0;
-  return 2 * dana_align_up((size_t)B * n * 4, 256) + sort_plan(B, n).total;
+  if (B <= 0 || n <= 0 || topn <= 0) return 0;
+  return ss_plan(B, n).total;  // (also for rows the single-workgroup kernel takes: dana_set_sort_mode may switch)
 }
 
 int dana_gather_boxes(const float* src, const int* order, int B, int n, int order_stride, int topn, float* dst,
@@ -620,7 +760,7 @@ static ProposalPlan proposal_plan(int B, int n, int pre_nms_topn, int post_nms_t
   int mk = (post_nms_topn > 0 && post_nms_topn < p.topn) ? post_nms_topn : p.topn;
   p.keep = take((size_t)B * mk * 4);
   p.num_keep = take((size_t)B * 4);
-  p.sort_ws = take(dana_sort_desc_workspace_bytes(B, n));
+  p.sort_ws = take(dana_topk_desc_workspace_bytes(B, n, p.topn));
   p.nms_ws = take(dana_nms_workspace_bytes(p.topn, B));
   p.total = o;
   return p;
@@ -655,13 +795,10 @@ int dana_proposal_layer(const float* cls, long cls_sb, long cls_sc, long cls_sp,
   int rc = dana_rpn_decode(cls, cls_sb, cls_sc, cls_sp, cls_is_prob, bbox, bbox_sb, bbox_sc, bbox_sp, im_info,
                            base_anchors, B, A, H, W, feat_stride, proposals, scores, stream);
   if (rc) return rc;
-  if (topk_preferred(n, p.topn)) {
-    topk_launch(scores, B, n, p.topn, order, n, nullptr, (hipStream_t)stream);
-    DANA_CHECK_LAUNCH("dana_proposal_layer(topk)");
-  } else {
-    rc = dana_sort_desc(scores, B, n, order, nullptr, ws + p.sort_ws, p.nms_ws - p.sort_ws, stream);
-    if (rc) return rc;
-  }
+  // the first pre_nms_topN of every image's descending score order (proposal_layer.py:135-150): the single-workgroup
+  // select + sort for short rows, the multi-workgroup sample sort for the real ones (dana_topk_desc)
+  rc = dana_topk_desc(scores, B, n, p.topn, order, n, nullptr, ws + p.sort_ws, p.nms_ws - p.sort_ws, stream);
+  if (rc) return rc;
   rc = dana_gather_boxes(proposals, order, B, n, n, p.topn, sorted_boxes, stream);
   if (rc) return rc;
   rc = dana_nms(sorted_boxes, p.topn, B, nms_thresh, nms_inclusive, mk, keep, mk, num_keep, ws + p.nms_ws,

@@ -115,23 +115,25 @@ int dana_rpn_decode(const float* cls, long cls_sb, long cls_sc, long cls_sp, int
                     int B, int A, int H, int W, int feat_stride, float* proposals, float* scores,
                     dana_stream_t stream);
 
-/* torch.sort(scores, 1, True) (proposal_layer.py:135): stable, per row. sorted_scores may be NULL. */
+/* torch.sort(scores, 1, True) (proposal_layer.py:135): stable, per row. sorted_scores may be NULL. (= dana_topk_desc with
+ * topn = n) */
 size_t dana_sort_desc_workspace_bytes(int B, int n);
 int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_scores, void* workspace,
                    size_t workspace_bytes, dana_stream_t stream);
 /* proposal_layer.py:135-150 as one operation: order[b][0..min(topn, n)) = the indices of row b's `topn` largest scores in
  * descending score order, equal scores in ascending index order -- the first topn entries of torch.sort(scores, 1, True)
- * (row stride of order / sorted_scores: order_stride >= min(topn, n); sorted_scores may be NULL). A hand-written kernel
- * exists for n <= 40 960 and min(topn, n) <= 12 288 (radix select in registers + stable LDS radix sort, one workgroup per
- * row, one launch); it is FASTER than the library sort for short rows only (measured: 19 vs 27 us at n = 300, 122 vs 102 us
- * at 4 x 21 546 -> 12 000), so rows of <= 4 096 scores take it -- here and in dana_sort_desc -- and longer rows go through
- * dana_sort_desc's library sort in `workspace` (dana_topk_desc_workspace_bytes). */
+ * (row stride of order / sorted_scores: order_stride >= min(topn, n); sorted_scores may be NULL). Two hand-written sorts, no
+ * library: rows of <= 4 096 scores take ONE workgroup per row (radix select in registers + stable LDS radix sort, one
+ * launch: 19 us at n = 300); longer rows a sample sort over the whole chip (splitters from 2 048 sampled keys, classify,
+ * scatter, per-bucket rank: four launches, `workspace` of dana_topk_desc_workspace_bytes; 4 x 21 546 -> 12 000 in 45 us
+ * where the single-workgroup kernel takes 122 us and rocPRIM's device-wide radix sort, used through round 4, took 88 us). */
 size_t dana_topk_desc_workspace_bytes(int B, int n, int topn);
 int dana_topk_desc(const float* scores, int B, int n, int topn, int* order, int order_stride, float* sorted_scores,
                    void* workspace, size_t workspace_bytes, dana_stream_t stream);
-/* test / A-B aid: 0 = the measured dispatch above (default), 1 = every sort of this library through rocPRIM's device-wide
- * radix sort, 2 = the hand-written kernel wherever it can run. A process-wide configuration call like dana_set_mfma_mode. */
-int dana_set_library_sort(int on);
+/* test / A-B aid: 0 = the measured dispatch above (default), 1 = the sample sort for every row, 2 = the single-workgroup
+ * kernel wherever it can run (n <= 40 960, min(topn, n) <= 12 288). A process-wide configuration call like
+ * dana_set_mfma_mode. */
+int dana_set_sort_mode(int mode);
 
 /* proposals_single[order_single[:topn]] (proposal_layer.py:148-151) */
 int dana_gather_boxes(const float* src, const int* order, int B, int n, int order_stride, int topn, float* dst,

@@ -328,11 +328,13 @@ def test_sort_desc_stable(dev):
 
 
 @pytest.mark.parametrize("n,topn", [(21546, 12000), (21546, 6000), (37800, 12000), (2394, 12000), (12288, 12288),
-                                    (40960, 300), (1, 5), (65, 64), (28728, 12000), (50000, 12000)])
+                                    (40960, 300), (1, 5), (65, 64), (28728, 12000), (50000, 12000), (4097, 4097), (100000, 2000),
+                                    (6000, 10)])
 def test_topk_desc_is_the_head_of_the_stable_sort(dev, n, topn):
-    """round 4: the hand-written select + LDS radix sort (proposal_layer.py:135-150 as one launch) against numpy's stable
-    sort: random scores, heavy ties (the cut falls INSIDE a run of equal scores), negative / zero / denormal values, and
-    bit-identity with the library sort it replaced"""
+    """the hand-written top-k sorts (proposal_layer.py:135-150) against numpy's stable sort: the single-workgroup select +
+    LDS radix sort (mode 2: wherever it can run), the multi-workgroup sample sort (mode 1: every row, also the short ones) and
+    the measured dispatch: random scores, heavy ties (the cut falls INSIDE a run of equal scores), negative / zero / denormal
+    values"""
     ops = _ops()
     from dana_amd._lib import lib
     rng = np.random.default_rng(n + topn)
@@ -343,27 +345,32 @@ def test_topk_desc_is_the_head_of_the_stable_sort(dev, n, topn):
     s[2, 1::7] = -0.0
     s[2, 5::11] = 1e-42                    # denormal
     m = min(topn, n)
-    lib().call("dana_set_library_sort", 2)  # the hand-written kernel wherever it can run (n = 50 000: the library path)
-    try:
-        order, ss = ops.topk_desc(torch.from_numpy(s).to(dev), topn)
-        torch.cuda.synchronize()
-    finally:
-        lib().call("dana_set_library_sort", 0)
-    # -0.0 sorts behind +0.0 (the key is the bit pattern, like the library sort's): compare through the same total order
+    # -0.0 sorts behind +0.0 (the key is the bit pattern): compare through the same total order
     bits = s.view(np.uint32).astype(np.int64)
     key = np.where(bits & 0x80000000, (~bits) & 0xFFFFFFFF, bits | 0x80000000)
     ref = np.argsort(-key, axis=1, kind="stable")[:, :m]
-    assert np.array_equal(order.cpu().numpy(), ref)
-    assert np.array_equal(ss.cpu().numpy().view(np.uint32), np.take_along_axis(s, ref, 1).view(np.uint32))
-    lib().call("dana_set_library_sort", 1)
-    try:
-        order_l, ss_l = ops.topk_desc(torch.from_numpy(s).to(dev), topn)
-        torch.cuda.synchronize()
-    finally:
-        lib().call("dana_set_library_sort", 0)
-    assert torch.equal(order, order_l) and torch.equal(ss, ss_l)
-    order_d, ss_d = ops.topk_desc(torch.from_numpy(s).to(dev), topn)  # ... and the measured dispatch
-    assert torch.equal(order, order_d) and torch.equal(ss, ss_d)
+    for mode in (2, 1, 0):
+        lib().call("dana_set_sort_mode", mode)
+        try:
+            order, ss = ops.topk_desc(torch.from_numpy(s).to(dev), topn)
+            torch.cuda.synchronize()
+        finally:
+            lib().call("dana_set_sort_mode", 0)
+        assert np.array_equal(order.cpu().numpy(), ref), mode
+        assert np.array_equal(ss.cpu().numpy().view(np.uint32), np.take_along_axis(s, ref, 1).view(np.uint32)), mode
+
+
+def test_sample_sort_on_rows_beyond_its_tuned_sizes(dev):
+    """rows longer than 65 536 scores (more keys per classify workgroup) and a row whose buckets exceed the LDS bucket sort
+    (ranked from global memory): correct, not fast"""
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    for n, topn in ((200000, 3000), (600000, 600000)):
+        s = rng.uniform(-1.0, 1.0, size=(1, n)).astype(np.float32)
+        order, ss = ops.topk_desc(torch.from_numpy(s).to(dev), topn)
+        ref = np.argsort(-s, axis=1, kind="stable")[:, :min(n, topn)]
+        assert np.array_equal(order.cpu().numpy(), ref)
+        assert np.array_equal(ss.cpu().numpy(), np.take_along_axis(s, ref, 1))
 
 
 def test_decode_clip_golden(G, dev):
