@@ -626,12 +626,28 @@ def main():
             ops.PROFILE = []
             model._single_stream = True
             torch.cuda.synchronize()
+            bounds = [0]
             for _ in range(args.steps):
                 eager_step()
+                bounds.append(len(ops.PROFILE))
             torch.cuda.synchronize()
             model._single_stream = bool(args.single_stream)
             prof, ops.PROFILE = ops.PROFILE, None
+            contraction_pass.bounds = bounds
             return prof
+
+        def launch_table(rows, bounds):
+            """(index in the step, tag) -> [flops, mean ms, executed flops] over the steps with the usual launch count (a step
+            that rebuilds a cached operand has one launch more and would shift every index behind it)"""
+            counts = [b - a for a, b in zip(bounds, bounds[1:])]
+            usual = max(set(counts), key=counts.count)
+            steps_ = [(a, b) for a, b in zip(bounds, bounds[1:]) if b - a == usual]
+            per = {}
+            for a, b in steps_:
+                for i, row in enumerate(rows[a:b]):
+                    e = per.setdefault((i, row[0]), [row[1], 0.0, row[5]])
+                    e[1] += row[2].elapsed_time(row[3]) / len(steps_)
+            return per
 
         def family(rows):
             f = sum(r[1] for r in rows)
@@ -641,6 +657,7 @@ def main():
 
         split = ops.get_mfma_mode() != 0
         prof = contraction_pass()
+        prof_bounds = contraction_pass.bounds
         flops, executed, secs = family(prof)
         ms = secs * 1e3
         launches = len(prof) // args.steps
@@ -696,10 +713,7 @@ def main():
             result["roofline"]["mfma_issued_frac_of_bf16_peak"] = round(6.0 * executed / secs / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
             result["roofline"]["vs_f32_mfma_peak"] = round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)
         if args.dump_launches:
-            per = {}
-            for i, row in enumerate(prof):
-                a = per.setdefault((i % launches, row[0]), [row[1], 0.0, row[5]])
-                a[1] += row[2].elapsed_time(row[3]) / args.steps
+            per = launch_table(prof, prof_bounds)
             with open(args.dump_launches, "w") as fh:
                 for (i, tag), (f, t, x) in sorted(per.items()):
                     fh.write("%3d %-40s %9.2f GF %9.1f us %7.2f TF/s (executed %7.2f)\n" % (
