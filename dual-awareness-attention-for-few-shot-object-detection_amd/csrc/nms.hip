@@ -13,11 +13,12 @@
 //                            ballot per round, K <- ballot(alive_j && (col_j & K) == 0). Suppression only points
 //                            from earlier to later boxes, so the rounds settle the boxes in order of their
 //                            dependency depth and the fixed point IS the greedy result (typically 3-8 rounds of
-//                            ~40 cycles, where the scalar chain cost ~165 cycles per kept box). The previous
-//                            block's kept boxes enter the same way through the transposed super-diagonal tile.
-//                            Waves 1..15 (the workers) OR the kept rows of block b-1 into the LDS-resident `remv`
-//                            for every later block, one iteration behind, with unconditional coalesced loads.
-//                            One barrier per block; nothing on the resolver's critical path waits for HBM.
+//                            ~40 cycles, where the scalar chain cost ~165 cycles per kept box). The kept
+//                            boxes of the last TWO blocks enter the same way through the transposed tiles of the first
+//                            and second super-diagonal. Waves 1..15 (the workers) OR the kept rows of block b-1 into the
+//                            LDS-resident `remv` for the blocks from b+2 on, two iterations behind: the loads issued in
+//                            one iteration stay in flight across the barrier (which waits for LDS only) and are OR-ed in
+//                            the next. One barrier per block; no L2 round trip inside an iteration.
 // Column bands when the caller keeps at most `max_keep` boxes (the RPN's post_nms_topN): greedy NMS stops after max_keep
 // keeps, which on score-sorted proposals happens long before the last box, and the scan only ever reads mask words
 // of rows it has visited. Band 0 fills and scans the triangle of the first ~2.5 * max_keep boxes; every later band
@@ -67,6 +68,8 @@ struct NmsPass {
   int kept_rows_hi;                      // row blocks < this were scanned in pass 1
   unsigned long long* diag_t;            // [problem][n]: bits of the EARLIER boxes of box j's block that suppress j
   unsigned long long* prev_t;            // [problem][n]: bits of the boxes of the PREVIOUS block that suppress j
+  unsigned long long* prev2_t;           // [problem][n]: ... of the block before that
+  unsigned long long* prev3_t;           // [problem][n]: ... and of the one before that
 };
 
 // grid = (ceil((cb_hi - cb_lo)/4), cb_hi, problems); wave w of the workgroup owns tile (rb, cb_lo + cg*4 + w)
@@ -79,7 +82,7 @@ nms_mask_kernel(const float4* __restrict__ boxes, unsigned long long* __restrict
   const int rb = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cb = ps.cb_lo + blockIdx.x * 4 + wave;
-  if (cb < rb || cb >= ps.cb_hi) return;  // wave-uniform: whole waves leave, no barrier below
+  if (cb + 3 < rb || cb >= ps.cb_hi) return;  // wave-uniform: whole waves leave, no barrier below
   const float4* pb = boxes + (long)blockIdx.z * n;
   unsigned long long* pm = mask + (long)blockIdx.z * n * col_blocks;
   const int row = rb * 64 + lane;
@@ -90,6 +93,17 @@ nms_mask_kernel(const float4* __restrict__ boxes, unsigned long long* __restrict
   colbox[wave][lane] = cbx;
   colarea[wave][lane] = box_area(cbx);
   __builtin_amdgcn_wave_barrier();
+  if (cb < rb) {
+    // One of the three tiles left of the diagonal: not a mask tile (the lower triangle is never read) but the TRANSPOSED
+    // tile of super-diagonal rb - cb -- bit i of box j's word = box i of the earlier block cb suppresses box j (the test is
+    // symmetric bit for bit: max / min / the commutative sa + sb). These waves would leave at once otherwise.
+    unsigned long long w = 0;
+    for (int i = 0; i < 64; ++i)  // (an earlier block is always full)
+      if (iou_suppress(me, sme, colbox[wave][i], colarea[wave][i], thr, inclusive)) w |= 1ULL << i;
+    unsigned long long* dst = rb - cb == 1 ? ps.prev_t : (rb - cb == 2 ? ps.prev2_t : ps.prev3_t);
+    if (row < n) dst[(long)blockIdx.z * n + row] = w;
+    return;
+  }
   const int csize = min(64, n - cb * 64);
   unsigned long long t = 0;
   if (cb != rb) {
@@ -98,23 +112,28 @@ nms_mask_kernel(const float4* __restrict__ boxes, unsigned long long* __restrict
   } else {
     // Diagonal tile: the test is symmetric bit for bit (max / min / the commutative sa + sb), so the same sweep over
     // ALL boxes of the block gives the row word (later boxes this one suppresses) and its transpose (earlier boxes
-    // that suppress this one); a second sweep over the previous block gives the transposed super-diagonal tile.
+    // that suppress this one); three more sweeps, over the three blocks before this one, give the transposed tiles of
+    // the first three super-diagonals.
     for (int i = 0; i < csize; ++i)
       if (i != lane && iou_suppress(me, sme, colbox[wave][i], colarea[wave][i], thr, inclusive)) t |= 1ULL << i;
     const unsigned long long below = (1ULL << lane) - 1;
-    unsigned long long pv = 0;
-    if (rb > 0) {
-      __builtin_amdgcn_wave_barrier();
-      const float4 pbx = pb[(rb - 1) * 64 + lane];  // the previous block is always full
-      colbox[wave][lane] = pbx;
-      colarea[wave][lane] = box_area(pbx);
-      __builtin_amdgcn_wave_barrier();
-      for (int i = 0; i < 64; ++i)
-        if (iou_suppress(me, sme, colbox[wave][i], colarea[wave][i], thr, inclusive)) pv |= 1ULL << i;
-    }
-    if (row < n) {
-      ps.diag_t[(long)blockIdx.z * n + row] = t & below;
-      ps.prev_t[(long)blockIdx.z * n + row] = pv;
+    if (row < n) ps.diag_t[(long)blockIdx.z * n + row] = t & below;
+    // the transposed super-diagonal tiles whose column block lies left of this band (no wave of this grid has them; a
+    // band's first three diagonal blocks) -- and the zero words of the blocks that have no such earlier block
+    for (int back = 1; back <= 3; ++back) {
+      if (rb - back >= ps.cb_lo) continue;
+      unsigned long long w = 0;
+      if (rb - back >= 0) {
+        __builtin_amdgcn_wave_barrier();
+        const float4 pbx = pb[(rb - back) * 64 + lane];
+        colbox[wave][lane] = pbx;
+        colarea[wave][lane] = box_area(pbx);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < 64; ++i)
+          if (iou_suppress(me, sme, colbox[wave][i], colarea[wave][i], thr, inclusive)) w |= 1ULL << i;
+      }
+      unsigned long long* dst = back == 1 ? ps.prev_t : (back == 2 ? ps.prev2_t : ps.prev3_t);
+      if (row < n) dst[(long)blockIdx.z * n + row] = w;
     }
     t &= ~below;
   }
@@ -259,6 +278,201 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int col_bloc
   }
 }
 
+// ---- the scan for bands of <= 128 column blocks (every band of the proposal layer's problems): a dataflow of waves with no
+// workgroup barrier and no memory round trip on the resolver's path. Measured on the kernel above: 1.27 us per block = one
+// round trip to the words the mask kernel just wrote (another XCD's L2 / the memory-side cache), paid by the resolver (its
+// prefetch of block b+1 is waited for at the end of the iteration: a register copy across the loop edge needs the data) and
+// by the workers (kept rows of block b-1, loaded and OR-ed inside one iteration). Holding loads in registers ACROSS
+// iterations does not help: the compiler's wait-count pass is conservative for loads that are live across a loop edge
+// (vmcnt(0..3) where 12-24 younger loads are in flight) -- so here no load is live across an iteration of its wave:
+//   wave 0        resolver: block after block, words from an LDS ring, K published to LDS, keep list stored directly;
+//                 waits (LDS flags) only for its words and for "rows of block b-4 folded"
+//   waves 1-2     word loaders: the transposed diagonal / first three super-diagonal words of 4 blocks per turn -> LDS ring
+//                 of 16 blocks, up to 12 blocks ahead of the resolver
+//   waves 3-14    row workers, 4 groups x 3 waves, block b -> group b % 4: load ALL 64 rows' words for the column blocks
+//                 >= b+4 (before the resolver gets there: nothing to wait for), then wait for K_b, OR the kept rows into
+//                 remv, count the block as folded. The resolver reaches the kept boxes of the last three blocks through the
+//                 transposed super-diagonal tiles; a group has four resolver steps per block (one memory round trip + the fold).
+// LDS: remv[col_blocks] | ring[16][4][64] | kw[128] | folded[128] | wflag[4] | count, done, resolved, stop
+constexpr int NMS_FLOW_MAX_BLOCKS = 128, NMS_FLOW_RING = 16;
+constexpr int NMS_FLOW_GROUPS = 4, NMS_FLOW_GW = 3, NMS_FLOW_U = 22;  // 4 worker groups x 3 waves x 22 rows each (>= 64;
+                                                                       // 6 x 2 x 32 spills: 128 registers per lane)
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// LDS flags between the waves of one workgroup: relaxed workgroup-scope atomics (re-read on every poll, no fence) -- a
+// `volatile` access makes the compiler wait for ALL outstanding memory operations (vmcnt(0): the resolver's keep-list stores,
+// ~1 500 cycles per block)
+template <typename T> __device__ __forceinline__ T flag_ld(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <typename T> __device__ __forceinline__ void flag_st(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ void __launch_bounds__(1024)
+nms_scan_flow_kernel(const unsigned long long* __restrict__ mask, int n, int col_blocks, int max_keep,
+                     int* __restrict__ keep, int* __restrict__ num_keep, int keep_stride, int b_lo, int b_hi,
+                     int* __restrict__ state, unsigned long long* __restrict__ keptmask,
+                     unsigned long long* __restrict__ remv_g, const unsigned long long* __restrict__ diag_t,
+                     const unsigned long long* __restrict__ prev_t, const unsigned long long* __restrict__ prev2_t,
+                     const unsigned long long* __restrict__ prev3_t) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];
+  unsigned long long* ring = remv + col_blocks;                          // [16 blocks][4 tables][64 lanes]
+  unsigned long long* kw = ring + NMS_FLOW_RING * 4 * 64;       // [128] kept boxes of block b_lo + i
+  int* folded = (int*)(kw + NMS_FLOW_MAX_BLOCKS);      // [128] worker waves done with block b_lo + i
+  int* wflag = folded + NMS_FLOW_MAX_BLOCKS;                    // [4] chunk index + 1 held by ring quarter i
+  int* s_count = wflag + 4;
+  int* s_done = wflag + 5;
+  int* s_res = wflag + 6;   // blocks resolved so far (relative to b_lo)
+  int* s_stop = wflag + 7;
+  const unsigned long long* pm = mask + (long)blockIdx.x * n * col_blocks;
+  int* pk = keep + (long)blockIdx.x * keep_stride;
+  int* st = state ? state + 2 * blockIdx.x : nullptr;
+  unsigned long long* km = keptmask ? keptmask + (long)blockIdx.x * col_blocks : nullptr;
+  unsigned long long* rg = remv_g ? remv_g + (long)blockIdx.x * col_blocks : nullptr;
+  if (b_lo > 0 && st[1]) return;  // pass 1 finished the problem (num_keep is already written)
+  for (int j = threadIdx.x; j < col_blocks; j += blockDim.x) {
+    remv[j] = b_lo > 0 ? rg[j] : 0ULL;
+    if (b_lo == 0 && rg) rg[j] = 0ULL;  // the band's mask tiles OR into it before pass 2 reads it
+  }
+  if (threadIdx.x < NMS_FLOW_MAX_BLOCKS) folded[threadIdx.x] = 0;
+  if (threadIdx.x < 8) wflag[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0 && b_lo > 0) *s_count = st[0];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = b_hi - b_lo;
+  if (wave == 0) {
+    // ---- resolver ----
+    unsigned long long k1 = 0, k2 = 0, k3 = 0;  // kept boxes of blocks b-1 .. b-3 (at the start of a band: already in remv)
+    int base = flag_ld(s_count);                // keeps so far (this wave is the only writer)
+    for (int i = 0; i < nblk; ++i) {
+      const int b = b_lo + i;
+      if ((i & 3) == 0) {  // a new chunk of the ring
+        while (flag_ld(&wflag[(i >> 2) & 3]) != (i >> 2) + 1) __builtin_amdgcn_s_sleep(1);
+        lds_wait();
+      }
+      // one LDS round trip for everything the block needs: its words, the fold counter of block b-4, the folded rows
+      const unsigned long long* w = ring + (i & (NMS_FLOW_RING - 1)) * 256 + lane;
+      const unsigned long long colw = w[0], prvw = w[64], prv2w = w[128], prv3w = w[192];
+      // (the counter is read BEFORE the word -- one wave's LDS reads execute in order -- so a complete count means a
+      //  complete word; late workers: poll the counter, then take the word again)
+      int fold = i >= 4 ? flag_ld(&folded[i - 4]) : NMS_FLOW_GW;
+      unsigned long long rm = flag_ld(&remv[b]);  // rows kept in blocks <= b-4 (and in earlier bands)
+      lds_wait();
+      while (fold < NMS_FLOW_GW) {
+        __builtin_amdgcn_s_sleep(1);
+        fold = flag_ld(&folded[i - 4]);
+        rm = flag_ld(&remv[b]);
+        lds_wait();
+      }
+      rm = uniform64(rm);
+      const int bsize = min(64, n - b * 64);
+      const bool al = lane < bsize && !((rm >> lane) & 1ULL) && (prvw & k1) == 0ULL && (prv2w & k2) == 0ULL &&
+                      (prv3w & k3) == 0ULL;
+      unsigned long long K = __ballot(al);
+      for (;;) {  // fixed point of K = alive & ~suppressed_by(K): the greedy result (see the header)
+        const unsigned long long Kn = __ballot(al && (colw & K) == 0ULL);
+        if (Kn == K) break;
+        K = Kn;
+      }
+      const unsigned long long below = (1ULL << lane) - 1;
+      int c = __builtin_popcountll(K);
+      if (base + c > max_keep) {  // the block that reaches max_keep: its first max_keep - base kept boxes
+        c = max_keep - base;
+        K = __ballot(((K >> lane) & 1ULL) && __builtin_popcountll(K & below) < c);
+      }
+      if ((K >> lane) & 1ULL) pk[base + __builtin_popcountll(K & below)] = b * 64 + lane;
+      base += c;
+      if (lane == 0) {
+        flag_st(&kw[i], K);
+        flag_st(s_res, i + 1);  // (behind kw[i]: one wave's LDS operations execute in order)
+        if (km) km[b] = K;
+      }
+      k3 = k2;
+      k2 = k1;
+      k1 = K;
+      if (base == max_keep) break;
+    }
+    if (lane == 0) {
+      flag_st(s_count, base);
+      if (base == max_keep) flag_st(s_done, 1);
+      flag_st(s_stop, 1);
+    }
+  } else if (wave <= 2) {
+    // ---- word loaders: chunk ci = blocks [4 ci, 4 ci + 4) of the band, chunks alternate between the two waves ----
+    const unsigned long long* tab[4] = {diag_t + (long)blockIdx.x * n, prev_t + (long)blockIdx.x * n,
+                                        prev2_t + (long)blockIdx.x * n, prev3_t + (long)blockIdx.x * n};
+    for (int ci = wave - 1; ci * 4 < nblk; ci += 2) {
+      // the ring quarter is free once the blocks that used it (chunk ci - 4) are resolved
+      while (flag_ld(s_res) < ci * 4 - 12 && !flag_ld(s_stop)) __builtin_amdgcn_s_sleep(1);
+      if (flag_ld(s_stop)) break;
+      unsigned long long v[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r0 = (b_lo + ci * 4 + q) * 64 + lane;
+        const int r = (ci * 4 + q < nblk && r0 < n) ? r0 : 0;  // (row 0's words are zero: no earlier box, no earlier block)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[q][t] = tab[t][r];
+      }
+      unsigned long long* dst = ring + ((ci * 4) & (NMS_FLOW_RING - 1)) * 256 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[q * 256 + t * 64] = v[q][t];
+      lds_wait();
+      if (lane == 0) flag_st(&wflag[ci & 3], ci + 1);
+    }
+  } else if (wave <= 14) {
+    // ---- row workers ----
+    const int grp = (wave - 3) / NMS_FLOW_GW, sub = (wave - 3) % NMS_FLOW_GW;
+    constexpr int U = NMS_FLOW_U;
+    for (int i = grp; i < nblk; i += NMS_FLOW_GROUPS) {
+      const int b = b_lo + i;
+      const int first = b + 4;
+      bool stop = false;
+      for (int g0 = first; g0 < b_hi && !stop; g0 += 64) {  // column groups of 64 blocks (two only at the head of a wide band)
+        const int j = g0 + lane;
+        unsigned long long hv[U];
+        // (32-bit offsets from the uniform base: 64-bit lane addresses for 22 loads do not fit the 128 registers of a
+        //  1024-lane workgroup; the mask of one problem is < 4 GB for every n the LDS-resident scan accepts)
+        // every load is issued whatever the item (a row or column behind the end reads word 0 of the mask and is dropped
+        // at the fold): a load under a condition is waited for at the join behind it -- 22 round trips in a row
+        const unsigned off0 = (unsigned)(b * 64 + sub) * (unsigned)col_blocks + (unsigned)j;
+        const bool colok = j < b_hi;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = sub + NMS_FLOW_GW * u;
+          const bool ok = r < 64 && b * 64 + r < n && colok;
+          hv[u] = pm[ok ? off0 + (unsigned)(NMS_FLOW_GW * u) * (unsigned)col_blocks : 0u];
+        }
+        while (flag_ld(s_res) <= i && !flag_ld(s_stop)) __builtin_amdgcn_s_sleep(1);
+        if (flag_ld(s_res) <= i) {  // the resolver stopped before this block
+          stop = true;
+          break;
+        }
+        lds_wait();
+        const unsigned long long K = flag_ld(&kw[i]);
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (sub + NMS_FLOW_GW * u < 64 && ((K >> ((sub + NMS_FLOW_GW * u) & 63)) & 1ULL)) acc |= hv[u];  // (K has no bit for a row >= n)
+        if (acc && colok) atomicOr(&remv[j], acc);
+      }
+      if (stop) break;
+      lds_wait();
+      if (lane == 0) atomicAdd(&folded[i], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    num_keep[blockIdx.x] = *s_count;
+    if (st) {
+      st[0] = *s_count;
+      st[1] = (*s_done || b_hi >= col_blocks) ? 1 : 0;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -267,9 +481,9 @@ size_t dana_nms_workspace_bytes(int n, int problems) {
   if (n <= 0 || problems <= 0) return 0;
   size_t cb = (size_t)(n + 63) / 64;
   // mask words | kept-row words [problems][cb] | folded column words [problems][cb] | state [problems][2]
-  // ... | transposed diagonal / super-diagonal words [2][problems][n]
+  // ... | transposed diagonal / first three super-diagonal words [4][problems][n]
   return (size_t)problems * n * cb * sizeof(unsigned long long) + (size_t)problems * (2 * cb * 8 + 16) +
-         (size_t)2 * problems * n * sizeof(unsigned long long);
+         (size_t)4 * problems * n * sizeof(unsigned long long);
 }
 
 int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, int max_keep, int* keep,
@@ -296,6 +510,7 @@ int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, 
   }
   const int cb = (n + 63) / 64;
   const size_t lds = (size_t)cb * 8 + 128 * 4 + 16;
+  const size_t flow_lds = (size_t)cb * 8 + NMS_FLOW_RING * 4 * 64 * 8 + NMS_FLOW_MAX_BLOCKS * 12 + 64;
   DANA_CHECK_ARG(lds <= 64 * 1024 && cb <= 65535, "dana_nms: n=%d too large for the LDS-resident scan", n);
   unsigned long long* maskw = (unsigned long long*)workspace;
   unsigned long long* keptmask = maskw + (size_t)problems * n * cb;
@@ -303,6 +518,8 @@ int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, 
   int* state = (int*)(remv_g + (size_t)problems * cb);
   unsigned long long* diag_t = (unsigned long long*)(state + 2 * (size_t)problems + 2 * ((size_t)problems & 1));
   unsigned long long* prev_t = diag_t + (size_t)problems * n;
+  unsigned long long* prev2_t = prev_t + (size_t)problems * n;
+  unsigned long long* prev3_t = prev2_t + (size_t)problems * n;
   // Band edges in units of max_keep boxes x 100: the first pass covers 2.5 x max_keep boxes, the second up to 5 x, the last
   // the rest (measured best on the proposal layer's 12 000 -> 2 000 problems; a single pass is what "0" edges give). An
   // edge that would leave less than a quarter of the problem for the later bands is dropped.
@@ -320,12 +537,17 @@ int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, 
   edge[nb] = cb;
   for (int i = 0; i < nb; ++i) {
     const int lo = edge[i], hi = edge[i + 1];
-    const NmsPass ps = {lo, hi, i ? state : nullptr, i ? keptmask : nullptr, i ? remv_g : nullptr, lo, diag_t, prev_t};
+    const NmsPass ps = {lo, hi, i ? state : nullptr, i ? keptmask : nullptr, i ? remv_g : nullptr, lo, diag_t, prev_t, prev2_t,
+                       prev3_t};
     nms_mask_kernel<<<dim3((hi - lo + 3) / 4, hi, problems), 256, 0, s>>>((const float4*)boxes, maskw, n, cb, thr, inclusive,
                                                                           ps);
     DANA_CHECK_LAUNCH("dana_nms(mask)");
-    nms_scan_kernel<<<problems, 1024, lds, s>>>(maskw, n, cb, max_keep, keep, num_keep, keep_stride, lo, hi, state, keptmask,
-                                                remv_g, diag_t, prev_t);
+    if (hi - lo <= NMS_FLOW_MAX_BLOCKS && flow_lds <= 64 * 1024)
+      nms_scan_flow_kernel<<<problems, 1024, flow_lds, s>>>(maskw, n, cb, max_keep, keep, num_keep, keep_stride, lo, hi, state,
+                                                            keptmask, remv_g, diag_t, prev_t, prev2_t, prev3_t);
+    else  // (a band wider than 128 column blocks: a single-band problem of more than 8 192 boxes)
+      nms_scan_kernel<<<problems, 1024, lds, s>>>(maskw, n, cb, max_keep, keep, num_keep, keep_stride, lo, hi, state, keptmask,
+                                                  remv_g, diag_t, prev_t);
     DANA_CHECK_LAUNCH("dana_nms(scan)");
   }
   return DANA_OK;

@@ -316,6 +316,31 @@ def test_nms_two_pass_hand_off_vs_oracle(dev, clusters, max_keep):
         assert seen == {"full", "short"}  # the case list really covers both outcomes in one launch
 
 
+@pytest.mark.parametrize("kind", ["disjoint", "identical", "chain"])
+def test_nms_dataflow_scan_extremes_and_repeatability(dev, kind):
+    """the barrier-free scan (resolver / word loaders / row workers talking through LDS flags): every box kept (64 rows
+    folded per block), one box suppressing all others (nothing folded), a chain in which every box overlaps only its
+    neighbour (the fixed point needs its full depth) -- 20 runs each must give the oracle's list every time"""
+    ops, orc = _ops(), _oracle()
+    n = 6000  # 94 column blocks: one band, two column groups at its head
+    if kind == "disjoint":
+        gx, gy = np.meshgrid(np.arange(100), np.arange(60))
+        boxes = np.stack([gx.ravel() * 20, gy.ravel() * 20, gx.ravel() * 20 + 9, gy.ravel() * 20 + 9], 1).astype(np.float32)
+    elif kind == "identical":
+        boxes = np.tile(np.array([[10, 10, 200, 150]], np.float32), (n, 1))
+    else:
+        x = np.arange(n, dtype=np.float32) * 3  # IoU of neighbours = 8/14 > 0.5, of second neighbours 5/17 < 0.5
+        boxes = np.stack([x, np.zeros(n, np.float32), x + 10, np.full(n, 10, np.float32)], 1)
+    thr = 0.5
+    ref = orc.nms(boxes, -np.arange(n, dtype=np.float32), thr, inclusive=False)
+    t = torch.from_numpy(boxes).to(dev).view(1, n, 4).repeat(3, 1, 1).contiguous()
+    for _ in range(20):
+        keep, num = ops.nms_sorted(t, thr, False)
+        for q in range(3):
+            assert int(num[q]) == len(ref)
+            assert np.array_equal(keep[q, :len(ref)].cpu().numpy(), ref)
+
+
 def test_sort_desc_stable(dev):
     ops = _ops()
     rng = np.random.default_rng(0)
