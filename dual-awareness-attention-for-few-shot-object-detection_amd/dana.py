@@ -981,7 +981,7 @@ class DAnARCNN(nn.Module):
         if tl is not None:
             tl.append(("enqueued trunk..proposals", _time.perf_counter()))
         rpn_loss_cls = rpn_loss_bbox = 0
-        rois_label = None
+        rois_label = rpn_draws = None
         if training:
             # Proposal targets, first half (proposal_target_layer_cascade.py:113-141), behind the proposal layer
             if side is not main:
@@ -1000,7 +1000,7 @@ class DAnARCNN(nn.Module):
                 drawn = yield dict(stage="draw", anchor_counts=at["counts"], anchor_stream=side,
                                    proposal_counts=pt["counts"], B=B, R=R_t, fg_per=fg_per,
                                    rpn_batchsize=int(tr_.RPN_BATCHSIZE), num_fg=num_fg, total=at["total"], layout=lay)
-                ops.anchor_target_apply_draws(at, drawn, lay)
+                rpn_draws = (drawn, lay)
                 picks_ptr, taken_ptr = drawn.data_ptr() + 4 * lay["picks"], drawn.data_ptr() + 4 * lay["taken"]
             else:
                 host = ops.proposal_target_sample_device(pt, R_t, fg_per, rng[0], rng[1] + 1, counter=ctr)
@@ -1009,11 +1009,8 @@ class DAnARCNN(nn.Module):
                 picks_ptr, taken_ptr = host.data_ptr(), host.data_ptr() + 4 * B * R_t
             if tl is not None:
                 tl.append(("draws (host sync)", _time.perf_counter()))
-            # fused RPN losses (rpn.py:97-115) straight from the head buffer [B*hw][2A | 4A]
-            rpn_l = ops.rpn_losses(heads, nh, at, sigma=3.0, inside_weight=tr_.RPN_BBOX_INSIDE_WEIGHTS[0])
-            rpn_loss_cls, rpn_loss_bbox = rpn_l[0], rpn_l[1]
-            if ctx is not None:
-                ctx.update(rpn_x=x, rpn_heads=heads, nh=nh, at=at, rpn_l=rpn_l)
+            # (the RPN losses are issued BEHIND RoIAlign, below: right behind the host round trip the host has no lead over the
+            #  GPU, so what is issued first starts first -- the sampled batch and RoIAlign are what the RoI stage waits for)
             rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = ops.proposal_target_finish(
                 pt, picks_ptr, taken_ptr, R_t, tr_.BBOX_NORMALIZE_MEANS, tr_.BBOX_NORMALIZE_STDS,
                 tr_.BBOX_INSIDE_WEIGHTS, tr_.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)
@@ -1062,6 +1059,15 @@ class DAnARCNN(nn.Module):
             inter["pooled"] = pooled
         pooled_ready = ops.record_event()
         mark("roi align")
+        if training:
+            # the anchor labels' drawn pairs, then the fused RPN losses (rpn.py:97-115) straight from the head buffer
+            # [B*hw][2A | 4A]: on the caller's stream, which has slack against layer4's chain on its own stream
+            if rpn_draws is not None:
+                ops.anchor_target_apply_draws(at, *rpn_draws)
+            rpn_l = ops.rpn_losses(heads, nh, at, sigma=3.0, inside_weight=tr_.RPN_BBOX_INSIDE_WEIGHTS[0])
+            rpn_loss_cls, rpn_loss_bbox = rpn_l[0], rpn_l[1]
+            if ctx is not None:
+                ctx.update(rpn_x=x, rpn_heads=heads, nh=nh, at=at, rpn_l=rpn_l)
 
         # -- box regression branch: layer4 + mean + Linear (dana.py:246,387-389), shared by the pos/neg heads.
         #    It is independent of the attention head below, so it runs on its own stream (tails overlap). --
