@@ -43,8 +43,8 @@ def test_argument_errors_are_reported_without_a_gpu():
         L.call("dana_gemm_nt", 16, 16, 16, None, None, None, 8, 8, 6, 6, 6, 8, 0, 1, 0, 0, 0, 1.0, 0, None)
     with pytest.raises(_lib.DanaError, match="workspace"):
         L.call("dana_nms", 16, 100, 1, 0.7, 0, 0, 16, 100, 16, None, 0, None)
-    # mask words + kept-row / folded-column words + state + the transposed diagonal / super-diagonal words
-    assert L.query("dana_nms_workspace_bytes", 12000, 4) == 4 * 12000 * 188 * 8 + 4 * (2 * 188 * 8 + 16) + 2 * 4 * 12000 * 8
+    # mask words + kept-row / folded-column words + state + the transposed diagonal / first three super-diagonal words
+    assert L.query("dana_nms_workspace_bytes", 12000, 4) == 4 * 12000 * 188 * 8 + 4 * (2 * 188 * 8 + 16) + 4 * 4 * 12000 * 8
     # empty inputs are a no-op, like the reference (nms.h:17-18, ROIAlign_cuda.cu:278-281)
     L.call("dana_roi_align_forward", None, None, None, 1, 8, 8, 8, 0, 1.0, 7, 7, 0, 0, 0, 0, None, None, 0, None)
 
