@@ -99,7 +99,9 @@ int dana_roi_pool_backward(const float* grad_out, const int* argmax, const float
  * (nms.cu:60); inclusive=1: IoU >= thr (nms_cpu.cpp:60).
  * With max_keep < n the mask is filled and scanned in column bands (the first covers ~2.5 x max_keep boxes; the later
  * ones leave at once when max_keep is reached): the result is the same greedy NMS truncated at max_keep, only the
- * work differs. DANA_NMS_BANDS="a,b" sets the band edges (percent of max_keep), "0" a single pass. */
+ * work differs. A band of <= 128 column blocks (every band of the proposal layer's problems) is scanned by a barrier-free
+ * dataflow of one workgroup's waves -- resolver, word loaders, row workers over LDS flags --, a wider one by the
+ * resolver + workers kernel with one barrier per 64-box block. */
 size_t dana_nms_workspace_bytes(int n, int problems);
 int dana_nms(const float* boxes, int n, int problems, float thr, int inclusive, int max_keep, int* keep,
              int keep_stride, int* num_keep, void* workspace, size_t workspace_bytes, dana_stream_t stream);
