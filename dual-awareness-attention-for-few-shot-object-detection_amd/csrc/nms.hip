@@ -357,11 +357,13 @@ nms_scan_flow_kernel(const unsigned long long* __restrict__ mask, int n, int col
       // (the counter is read BEFORE the word -- one wave's LDS reads execute in order -- so a complete count means a
       //  complete word; late workers: poll the counter, then take the word again)
       int fold = i >= 4 ? flag_ld(&folded[i - 4]) : NMS_FLOW_GW;
+      asm volatile("" ::: "memory");  // (the compiler keeps the order of the two reads; the LDS executes them in order)
       unsigned long long rm = flag_ld(&remv[b]);  // rows kept in blocks <= b-4 (and in earlier bands)
       lds_wait();
       while (fold < NMS_FLOW_GW) {
         __builtin_amdgcn_s_sleep(1);
         fold = flag_ld(&folded[i - 4]);
+        asm volatile("" ::: "memory");
         rm = flag_ld(&remv[b]);
         lds_wait();
       }
@@ -385,6 +387,7 @@ nms_scan_flow_kernel(const unsigned long long* __restrict__ mask, int n, int col
       base += c;
       if (lane == 0) {
         flag_st(&kw[i], K);
+        asm volatile("" ::: "memory");
         flag_st(s_res, i + 1);  // (behind kw[i]: one wave's LDS operations execute in order)
         if (km) km[b] = K;
       }
