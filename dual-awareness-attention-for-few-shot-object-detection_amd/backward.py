@@ -27,9 +27,10 @@ class WeightGrads:
         self.stream = stream
         self.model = model
         self.direct = {}  # key -> packed VIEW of param.grad (trainer layout): weight gradients land there directly
-        # One side stream PER CALLER STREAM (the box branch issues its weight gradients from the layer4 stream, the rest
-        # of the backward from the caller's): every side stream forks from and joins into exactly one parent, and the
-        # two families of launches no longer queue behind each other.
+        # ONE weight-gradient stream for every caller stream (the box branch issues its weight gradients from the layer4
+        # stream, the RPN chain from its own, the rest of the backward from the caller's). Round 4 gave every caller stream
+        # a side stream of its own; measured in round 5 (profiles/r5_role_streams.md): more streams than hardware queues
+        # make unrelated chains share a queue, and a second weight-gradient stream costs the iteration 1.3-1.7 ms.
         self.side = {}    # caller stream handle -> [side stream, operands kept alive while its launches are in flight]
         self.compact = {}  # gathered input rows of strided 1x1 convs (shared by a block's conv1 and downsample conv)
 
@@ -37,11 +38,7 @@ class WeightGrads:
         cur = ops.cur_stream()
         ent = self.side.get(cur.cuda_stream)
         if ent is None:
-            if not self.side or self.model is None:
-                st = self.stream
-            else:
-                st = self.model._stream("wgrad.%d" % len(self.side), cur.device)
-            ent = self.side[cur.cuda_stream] = [st, []]
+            ent = self.side[cur.cuda_stream] = [self.stream, []]
         return ent
 
     def _direct_view(self, key):
@@ -480,11 +477,10 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     ug = model.unary_gamma
 
     # -- the trunk's data-gradient weights (flipped / transposed / BN-scaled copies, Winograd-domain filters: ~45 small
-    #    launches that depend on the weights only) are derived on a stream of their own instead of one by one in front of
-    #    the trunk's data-gradient launches that need them (the chain every other launch of the trunk's backward waits
-    #    for); joined into the caller's stream before the pause below. (Issuing that stream behind the heads' backward
-    #    instead is 0.3 ms faster in a process that only trains and 1.6 ms slower behind other work -- HIP spreads a process's
-    #    streams over four hardware queues in creation order, profiles/r4_graph_handover.md 3: the robust order stays) --
+    #    launches that depend on the weights only) are derived at the head of the weight-gradient stream instead of one by
+    #    one in front of the trunk's data-gradient launches that need them (the chain every other launch of the trunk's
+    #    backward waits for). (Round 4 gave them a stream of their own; which hardware queue that stream landed on decided
+    #    1-2 ms of the iteration: profiles/r5_role_streams.md.) --
     rpn = model.RCNN_rpn
     c_rpn = _rpn_conv_plan(model, ctx)
     dgw_ready = l4w_ready = rpnw_ready = None
@@ -500,7 +496,7 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
                     _dgrad_weights(c)
 
     if prefetch:
-        prep = model._stream("dgradw", dev)
+        prep = model._stream("wgrad", dev)  # (at the head of the weight-gradient stream: nothing is queued there yet)
         ev0 = ops.record_event()
         prep.wait_event(ev0)
         with ops.on_stream(prep):
@@ -529,10 +525,10 @@ def model_backward_gen(model, grad_losses=(1.0, 1.0, 1.0, 1.0), ctx=None):
     rpn_start = ops.record_event() if rpn_early else None
 
     def launch_rpn_chain():
-        rpn_stream = model._stream("rpn_bwd", dev)
+        rpn_stream = model._stream("support", dev)  # (the forward's support stream: idle in the backward)
         rpn_stream.wait_event(rpn_start)
         with ops.on_stream(rpn_stream):
-            grads_r = WeightGrads(None if capturing else model._stream("wgrad_rpn", dev), model)
+            grads_r = WeightGrads(None if capturing else model._stream("wgrad", dev), model)
             out = _rpn_chain(model, ctx, g1, g2, g_dev, grads_r, rpnw_ready)
             for t_ in out:
                 t_.record_stream(main)

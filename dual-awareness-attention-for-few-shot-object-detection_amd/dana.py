@@ -374,13 +374,31 @@ class DAnARCNN(nn.Module):
             t = self._consts[key] = positional_encoding_table(length).to(dev)
         return t
 
+    # the side streams of the forward and of the backward (backward.py reuses them by role: RPN chain -> "support", the weight
+    # gradients and the data-gradient weights -> "wgrad"). HIP spreads a process's streams over FOUR hardware queues in
+    # creation order, and two roles that land on one queue run one behind the other: which roles share decides 1-2 ms of
+    # the training iteration (profiles/r5_role_streams.md). So all five are created together, in this order, at the first
+    # request, and used once -- streams that a caller creates later (graph capture, RCCL) cannot move them -- and no role
+    # creates more.
+    _ROLE_STREAMS = ("support", "targets", "layer4", "neg_head", "wgrad")
+
     def _stream(self, name, dev):
         if getattr(self, "_single_stream", False):  # bench.py's per-launch timing pass: no overlap
             return ops.cur_stream()
         key = ("stream", name, str(dev))
         st = self._consts.get(key)
         if st is None:
-            st = self._consts[key] = torch.cuda.Stream(device=dev)
+            if name not in self._ROLE_STREAMS:
+                raise KeyError("no stream role '%s'" % name)
+            touch = not torch.cuda.is_current_stream_capturing()
+            for role in self._ROLE_STREAMS:
+                r = self._consts[("stream", role, str(dev))] = torch.cuda.Stream(device=dev)
+                if touch:
+                    # a stream takes its hardware queue at its FIRST USE (the least referenced one at that moment): used
+                    # here, all five take theirs now, in this order, whatever the process creates before the first backward
+                    with torch.cuda.stream(r):
+                        torch.zeros(1, device=dev)
+            st = self._consts[key]
         return st
 
     def _rng_counter(self, dev):
