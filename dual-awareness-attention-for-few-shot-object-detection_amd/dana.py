@@ -381,24 +381,26 @@ class DAnARCNN(nn.Module):
     # request, and used once -- streams that a caller creates later (graph capture, RCCL) cannot move them -- and no role
     # creates more.
     _ROLE_STREAMS = ("support", "targets", "layer4", "neg_head", "wgrad")
+    _role_streams = {}  # (role, device) -> stream; per PROCESS, shared by every model on the device (a second model -- the
+    #                     bench's secondary workloads, a sibling -- must not open five more and land on other queues)
 
     def _stream(self, name, dev):
         if getattr(self, "_single_stream", False):  # bench.py's per-launch timing pass: no overlap
             return ops.cur_stream()
-        key = ("stream", name, str(dev))
-        st = self._consts.get(key)
+        key = (name, str(dev))
+        st = DAnARCNN._role_streams.get(key)
         if st is None:
             if name not in self._ROLE_STREAMS:
                 raise KeyError("no stream role '%s'" % name)
             touch = not torch.cuda.is_current_stream_capturing()
             for role in self._ROLE_STREAMS:
-                r = self._consts[("stream", role, str(dev))] = torch.cuda.Stream(device=dev)
+                r = DAnARCNN._role_streams[(role, str(dev))] = torch.cuda.Stream(device=dev)
                 if touch:
                     # a stream takes its hardware queue at its FIRST USE (the least referenced one at that moment): used
                     # here, all five take theirs now, in this order, whatever the process creates before the first backward
                     with torch.cuda.stream(r):
                         torch.zeros(1, device=dev)
-            st = self._consts[key]
+            st = DAnARCNN._role_streams[key]
         return st
 
     def _rng_counter(self, dev):
