@@ -136,6 +136,12 @@ class WeightGrads:
         for t in _FRESH.grads:
             t.record_stream(cur)
         del _FRESH.grads[:]
+        # the packed gradients were allocated in the weight-gradient stream's pool and are finished on the CALLER's stream
+        # (finish_conv): without this a buffer popped there goes back to that pool while the caller's kernel still reads it --
+        # harmless as long as every caller had a weight-gradient stream to itself, a wrong RPN_Conv gradient with the one
+        # shared stream of round 5 (the trunk's next weight gradient took the block)
+        for t in self.packed.values():
+            t.record_stream(cur)
         for st, keep in self.side.values():
             if keep:
                 done = torch.cuda.Event()
