@@ -402,6 +402,45 @@ def test_sibling_backward_vs_oracle_autograd_and_trainer_step(dev, mfma_mode, na
     assert moved >= len(before) - 2, "only %d of %d trainable tensors moved" % (moved, len(before))
 
 
+def test_backward_on_the_role_streams_equals_the_single_stream_backward(dev):
+    """the backward's chains run on the model's role streams (RPN chain on `support`, box branch on `layer4`, every weight
+    gradient on the ONE `wgrad` stream); buffers that one stream's pool hands out and another stream's kernel still reads
+    must be fenced (round 5: a packed RPN_Conv gradient was not). Three multi-stream backwards with allocator churn in
+    between against the single-stream backward of the same forward: same kernels, same order per gradient -> same bits
+    (the trunk's gradients to roundoff: RoIAlign-backward atomics are unordered)."""
+    import dana_amd
+    from dana_amd import synthetic as S, backward as BW
+    B, way, shot, H, W = 2, 2, 2, 160, 224
+    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=True, way=way, shot=shot, classes=["fg", "bg"])
+    m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=21, profile="test"))
+    m.to(dev).train()
+    m.save_for_backward = True
+    inputs = [t.to(dev) for t in S.episode_inputs(B, way, shot, H, W, seed=4)]
+
+    def grads_of(single):
+        m._single_stream = single
+        np.random.seed(7)
+        with torch.no_grad():
+            m(*inputs)
+        for p_ in m.parameters():
+            p_.grad = None
+        BW.model_backward(m, (1.0, 1.0, 1.0, 1.0))
+        torch.cuda.synchronize()
+        m._single_stream = False
+        return {k: p_.grad.detach().clone() for k, p_ in m.named_parameters() if p_.grad is not None}
+
+    ref = grads_of(True)
+    for rep in range(3):
+        junk = [torch.full((n,), float("nan"), device=dev) for n in (1 << 22, 1 << 20, 1 << 18, 3 << 16, 1 << 14)]
+        del junk  # freed blocks full of NaN: whatever reads a recycled block too early shows
+        got = grads_of(False)
+        assert got.keys() == ref.keys()
+        for k in ref:
+            assert torch.isfinite(got[k]).all(), k
+            tol = 1e-5 * float(ref[k].abs().max()) + 1e-12
+            assert float((got[k] - ref[k]).abs().max()) <= tol, (rep, k)
+
+
 @pytest.mark.parametrize("merge_from", [0, 2, 3])
 def test_merged_trunk_modes_equal_the_two_stream_trunk(dev, mfma_mode, merge_from):
     """DAnARCNN.merge_trunk: query + support batch through one set of [query | support] activation buffers, the stages
