@@ -5,20 +5,20 @@
 //                            triangle only (the lower one is never read); one wave per tile, the
 //                            grid enumerates (column group, row block) so every workgroup has the
 //                            same amount of work (the reference's row-major sweep is triangular).
-//   host scan (:100-123)  -> nms_scan_kernel : one 1024-thread workgroup per problem walks the
+//   host scan (:100-123)  -> nms_scan_flow_kernel / nms_scan_kernel : one 1024-thread workgroup per problem walks the
 //                            64-box blocks in order. Wave 0 (the resolver) settles block b as a FIXED POINT
 //                            instead of the reference's box-by-box chain: lane j holds the bits of the earlier
 //                            boxes of its block that suppress box j (the transposed diagonal tile, written by
 //                            the mask kernel), so "kept = alive and no kept earlier box suppresses me" is one
 //                            ballot per round, K <- ballot(alive_j && (col_j & K) == 0). Suppression only points
 //                            from earlier to later boxes, so the rounds settle the boxes in order of their
-//                            dependency depth and the fixed point IS the greedy result (typically 3-8 rounds of
-//                            ~40 cycles, where the scalar chain cost ~165 cycles per kept box). The kept
-//                            boxes of the last TWO blocks enter the same way through the transposed tiles of the first
-//                            and second super-diagonal. Waves 1..15 (the workers) OR the kept rows of block b-1 into the
-//                            LDS-resident `remv` for the blocks from b+2 on, two iterations behind: the loads issued in
-//                            one iteration stay in flight across the barrier (which waits for LDS only) and are OR-ed in
-//                            the next. One barrier per block; no L2 round trip inside an iteration.
+//                            dependency depth and the fixed point IS the greedy result (1.4 rounds per block on the
+//                            proposal layer's boxes, where the scalar chain cost ~165 cycles per kept box). The kept
+//                            boxes of the last block(s) enter the same way through the transposed tiles of the first
+//                            super-diagonal(s); the other waves OR the kept rows of earlier blocks into the LDS-resident
+//                            `remv`. Two forms: the barrier-free dataflow kernel (bands of <= 128 column blocks: every
+//                            band of the proposal layer; described at the kernel) and the round 2-4 kernel with one
+//                            workgroup barrier per block (wider bands).
 // Column bands when the caller keeps at most `max_keep` boxes (the RPN's post_nms_topN): greedy NMS stops after max_keep
 // keeps, which on score-sorted proposals happens long before the last box, and the scan only ever reads mask words
 // of rows it has visited. Band 0 fills and scans the triangle of the first ~2.5 * max_keep boxes; every later band
