@@ -7,9 +7,11 @@
 //
 // Two feature-map layouts:
 //   NCHW  -- the layout the reference's `_C.roi_align_forward` contract hands over.
-//   NHWC  -- the layout of this build's trunk: one workgroup per (roi, bin), 256 lanes
-//            x float4 sweep the channel axis, so every bilinear tap is a fully
-//            coalesced 16 B/lane read and the output row [C] is one contiguous store.
+//   NHWC  -- the layout of this build's trunk: one wave per (roi, bin, slice of 256
+//            channels), 64 lanes x float4, so every bilinear tap is a fully coalesced
+//            16 B/lane read; a channel slice stays on one or two XCDs (its L2 holds the
+//            slice of the image the rois come from). Channel counts whose slices do not
+//            divide the 8 XCDs: one workgroup per (roi, bin) sweeping all channels.
 //
 // This file is compiled with -ffp-contract=off so the per-sample arithmetic
 // (w1*v1 + w2*v2 + w3*v3 + w4*v4, running sum, final divide) rounds exactly like the
@@ -161,6 +163,67 @@ roi_align_fwd_nhwc(const float* __restrict__ in, const float* __restrict__ rois,
           make_float4(r.x + a.x, r.y + a.y, r.z + a.z, r.w + a.w);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// NHWC forward, channel slices pinned to XCDs (end of round 5; the default whenever ceil(C / 256) divides the 8 XCDs).
+// Counters of the workgroup-per-bin kernel above on the bench's own proposals (profiles/r5_roi_align_counters.md): every
+// XCD works on whole rois, i.e. on all 1024 channels of an image's map -- 9.8 MB touched per image against a 4 MB L2 per
+// XCD -- and the launch fetches 1.5x its algorithmic bytes; and its contiguous (roi, bin) run per XCD makes the launch as
+// slow as its unluckiest XCD: the same 512 rois sorted by falling size (what a proposal list sorted by score tends to
+// look like) take 188 us instead of 80. Here an XCD owns a SLICE of 256 channels (64 lanes x float4 = one full wave load
+// per tap) of EVERY roi: with C = 1024 two XCDs share a slice, the rois of one image -- which arrive together -- keep
+// 38 x 63 x 1 KB = 2.4 MB of that image in the XCD's L2, and every XCD sees the same mix of small and large rois. One
+// wave per (roi, bin, slice); per-channel arithmetic and order are the kernel's above (bit-identical). Measured: memory
+// reads per launch halved (TCC_EA0_RDREQ 1.46 M -> 0.83 M), 77-80 us on the bench's rois (as before), 76 us on the
+// sorted list (188). What the launch costs is no longer its reads: with every roi shrunk to one sample per bin it still
+// takes 55 us -- 205 MB of output rows (the pooled map and its positional-encoded copy) from 100 352 short waves.
+__global__ void __launch_bounds__(256)
+roi_align_fwd_nhwc_sliced(const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ out,
+                          float* __restrict__ out2, const float* __restrict__ add2,
+                          int C, int H, int W, int PH, int PW, float scale, int sr, long in_pix_stride,
+                          long out_pix_stride, long out2_pix_stride, int total_bins, int xps) {
+  // workgroup b runs on XCD b % 8: XCDs slice * xps .. slice * xps + xps - 1 take that slice's (roi, bin) quadruples in turn
+  const int lin = blockIdx.x, xcd = lin & 7, idx = lin >> 3;
+  const int slice = xcd / xps, part = xcd - slice * xps;
+  const int lane = threadIdx.x & 63;
+  const int gb = __builtin_amdgcn_readfirstlane((idx * xps + part) * 4 + (int)(threadIdx.x >> 6));
+  if (gb >= total_bins) return;
+  const int bins = PH * PW;
+  const int n = gb / bins;
+  const int bin = gb - n * bins;
+  const int ph = bin / PW, pw = bin - ph * PW;
+  const RoiGeom g = roi_geom(rois + (long)n * 5, scale, PH, PW, sr);
+  const int c = slice * 256 + lane * 4;
+  const bool act = c < C;  // (the last slice of a C that is not a multiple of 256: idle lanes read channel 0)
+  const float* img = in + (long)g.batch * H * W * in_pix_stride + (act ? c : 0);
+  // (the second output's addend does not depend on the samples: in flight beside the first taps, not behind the last)
+  float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (out2) pe = *(const float4*)(add2 + (long)bin * C + (act ? c : 0));
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int iy = 0; iy < g.grid_h; ++iy) {
+    const float y = g.start_h + ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+    const AxisSample sy = axis_sample(y, H);
+    for (int ix = 0; ix < g.grid_w; ++ix) {
+      const float x = g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+      const AxisSample sx = axis_sample(x, W);
+      if (sy.empty || sx.empty) continue;  // contributes exactly +0
+      const float4 v1 = *(const float4*)(img + ((long)sy.lo * W + sx.lo) * in_pix_stride);
+      const float4 v2 = *(const float4*)(img + ((long)sy.lo * W + sx.hi) * in_pix_stride);
+      const float4 v3 = *(const float4*)(img + ((long)sy.hi * W + sx.lo) * in_pix_stride);
+      const float4 v4 = *(const float4*)(img + ((long)sy.hi * W + sx.hi) * in_pix_stride);
+      const float w1 = sy.h * sx.h, w2 = sy.h * sx.l, w3 = sy.l * sx.h, w4 = sy.l * sx.l;
+      acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+      acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+      acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+      acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+    }
+  }
+  if (!act) return;
+  const float4 r = make_float4(acc.x / g.count, acc.y / g.count, acc.z / g.count, acc.w / g.count);
+  *(float4*)(out + ((long)n * bins + bin) * out_pix_stride + c) = r;
+  if (out2)
+    *(float4*)(out2 + ((long)n * bins + bin) * out2_pix_stride + c) = make_float4(r.x + pe.x, r.y + pe.y, r.z + pe.z, r.w + pe.w);
 }
 
 // total weight the sample lattice of one bin puts on feature row / column `cell` (the gather backward below)
@@ -466,10 +529,20 @@ int dana_roi_align_forward(const float* input, const float* rois, float* output,
                        out2_pix_stride % 4 == 0,
                    "dana_roi_align_forward: NHWC needs C and pixel strides %% 4 == 0");
     DANA_CHECK_ARG(!output2 || add2, "dana_roi_align_forward: output2 needs add2");
-    dim3 grid(num_rois, pooled_h * pooled_w);
-    roi_align_fwd_nhwc<<<grid, 256, 0, s>>>(input, rois, output, output2, add2, channels, height, width, pooled_h,
-                                            pooled_w, spatial_scale, sampling_ratio, in_pix_stride,
-                                            out_pix_stride, out2_pix_stride);
+    const int nsl = (channels + 255) / 256;  // channel slices of 256
+    const long total_bins = (long)num_rois * pooled_h * pooled_w;
+    if (nsl <= 8 && 8 % nsl == 0 && total_bins < (1l << 28)) {
+      const int xps = 8 / nsl;  // XCDs per slice
+      const long quads = (total_bins + 3) / 4;
+      roi_align_fwd_nhwc_sliced<<<(unsigned)(8 * ((quads + xps - 1) / xps)), 256, 0, s>>>(
+          input, rois, output, output2, add2, channels, height, width, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+          in_pix_stride, out_pix_stride, out2_pix_stride, (int)total_bins, xps);
+    } else {  // (a slice count that does not divide the 8 XCDs: every workgroup sweeps all channels of its bin)
+      dim3 grid(num_rois, pooled_h * pooled_w);
+      roi_align_fwd_nhwc<<<grid, 256, 0, s>>>(input, rois, output, output2, add2, channels, height, width, pooled_h,
+                                              pooled_w, spatial_scale, sampling_ratio, in_pix_stride,
+                                              out_pix_stride, out2_pix_stride);
+    }
   } else {
     DANA_CHECK_ARG(false, "dana_roi_align_forward: unknown layout %d", layout);
   }
