@@ -50,12 +50,15 @@ def test_roi_align_nhwc_matches_nchw_and_pe(G, dev):
 
 
 def test_roi_align_nhwc_is_bit_exact_on_wild_rois(dev):
-    """the NHWC kernel on 300 random rois -- degenerate, out of bounds, bins of 0.1 .. 30 cells, sampling_ratio 0 and 2,
-    channel counts that are not a multiple of the workgroup -- against the oracle's restatement of cpu/ROIAlign_cpu.cpp:
-    array_equal"""
+    """the NHWC kernels on 300 random rois -- degenerate, out of bounds, bins of 0.1 .. 30 cells, sampling_ratio 0 and 2,
+    channel counts that are not a multiple of the workgroup / of a slice -- against the oracle's restatement of
+    cpu/ROIAlign_cpu.cpp: array_equal"""
     ops, orc = _ops(), _oracle()
     rng = np.random.default_rng(6)
-    for (B, C, H, W), sr in (((2, 64, 50, 84), 0), ((2, 1028, 12, 20), 0), ((1, 8, 200, 320), 0), ((2, 64, 50, 84), 2)):
+    # (channel counts: one, two, four and eight 256-wide slices pinned to XCDs, a ragged last slice (300), and 1028 = five
+    # slices, which do not divide the 8 XCDs -> the workgroup-per-bin kernel)
+    for (B, C, H, W), sr in (((2, 64, 50, 84), 0), ((2, 1028, 12, 20), 0), ((1, 8, 200, 320), 0), ((2, 64, 50, 84), 2),
+                             ((2, 512, 12, 20), 0), ((1, 300, 14, 9), 0), ((2, 1024, 10, 16), 2), ((1, 2048, 9, 11), 0)):
         feat = rng.normal(size=(B, C, H, W)).astype(np.float32)
         rois = np.zeros((300, 5), np.float32)
         x1 = rng.uniform(-40, 16 * W, 300); y1 = rng.uniform(-40, 16 * H, 300)
