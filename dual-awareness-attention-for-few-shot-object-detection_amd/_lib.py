@@ -11,6 +11,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "dana_hip.h")
+# debug / tuning switches: bound for tools/ and the bit-identity tests, not part of the drop-in ABI
+DEBUG_HEADER = os.path.join(_ROOT, "include", "dana_hip_debug.h")
 LIB_PATH = os.environ.get("DANA_LIB_PATH") or os.path.join(_HERE, "libdana_hip.so")  # (override: same-box A/B of two builds)
 
 _CTYPES = {
@@ -21,6 +23,7 @@ _CTYPES = {
     "unsigned long long": ctypes.c_ulonglong,
     "size_t": ctypes.c_size_t,
     "dana_stream_t": ctypes.c_void_p,
+    "unsigned int": ctypes.c_uint,
 }
 
 
@@ -61,8 +64,9 @@ class _Lib:
                 "or `make -C %s/csrc`. There is no CPU fallback." % (LIB_PATH, _HERE))
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
+        self.debug_protos = parse_header(DEBUG_HEADER) if os.path.exists(DEBUG_HEADER) else {}
         self.fn = {}  # name -> bound foreign function (one dict lookup per launch on the hot path)
-        for name, (ret, args) in self.protos.items():
+        for name, (ret, args) in list(self.protos.items()) + list(self.debug_protos.items()):
             fn = getattr(self.cdll, name)
             fn.argtypes = [_ctype(t) for t, _ in args]
             fn.restype = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret]

@@ -6,6 +6,12 @@
 #include <stdarg.h>
 #include <string.h>
 #include <atomic>
+#include <mutex>
+#include <initializer_list>
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libdana_hip.so is gfx950-only: kernels here declare up to ~69 KB of static and 160 KB of dynamic LDS (CDNA4's 160 KB per CU) and use gfx950 MFMA / LDS-DMA instructions"
+#endif
 
 #define DANA_OK 0
 #define DANA_ERR_ARG (-1)
@@ -37,11 +43,22 @@ void dana_set_error(const char* fmt, ...);
 // include/dana_hip.h) launches on each of them. One static DeviceOnce per kernel instantiation.
 struct DeviceOnce {
   std::atomic<unsigned long long> done{0};  // bit d: device d has the attribute (devices >= 64: set on every call)
-  bool need() {
+  std::mutex mu;
+  // Runs `set` (-> hipError_t) unless this device already has the attribute. The bit is published only AFTER a successful
+  // call, under a mutex: a second host thread on the same device either sees the bit (the opt-in has happened) or waits
+  // for it -- it can never launch in between -- and a failed opt-in is retried by the next launch.
+  template <class F>
+  void once(F&& set) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      (void)set();
+      return;
+    }
     const unsigned long long bit = 1ull << dev;
-    return !(done.fetch_or(bit, std::memory_order_relaxed) & bit);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    if (set() == hipSuccess) done.fetch_or(bit, std::memory_order_release);
   }
 };
 

@@ -31,7 +31,7 @@
 //    thread finishes 4 consecutive channels of one pixel: float4 scale/shift, float4 residual
 //    load, float4 store -- whole 256/512-byte rows per wave instead of 4-byte scattered stores.
 #include "common.h"
-#include "../../include/dana_hip.h"
+#include "../../include/dana_hip_debug.h"
 #include <stdlib.h>
 #include <atomic>
 
@@ -1695,8 +1695,7 @@ int launch(const IgemmParams& p0, int batch, hipStream_t s) {
   const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds_c > lds) lds = lds_c;
   static DeviceOnce attr;  // >64 KiB of dynamic LDS needs the opt-in once per device
-  if (attr.need())
-    (void)hipFuncSetAttribute((const void*)igemm_f32_kernel<BM, BN, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  attr.once([&] { return hipFuncSetAttribute((const void*)igemm_f32_kernel<BM, BN, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
   igemm_f32_kernel<BM, BN, STEM><<<grid, 256, lds, s>>>(p);
   return 0;
@@ -1720,14 +1719,12 @@ int launch_split(const IgemmParams& p0, int batch, hipStream_t s) {
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
   static DeviceOnce attr;
   if constexpr (BM * BN >= 128 * 128) {
-    if (attr.need())
-      (void)hipFuncSetAttribute((const void*)igemm_split_kernel_128<STEM, BPRE, ELDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
+    attr.once([&] { return hipFuncSetAttribute((const void*)igemm_split_kernel_128<STEM, BPRE, ELDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds); });
     igemm_split_kernel_128<STEM, BPRE, ELDS><<<grid, 256, lds, s>>>(p);
   } else {
-    if (attr.need())
-      (void)hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE, FUSE, ELDS>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr.once([&] { return hipFuncSetAttribute((const void*)igemm_split_kernel<BM, BN, STEM, BPRE, FUSE, ELDS>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     igemm_split_kernel<BM, BN, STEM, BPRE, FUSE, ELDS><<<grid, 256, lds, s>>>(p);
   }
   return 0;
@@ -1740,7 +1737,7 @@ int launch_dma(const IgemmParams& p0, int batch, hipStream_t s) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NST * 3 * (128 + BN) * 32;
   static DeviceOnce attr;
-  if (attr.need()) (void)hipFuncSetAttribute((const void*)igemm_dma_kernel<BN, NST, APRE, DF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  attr.once([&] { return hipFuncSetAttribute((const void*)igemm_dma_kernel<BN, NST, APRE, DF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
   igemm_dma_kernel<BN, NST, APRE, DF><<<grid, 256, lds, s>>>(p);
   return 0;
@@ -1759,6 +1756,17 @@ std::atomic<int>& mfma_mode_cell() {
   static std::atomic<int> cell(getenv("DANA_MFMA_SPLIT") ? atoi(getenv("DANA_MFMA_SPLIT")) : 1);
   return cell;
 }
+// An A/B knob from the environment, read ONCE per process (function-local statics at the call sites) and validated: an
+// unknown value is reported and ignored instead of silently meaning something else. -1 = not set.
+int env_choice(const char* name, std::initializer_list<int> allowed) {
+  const char* e = getenv(name);
+  if (!e || !*e) return -1;
+  const int v = atoi(e);
+  for (int a : allowed)
+    if (a == v) return v;
+  fprintf(stderr, "libdana_hip: %s=%s is not one of the accepted values; ignored\n", name, e);
+  return -1;
+}
 unsigned long long* g_trace = nullptr;  // debug: per-block timestamps of the next split launches (dana_set_igemm_trace)
 
 int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
@@ -1774,9 +1782,9 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
     // planes x planes. DANA_PP_STAGES forces a form (tools/pp_probe.py, tests): 2 / 3 / 4 / 6 stages, 13 / 14 = 3 / 4 stages
     // with two fragment sets. Default (profiles/r5_dma_kernel_probe.md): many tiles and a short K walk -> two stages, three
     // workgroups per CU; tile-starved or long-K launches -> three stages, two fragment sets.
-    const char* e = getenv("DANA_PP_STAGES");
+    static const int pp_env = env_choice("DANA_PP_STAGES", {2, 3, 4, 6, 13, 14});
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-    const int stages = e ? atoi(e) : ((t128 < 400 || p.K >= 1024) ? 13 : 2);
+    const int stages = pp_env >= 0 ? pp_env : ((t128 < 400 || p.K >= 1024) ? 13 : 2);
     if (p.N <= 64) return stages == 2 ? launch_dma<64, 2, 1>(p, batch, s) : launch_dma<64, 3, 1>(p, batch, s);
     if (stages == 2) return launch_dma<128, 2, 1>(p, batch, s);
     if (stages == 4) return launch_dma<128, 4, 1>(p, batch, s);
@@ -1788,8 +1796,8 @@ int dispatch(const IgemmParams& p, int batch, int stem, hipStream_t s) {
   // pre-split weights, no ReLU-adjoint mask: the three-workgroups-per-CU kernel for the launches that took 128 x 128 tiles
   // (DANA_DMA_KERNEL=0: the round-4 kernel, for A/Bs; 2: wherever it can run, 64-wide tiles for N <= 64 -- tests)
   if (mode == 1 && p.bpre && !p.mask && p.KH * p.KW <= 32) {
-    const char* e = getenv("DANA_DMA_KERNEL");
-    const int dm = e ? atoi(e) : 1;
+    static const int dm_env = env_choice("DANA_DMA_KERNEL", {0, 1, 2});
+    const int dm = dm_env >= 0 ? dm_env : 1;
     if (dm == 2) return p.N <= 64 ? launch_dma<64, 2, 0>(p, batch, s) : launch_dma<128, 2, 0>(p, batch, s);
     if (dm == 1 && p.N > 64) {
       // measured (profiles/r5_dma_kernel_probe.md, each launch alone): with fp32 activation rows the third workgroup per CU
@@ -1849,8 +1857,15 @@ int dana_set_epilogue_mode(int mode) {
 int dana_get_epilogue_mode(void) { return epilogue_mode_cell().load(std::memory_order_relaxed); }
 
 int dana_set_mfma_mode(int mode) {
-  DANA_CHECK_ARG(mode >= 0 && mode <= 5, "dana_set_mfma_mode: mode must be 0 (f32 MFMA) or 1 (bf16x6 split; 2-5: forced tiles)");
+  DANA_CHECK_ARG(mode == 0 || mode == 1, "dana_set_mfma_mode: mode must be 0 (f32 MFMA) or 1 (bf16x6 split)");
   mfma_mode_cell().store(mode, std::memory_order_relaxed);
+  return DANA_OK;
+}
+
+int dana_debug_force_tile(int tile) {
+  DANA_CHECK_ARG(tile == 0 || (tile >= 2 && tile <= 5), "dana_debug_force_tile: 0 (dispatcher), 2 = 128x64, 3 = 64x64, 4 = 128x128, 5 = 64x128");
+  DANA_CHECK_ARG(mfma_mode_cell().load(std::memory_order_relaxed) != 0, "dana_debug_force_tile: split kernel only");
+  mfma_mode_cell().store(tile ? tile : 1, std::memory_order_relaxed);
   return DANA_OK;
 }
 
@@ -1860,7 +1875,7 @@ int dana_set_igemm_trace(unsigned long long* buffer) {
 }
 
 int dana_get_mfma_mode(void) {
-  return mfma_mode_cell().load(std::memory_order_relaxed);
+  return mfma_mode_cell().load(std::memory_order_relaxed) ? 1 : 0;
 }
 
 static int conv2d_impl(const char* who, const float* input, const float* weight, float* out0, float* out1,

@@ -11,7 +11,7 @@
 // Compiled with -ffp-contract=off (decode rounds like the reference's unfused torch ops).
 #include "common.h"
 #include <atomic>
-#include "../../include/dana_hip.h"
+#include "../../include/dana_hip_debug.h"
 
 namespace {
 
@@ -642,10 +642,11 @@ bool topk_preferred(int n, int topn) {
 int topk_launch(const float* scores, int B, int n, int topn, int* order, int order_stride, float* sorted_scores,
                 hipStream_t s) {
   static DeviceOnce attr;  // (per device: common.h)
-  if (attr.need()) {
-    (void)hipFuncSetAttribute((const void*)topk_sort_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
-    (void)hipFuncSetAttribute((const void*)topk_sort_kernel<TK_MAXR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
-  }
+  attr.once([&] {
+    const hipError_t e0 = hipFuncSetAttribute((const void*)topk_sort_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
+    const hipError_t e1 = hipFuncSetAttribute((const void*)topk_sort_kernel<TK_MAXR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopkSmem));
+    return e0 != hipSuccess ? e0 : e1;
+  });
   if (n <= 24 * TK_THREADS)
     topk_sort_kernel<24><<<B, TK_THREADS, sizeof(TopkSmem), s>>>(scores, n, topn, order, order_stride, sorted_scores);
   else

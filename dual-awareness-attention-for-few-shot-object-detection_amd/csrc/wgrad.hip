@@ -777,12 +777,12 @@ void launch_wgrad_128(const WgradParams& p, dim3 grid, hipStream_t s) {
   if (dana_get_mfma_mode() != 0) {
     constexpr int lds = 2 * 2 * 3 * 128 * WSLD * (int)sizeof(unsigned);
     static DeviceOnce attr;
-    if (attr.need()) (void)hipFuncSetAttribute((const void*)wgrad_split_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr.once([&] { return hipFuncSetAttribute((const void*)wgrad_split_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     // rows of both operands are pixel rows (1x1 / stride 1 / no padding: every Linear, most convs, the Winograd-domain
     // planes): the software-pipelined kernel; strided / multi-tap launches: the general one
     if (p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {
       static DeviceOnce attr_p;
-      if (attr_p.need()) (void)hipFuncSetAttribute((const void*)wgrad_split_128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_p.once([&] { return hipFuncSetAttribute((const void*)wgrad_split_128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
       wgrad_split_128p_kernel<<<grid, 256, lds, s>>>(p);
     } else {
       wgrad_split_128_kernel<<<grid, 256, lds, s>>>(p);

@@ -897,9 +897,31 @@ def get_mfma_mode():
     return lib().query("dana_get_mfma_mode")
 
 
+def force_tile(tile):
+    """debug (include/dana_hip_debug.h: dana_debug_force_tile): 0 = the dispatcher's tile choice, 2 = 128x64, 3 = 64x64,
+    4 = 128x128, 5 = 64x128 for every split-kernel launch that can take it."""
+    lib().call("dana_debug_force_tile", int(tile))
+
+
+def cumask_stream(cus_per_xcd, n_xcd=8, cus_in_xcd=32):
+    """debug: a torch stream restricted to CUs `cus_per_xcd` (an iterable of CU indices 0..31) of EVERY XCD
+    (include/dana_hip_debug.h: dana_debug_stream_create_cumask; mask bit i = CU i // n_xcd of XCD i % n_xcd)."""
+    import ctypes
+    words = (n_xcd * cus_in_xcd + 31) // 32
+    mask = (ctypes.c_uint * words)()
+    for c in cus_per_xcd:
+        for x in range(n_xcd):
+            i = int(c) * n_xcd + x
+            mask[i >> 5] |= 1 << (i & 31)
+    out = ctypes.c_void_p()
+    lib().call("dana_debug_stream_create_cumask", ctypes.cast(mask, ctypes.c_void_p), words, n_xcd,
+               ctypes.cast(ctypes.byref(out), ctypes.c_void_p))
+    return torch.cuda.ExternalStream(out.value)
+
+
 def set_epilogue_mode(mode):
     """0 (default): the split kernel's epilogue runs on the accumulator registers; 1: through an LDS C tile (the round-1..4
-    form, kept as the bit-identity reference: include/dana_hip.h dana_set_epilogue_mode). Returns the previous mode."""
+    form, kept as the bit-identity reference: include/dana_hip_debug.h dana_set_epilogue_mode). Returns the previous mode."""
     prev = lib().query("dana_get_epilogue_mode")
     lib().call("dana_set_epilogue_mode", int(mode))
     return prev

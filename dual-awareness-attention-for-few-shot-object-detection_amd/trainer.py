@@ -239,6 +239,45 @@ class Trainer:
         self.optimizer_step()
         return out
 
+    # ---- checkpoint / resume (train.py:92-101,181-189 save and restore model + optimizer state) -----------------
+    def _views(self, flats):
+        """name -> view of the flat optimizer buffers in the parameter's logical shape (conv weights live [O][KH][KW][I] in
+        the flat buffers, the checkpoint speaks OIHW like torch.optim's momentum_buffer entries)"""
+        out, params = {}, dict(self.model.named_parameters())
+        for (fb, _, _), flat in zip(self.groups, flats):
+            for n in fb.names:
+                o, k = fb.offsets[n]
+                p = params[n]
+                if p.dim() == 4:
+                    O, I, KH, KW = p.shape
+                    out[n] = flat[o:o + k].view(O, KH, KW, I).permute(0, 3, 1, 2)
+                else:
+                    out[n] = flat[o:o + k].view(p.shape)
+        return out
+
+    def state_dict(self):
+        """what a resumed run needs besides model.state_dict(): decayed lr, momentum, step count (Adam's bias correction,
+        SGD's first-step rule) and the momentum / moment buffers per parameter name"""
+        out = {"lr": self.lr, "momentum": self.momentum, "steps": self.steps, "optimizer": self.optimizer,
+               "momentum_buffer": {n: v.detach().clone().contiguous() for n, v in self._views(self.bufs).items()}}
+        if self.optimizer == "adam":
+            out["exp_avg_sq"] = {n: v.detach().clone().contiguous() for n, v in self._views(self.bufs2).items()}
+        return out
+
+    def load_state_dict(self, state):
+        if state.get("optimizer", self.optimizer) != self.optimizer:
+            raise ValueError("checkpoint holds %s state, this trainer runs %s" % (state.get("optimizer"), self.optimizer))
+        mom = self._views(self.bufs)
+        missing = sorted(set(mom) - set(state["momentum_buffer"]))
+        if missing:
+            raise KeyError("optimizer checkpoint lacks %d of %d parameters, e.g. %s" % (len(missing), len(mom), missing[:3]))
+        self.lr, self.momentum, self.steps = float(state["lr"]), float(state["momentum"]), int(state["steps"])
+        for n, v in mom.items():
+            v.copy_(state["momentum_buffer"][n])
+        if self.optimizer == "adam":
+            for n, v in self._views(self.bufs2).items():
+                v.copy_(state["exp_avg_sq"][n])
+
     def adjust_learning_rate(self, decay=0.1):
         """net_utils.adjust_learning_rate (train.py:118-120)"""
         self.lr *= decay

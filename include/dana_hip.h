@@ -45,20 +45,11 @@ int dana_abi_version(void);
 /* How the fp32 contractions (every conv / GEMM below) use the matrix cores. 1 (default; DANA_MFMA_SPLIT overrides the
  * initial value): each fp32 operand is split EXACTLY into three bf16 numbers and the six products of weight >= 2^-16
  * run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error vs an fp64 contraction equal to the f32 kernel's,
- * tests/test_gpu_contractions.py); 0: v_mfma_f32_32x32x2_f32. (2, 3, 4 force a tile shape of mode 1, for tuning.)
+ * tests/test_gpu_contractions.py); 0: v_mfma_f32_32x32x2_f32. (Forced tile shapes, the LDS epilogue form, the sort dispatch and the per-block trace are
+ * debug switches: include/dana_hip_debug.h.)
  * Replaces nothing in the reference: cuDNN picks its own algorithm / math mode there (lib/model/framework/resnet.py). */
 int dana_set_mfma_mode(int mode);
 int dana_get_mfma_mode(void);
-/* Epilogue form of the split kernel (a configuration call like dana_set_mfma_mode). 0 (default): scale / shift / residual / ReLU / ReLU-adjoint mask run on the accumulator registers and the
- * results leave as dword buffer stores (a 32x32 accumulator row = 32 consecutive channels = one 128-byte segment per row and
- * half-wave): no LDS C tile, 49 instead of 67.6 KB of LDS per 128x128 tile. 1: the round-1..4 form through an LDS C tile
- * (float4 rows). Same arithmetic in the same order -> the same bits (tests/test_gpu_contractions.py). */
-int dana_set_epilogue_mode(int mode);
-int dana_get_epilogue_mode(void);
-/* debug / profiling aid (tools/igemm_trace.py, gemm_power.py): while `buffer` is non-null every split-kernel block writes
- * eight 64-bit words {shader-clock at start, at the first K-step, after the K loop, at the end, HW_ID, 100 MHz wall clock
- * at the end, wall clock at the start, 0} at buffer[(z * grid + block) * 8]. The caller sizes the buffer for the launches it traces; null switches it off. */
-int dana_set_igemm_trace(unsigned long long* buffer);
 
 /* ---- native operators: lib/model/csrc/vision.cpp:7-13 (module `model._C`) ------------------- */
 
@@ -132,10 +123,6 @@ int dana_sort_desc(const float* scores, int B, int n, int* order, float* sorted_
 size_t dana_topk_desc_workspace_bytes(int B, int n, int topn);
 int dana_topk_desc(const float* scores, int B, int n, int topn, int* order, int order_stride, float* sorted_scores,
                    void* workspace, size_t workspace_bytes, dana_stream_t stream);
-/* test / A-B aid: 0 = the measured dispatch above (default), 1 = the sample sort for every row, 2 = the single-workgroup
- * kernel wherever it can run (n <= 40 960, min(topn, n) <= 12 288). A process-wide configuration call like
- * dana_set_mfma_mode. */
-int dana_set_sort_mode(int mode);
 
 /* proposals_single[order_single[:topn]] (proposal_layer.py:148-151) */
 int dana_gather_boxes(const float* src, const int* order, int B, int n, int order_stride, int topn, float* dst,

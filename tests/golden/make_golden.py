@@ -117,8 +117,17 @@ def op_goldens(ref):
     save("ops", **out)
 
 
-def e2e(tag, use_ba, training, B, way, shot, H, W, nms_seed=7):
-    """Run reference + oracle on the seeded episode; store reference outputs."""
+def R_iou(a, b):
+    """row-wise IoU (+1 convention) of two [n,4] box arrays"""
+    x1, y1 = np.maximum(a[:, 0], b[:, 0]), np.maximum(a[:, 1], b[:, 1])
+    x2, y2 = np.minimum(a[:, 2], b[:, 2]), np.minimum(a[:, 3], b[:, 3])
+    it = np.clip(x2 - x1 + 1, 0, None) * np.clip(y2 - y1 + 1, 0, None)
+    return it / ((a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1) + (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1) - it)
+
+
+def e2e(tag, use_ba, training, B, way, shot, H, W, nms_seed=7, slim=False):
+    """Run reference + oracle on the seeded episode; store reference outputs (slim: the eight outputs only, no strided
+    intermediates -- the full-size train-mode fixtures stay a few tens of KB)."""
     m = R.build_model(use_ba, way, shot)
     sd = S.fill_state_dict(m.state_dict(), seed=11, profile="test")
     m.load_state_dict(sd)
@@ -134,6 +143,22 @@ def e2e(tag, use_ba, training, B, way, shot, H, W, nms_seed=7):
                            inter=inter)
     names = ["rois", "cls_prob", "bbox_pred", "rpn_loss_cls", "rpn_loss_bbox", "RCNN_loss_cls", "RCNN_loss_bbox",
              "rois_label"]
+    if training and slim and (out_ref[0] - out_or[0]).abs().max().item() > 1e-3:
+        # At 600x1000 the reference and the oracle each sort ~21 500 scores and run NMS over 12 000 boxes per image: a
+        # near-tie (the oracle re-associates a few bmm / linear calls: roundoff-level differences) flips ONE discrete
+        # decision, the candidate list shifts by a slot and the same np.random stream then draws another subset. That is
+        # not an error of either side, and nothing position-wise survives it -- so the oracle is pinned STAGE-WISE here:
+        # the reference's own sampled batch goes in (sampled_targets: the regression targets are a deterministic function
+        # of rois + labels), and everything downstream of the sampling must agree; the RPN losses do not depend on it.
+        n_roi = out_ref[0].shape[0] * out_ref[0].shape[1]
+        prop_ref = out_ref[0]
+        frac = float((R_iou(prop_ref.reshape(-1, 5)[:, 1:].numpy(), out_or[0].reshape(-1, 5)[:, 1:].numpy()) >= 1 - 1e-3).mean())
+        print("  sampled rois differ position-wise (%.1f%% equal): a flipped near-tie upstream; pinning stage-wise" % (100 * frac))
+        inj = O.sampled_targets(out_ref[0], out_ref[7][:n_roi].float().view(out_ref[0].shape[0], -1), gt)
+        np.random.seed(nms_seed)
+        with torch.no_grad():
+            out_or = O.forward(sd, im_data, im_info, gt, nb, sup, training, way, shot, use_ba, nms_inclusive=True,
+                               sampled=inj)
     store = {}
     for n, a, b in zip(names, out_ref, out_or):
         if a is None or (not torch.is_tensor(a) and a == 0):
@@ -146,6 +171,10 @@ def e2e(tag, use_ba, training, B, way, shot, H, W, nms_seed=7):
         tol = {"rois": 1e-3, "rois_label": 0.0}.get(n, 2e-5)
         assert diff <= tol, (n, diff)
         store[n] = a.numpy()
+    if slim:
+        store["meta"] = np.array([int(use_ba), int(training), B, way, shot, H, W, 11, 1996, nms_seed])
+        save("e2e_" + tag, **store)
+        return
     # strided intermediates from the ORACLE trace (pinned to the reference through the outputs above)
     store["base_feat_s"] = inter["base_feat"][:, ::16].numpy()
     store["dense_s"] = inter["dense_support_feature"][:, ::16].numpy()
@@ -326,3 +355,7 @@ if __name__ == "__main__":
         print("frcnn train 192x256 B=2"); e2e_frcnn("train_small", True, 2, 192, 256)
         if "--full" in sys.argv:
             print("eval 600x1000 BA on"); e2e("eval_full_ba", True, False, 1, 1, 3, 600, 1000)
+        if "--full" in sys.argv or "--train-full" in sys.argv:
+            # BASELINE configs[2] / configs[1] themselves: train mode, B = 4, 600x1000, way 2, shot 3 (dana.py:87-220)
+            print("train 600x1000 B=4 BA on"); e2e("train_full_ba", True, True, 4, 2, 3, 600, 1000, slim=True)
+            print("train 600x1000 B=4 BA off"); e2e("train_full_cisa", False, True, 4, 2, 3, 600, 1000, slim=True)

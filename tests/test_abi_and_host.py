@@ -33,6 +33,14 @@ def test_library_exports_every_declared_symbol():
         for ty, _ in args:
             assert ty in allowed, "%s: parameter type %r is not a plain C scalar / raw pointer" % (name, ty)
     assert _lib.lib().query("dana_abi_version") == 1
+    # the debug / tuning switches live in their own header (include/dana_hip_debug.h), are exported too, and none of them
+    # is declared by the drop-in ABI
+    dbg = _lib.parse_header(_lib.DEBUG_HEADER)
+    assert {"dana_set_epilogue_mode", "dana_set_sort_mode", "dana_set_igemm_trace", "dana_debug_force_tile",
+            "dana_debug_stream_create_cumask"} <= set(dbg)
+    assert not set(dbg) & set(protos)
+    for name in dbg:
+        assert hasattr(cdll, name), "libdana_hip.so does not export %s" % name
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -53,11 +61,21 @@ def test_mfma_mode_switch_roundtrip_and_errors():
     """dana_set_mfma_mode / dana_get_mfma_mode (host-side state only: no GPU needed)"""
     L = _lib.lib()
     prev = ops.get_mfma_mode()
-    assert prev in (0, 1, 2, 3, 4)
+    assert prev in (0, 1)
     assert ops.set_mfma_mode(0) == prev and ops.get_mfma_mode() == 0
     assert ops.set_mfma_mode(1) == 0 and ops.get_mfma_mode() == 1
     with pytest.raises(_lib.DanaError, match="mode must be"):
         L.call("dana_set_mfma_mode", 7)
+    with pytest.raises(_lib.DanaError, match="mode must be"):
+        L.call("dana_set_mfma_mode", 2)  # forced tiles are a debug switch now (dana_debug_force_tile)
+    ops.force_tile(3)
+    assert ops.get_mfma_mode() == 1
+    ops.force_tile(0)
+    # a CU mask that leaves an XCD without CUs is refused before any HIP call (bit i = CU i // 8 of XCD i % 8)
+    mask, out = (ctypes.c_uint * 8)(*([0x0f0f0f0f] * 8)), ctypes.c_void_p()
+    with pytest.raises(_lib.DanaError, match="every XCD needs"):
+        L.call("dana_debug_stream_create_cumask", ctypes.cast(mask, ctypes.c_void_p), 8, 8,
+               ctypes.cast(ctypes.byref(out), ctypes.c_void_p))
     assert ops.get_mfma_mode() == 1
     ops.set_mfma_mode(prev)
 

@@ -261,6 +261,57 @@ def test_trainer_step_matches_reference_loop_with_torch_sgd(dev):
     assert len(moved) == sum(p.requires_grad for p in pa.values()) - 7
 
 
+def test_checkpoint_resume_reproduces_the_next_iteration(dev):
+    """train.py:92-101,181-189: save model + optimizer state after one iteration (and one lr decay), restore into a FRESH
+    model / trainer (OIHW in the checkpoint, kernel layout inside), and the next iteration gives the same parameters --
+    i.e. momentum, decayed lr and the step count travel; a trainer of the other optimizer type refuses the state"""
+    import io
+    import dana_amd
+    from dana_amd import synthetic as S
+    from dana_amd.trainer import Trainer
+
+    def build(seed):
+        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=False, way=2, shot=2, classes=["fg", "bg"])
+        m.load_state_dict(S.fill_state_dict(m.state_dict(), seed=seed, profile="test"))
+        return m.to(dev).train()
+
+    inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=6)]
+    ma = build(5)
+    ta = Trainer(ma, 0.1)
+    np.random.seed(1)
+    ta.step(*inputs)
+    ta.adjust_learning_rate(0.1)
+    buf = io.BytesIO()
+    torch.save({"model": ma.state_dict(), "optimizer": ta.state_dict()}, buf)  # train.py:181-189
+    np.random.seed(2)
+    ta.step(*inputs)
+    buf.seek(0)
+    ck = torch.load(buf, map_location=dev)
+    assert ck["optimizer"]["momentum_buffer"]["RCNN_rpn.RPN_Conv.weight"].shape == (512, 2048, 3, 3)  # OIHW
+    mb = build(99)  # different initial weights: everything must come from the checkpoint
+    mb.load_state_dict(ck["model"])
+    tb = Trainer(mb, 0.5)
+    tb.load_state_dict(ck["optimizer"])
+    assert abs(tb.lr - 0.01) < 1e-12 and tb.steps == 1
+    np.random.seed(2)
+    tb.step(*inputs)
+    torch.cuda.synchronize()
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    for k in pa:  # (RoIAlign backward accumulates with float atomics, like the reference's: equal up to summation order)
+        d = (pa[k].detach() - pb[k].detach()).abs().max().item()
+        assert d <= 1e-6 + 1e-5 * pa[k].detach().abs().max().item(), (k, d)
+    # without the optimizer state the same iteration differs (momentum restarts at zero, lr is the constructor's)
+    mc = build(99)
+    mc.load_state_dict(ck["model"])
+    tc = Trainer(mc, 0.01)
+    np.random.seed(2)
+    tc.step(*inputs)
+    pc = dict(mc.named_parameters())
+    assert max((pa[k].detach() - pc[k].detach()).abs().max().item() for k in pa) > 1e-5
+    with pytest.raises(ValueError, match="holds sgd"):
+        Trainer(build(5), 0.01, optimizer="adam").load_state_dict(ck["optimizer"])
+
+
 def test_trainer_adam_matches_torch_adam(dev):
     """train.py:84-85 (--o adam): two iterations through the autograd bridge + torch.optim.Adam vs Trainer(optimizer='adam')"""
     import dana_amd

@@ -97,9 +97,12 @@ def _assert_train_outputs(out, ref, matched=None):
         assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b))), (name, float(a), float(b))
 
 
-def test_train_forward_matches_reference_golden(golden_dir, dev, mfma_mode):
+@pytest.mark.parametrize("tag", ["train_small_ba", "train_full_ba", "train_full_cisa"])
+def test_train_forward_matches_reference_golden(golden_dir, dev, mfma_mode, tag):
+    """train-mode forward (dana.py:87-220) against outputs the REFERENCE produced: 192x256 B=2, and BASELINE configs[2] /
+    configs[1] themselves (600x1000, B=4, way 2, shot 3, BA on / off; make_golden.py --train-full)"""
     from oracle import model_ref as O
-    g = _load(golden_dir, "train_small_ba")
+    g = _load(golden_dir, tag)
     m, sd, din, inputs, (use_ba, training, B, way, shot, nseed) = _build(g["meta"], dev)
     # (1) the whole path incl. this build's own target sampling under the reference's np.random stream
     np.random.seed(nseed)
@@ -108,7 +111,14 @@ def test_train_forward_matches_reference_golden(golden_dir, dev, mfma_mode):
     r, rg = rois.cpu().numpy().reshape(-1, 5), g["rois"].reshape(-1, 5)
     assert r.shape == rg.shape
     matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
-    assert matched.mean() >= 0.97, "sampled rois diverge from the reference: %.1f%% match" % (100 * matched.mean())
+    if "full" not in tag:
+        assert matched.mean() >= 0.97, "sampled rois diverge from the reference: %.1f%% match" % (100 * matched.mean())
+    else:
+        # ~21 500 sorted scores and 12 000 NMS candidates per image: one near-tie flips a discrete decision, the candidate
+        # list shifts and the same np.random stream draws another subset (the reference and the CPU oracle differ from
+        # EACH OTHER that way at this size, make_golden.py) -- position-wise identity is asserted where it is defined:
+        # (2) below on the reference's sampled batch, _train_vs_oracle (e) on a common proposal list
+        print("%s: %.1f%% of the sampled rois equal the reference's position-wise" % (tag, 100 * matched.mean()))
     for name, v in (("rpn_loss_cls", l1), ("rpn_loss_bbox", l2)):  # independent of which rois were sampled
         assert abs(float(v) - float(g[name])) <= 1e-4 * max(1.0, abs(float(g[name]))), name
     # (2) stage-wise, UNCONDITIONAL: the reference's own sampled batch (golden rois + labels; the regression targets
@@ -284,18 +294,45 @@ def _train_vs_oracle(dev, B, way, shot, H, W, ba, wseed=11, iseed=1996, nseed=5,
     # (b) the RPN losses depend on the anchor sampling only (exact inputs): always comparable
     assert abs(float(out[3]) - float(ref[3])) <= 1e-4 * max(1.0, abs(float(ref[3])))  # rpn_loss_cls
     assert abs(float(out[4]) - float(ref[4])) <= 1e-4 * max(1.0, abs(float(ref[4])))  # rpn_loss_bbox
-    # (c) this build's own sampling under the same np.random stream: identical picks wherever the candidate list is
-    # identical. (An image whose proposal list differs from the oracle's by ONE discrete decision -- a near-tie in the
-    # score sort or an IoU within an ulp of 0.7 -- has a shifted candidate list, hence a different random subset: that
-    # is not comparable position by position, and everything downstream of the sampling is asserted in (d) instead.)
+    # (c) this build's own sampling at this size, asserted by what proposal_target_layer_cascade.py:120-213 guarantees for
+    # ANY proposal list -- so it holds (and can fail) whether or not a near-tie flipped a discrete decision upstream:
+    # every sampled roi is a row of THIS run's proposal list or a gt box; its label is 1 exactly when its best IoU (+1
+    # convention) with a gt box reaches FG_THRESH = 0.5; the fg count is min(32, fg candidates) and the batch is full.
+    # (Position-wise identity with the oracle under the same np.random stream needs the same candidate list: that is
+    # step (e), on the oracle's list; the position-wise fractions against the oracle's own run are printed below.)
     R = out[0].size(1)
     r, rg = out[0].cpu().numpy(), ref[0].numpy()
+    lab = out[7].cpu().numpy()[:B * R].reshape(B, R)
+    gt_np = inputs[2].numpy()
+
+    def _iou_matrix(a_, b_):
+        x1, y1 = np.maximum(a_[:, None, 0], b_[None, :, 0]), np.maximum(a_[:, None, 1], b_[None, :, 1])
+        x2, y2 = np.minimum(a_[:, None, 2], b_[None, :, 2]), np.minimum(a_[:, None, 3], b_[None, :, 3])
+        it = np.clip(x2 - x1 + 1, 0, None) * np.clip(y2 - y1 + 1, 0, None)
+        aa_ = (a_[:, 2] - a_[:, 0] + 1) * (a_[:, 3] - a_[:, 1] + 1)
+        ab_ = (b_[:, 2] - b_[:, 0] + 1) * (b_[:, 3] - b_[:, 1] + 1)
+        return it / (aa_[:, None] + ab_[None, :] - it)
+
+    for i in range(B):
+        n_gt = int(inputs[3][i])
+        cand = np.concatenate([ours_prop[i, :, 1:], gt_np[i, :n_gt, :4]], 0)
+        cand_set = {row.tobytes() for row in np.ascontiguousarray(cand, dtype=np.float32)}
+        assert all(np.ascontiguousarray(row, dtype=np.float32).tobytes() in cand_set for row in r[i, :, 1:]), \
+            "image %d: a sampled roi is neither one of this run's proposals nor a gt box" % i
+        assert np.all(r[i, :, 0] == i)
+        best = _iou_matrix(r[i, :, 1:].astype(np.float64), gt_np[i, :n_gt, :4].astype(np.float64)).max(1)
+        clear = np.abs(best - 0.5) > 1e-5  # (an IoU within rounding of the threshold may fall either way)
+        assert np.array_equal(lab[i][clear] == 1, best[clear] >= 0.5), "image %d: labels disagree with the IoU rule" % i
+        cand_best = _iou_matrix(cand.astype(np.float64), gt_np[i, :n_gt, :4].astype(np.float64)).max(1)
+        n_fg_c = int((cand_best >= 0.5 + 1e-5).sum())
+        n_fg_max = int((cand_best >= 0.5 - 1e-5).sum())
+        n_fg = int((lab[i] == 1).sum())
+        assert min(32, n_fg_c) <= n_fg <= min(32, n_fg_max), (i, n_fg, n_fg_c)
     per_image = [float((_iou(r[i, :, 1:], rg[i, :, 1:]) >= 1 - 1e-3).mean()) for i in range(B)]
     good = [v >= min_match for v in per_image]
-    for i in range(B):  # an image may only miss the bar if its proposal list really differs from the oracle's
+    for i in range(B):  # same proposal list as the oracle's -> the same picks, position by position
         assert good[i] or not flip_free[i], "image %d: same proposals, but only %.1f%% of the sampled rois match" % (
             i, 100 * per_image[i])
-    assert sum(good) * 2 >= B, "sampled rois diverge from the oracle on most images: %s" % per_image
     matched = np.array(per_image)
     # make a drift visible: how many images had a flip-free proposal list, and how many met the sampled-roi bar
     # (pytest -rP / -s shows it; the caller asserts its own floor on the flip-free count)

@@ -10,7 +10,9 @@ from dana_amd._lib import lib
 n, h, w, ci, co, k, st, res = [int(v) for v in sys.argv[1:9]]
 mode = int(sys.argv[9]) if len(sys.argv) > 9 else 1
 dev = torch.device("cuda:0")
-ops.set_mfma_mode(mode)
+ops.set_mfma_mode(1 if mode else 0)
+if mode > 1:
+    ops.force_tile(mode)
 x = torch.randn(n * h * w, ci, device=dev)
 wt = torch.randn(co, k * k * ci, device=dev) * 0.05
 sc, sh = torch.ones(co, device=dev), torch.zeros(co, device=dev)

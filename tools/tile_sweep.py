@@ -1,5 +1,5 @@
 """Which block tile is fastest for each contraction shape of the bs-4 step? Times the split kernel with the tile forced
-(dana_set_mfma_mode 4: 128x128, 2: 128x64, 5: 64x128, 3: 64x64) and with the dispatcher's own choice (1).
+(dana_debug_force_tile 4: 128x128, 2: 128x64, 5: 64x128, 3: 64x64) and with the dispatcher's own choice (1 -> 0).
 usage: python tools/tile_sweep.py [out.md]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -54,7 +54,7 @@ for name, n, h, w, ci, co, k, st, res in CONV:
     gf = 2.0 * n * oh * ow * co * k * k * ci / 1e9
     t = []
     for mode, _ in MODES:
-        ops.set_mfma_mode(mode)
+        ops.force_tile(0 if mode == 1 else mode)
         t.append(timeit(lambda: ops.conv2d_nhwc(x, n, h, w, ci, wt, co, k, k, st, k // 2, scale=sc, shift=sh, residual=r, relu=True)))
     rows.append(("%s M=%d N=%d K=%d%s" % (name, n * oh * ow, co, k * k * ci, " +res" if res else ""), gf, t))
 for name, m, n, k, b in GEMM:
@@ -64,10 +64,10 @@ for name, m, n, k, b in GEMM:
     gf = 2.0 * b * m * n * k / 1e9
     t = []
     for mode, _ in MODES:
-        ops.set_mfma_mode(mode)
+        ops.force_tile(0 if mode == 1 else mode)
         t.append(timeit(lambda: ops.gemm_nt(a, bm, m, n, k, out=out, ldc=n, batch=b, batch_a=m * k, batch_b=n * k, batch_c=m * n)))
     rows.append(("gemm %s M=%d N=%d K=%d b%d" % (name, m, n, k, b), gf, t))
-ops.set_mfma_mode(1)
+ops.force_tile(0)
 L = ["| shape | GF | " + " | ".join("%s us" % nm for _, nm in MODES) + " | best |", "|---|---|" + "---|" * (len(MODES) + 1)]
 for name, gf, t in rows:
     best = min(range(1, len(t)), key=lambda i: t[i])
