@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--device-rng", action="store_true",
                     help="sample the training targets with the device Philox RNG (no host sync; NOT the reference's "
                          "np.random stream, which is the default and what the parity tests pin)")
-    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager", "program"],
                     help="graph: replay captured hipGraphs (graphs.py: ~4x less host time per step); eager: one C-ABI call "
                          "per kernel from Python; auto (default): a short trial of both, the faster one is timed and both "
                          "trial figures are reported")
@@ -322,9 +322,22 @@ def main():
     step = eager_step
     if args.eager:
         args.launch = "eager"
-    use_graphs = args.launch != "eager" and args.model == "DAnA" and not args.single_stream
+    replayable = args.model == "DAnA" and not args.single_stream
+    use_graphs = args.launch in ("auto", "graph") and replayable
+    use_programs = args.launch in ("auto", "program") and replayable and not args.device_rng
     np.random.seed(1996 + rank)
     graphed = {}
+    cands = {"eager": eager_step}
+
+    def with_postprocess(run):
+        def step_():
+            from dana_amd.postprocess import detections
+            rois, cls_prob, bbox_pred = run(*run.inputs)[:3]
+            return [detections(rois[i:i + 1], cls_prob[i * rois.size(1):(i + 1) * rois.size(1)],
+                               bbox_pred[i * rois.size(1):(i + 1) * rois.size(1)], inputs[1][i:i + 1])
+                    for i in range(rois.size(0))]
+        return step_
+
     if use_graphs:
         # hipGraph replay (graphs.py): the forward = two captured graphs around the one host round trip (the reference's
         # np.random draws need the fg / bg counts), the training iteration likewise (+ backward + SGD; multi-rank: cut
@@ -333,19 +346,23 @@ def main():
         if args.mode == "step":
             train_step()  # builds the trainer
             gtr = graphed["trainer"] = GraphedTrainer(trainer[0], *inputs)
-            step = lambda: gtr.step(*gtr.inputs)  # noqa: E731
+            cands["graph"] = lambda: gtr.step(*gtr.inputs)  # noqa: E731
         else:
             run = graphed["forward"] = GraphedDAnA(model, *inputs)
-            if args.mode == "infer":
-                def step():
-                    from dana_amd.postprocess import detections
-                    rois, cls_prob, bbox_pred = run(*run.inputs)[:3]
-                    return [detections(rois[i:i + 1], cls_prob[i * rois.size(1):(i + 1) * rois.size(1)],
-                                       bbox_pred[i * rois.size(1):(i + 1) * rois.size(1)], inputs[1][i:i + 1])
-                            for i in range(rois.size(0))]
-            else:
-                step = lambda: run(*run.inputs)  # noqa: E731
-    graph_step = step
+            cands["graph"] = with_postprocess(run) if args.mode == "infer" else (lambda: run(*run.inputs))
+    if use_programs:
+        # launch-program replay (program.py): the EAGER step's own launches on the eager step's streams, recorded once and
+        # re-issued from one Python loop -- two programs around the host round trip; multi-rank: the bucket all-reduces
+        # are host callbacks inside the second one
+        from dana_amd.program import ProgramDAnA, ProgramTrainer
+        if args.mode == "step":
+            train_step()
+            ptr = graphed["program_trainer"] = ProgramTrainer(trainer[0], *inputs)
+            cands["program"] = lambda: ptr.step(*ptr.inputs)  # noqa: E731
+        else:
+            prun = graphed["program_forward"] = ProgramDAnA(model, *inputs)
+            cands["program"] = with_postprocess(prun) if args.mode == "infer" else (lambda: prun(*prun.inputs))
+    graph_step = cands.get("graph")
 
     def median_interval(evs):
         """median GPU-side interval between consecutive iteration-end events (ms): robust against the host stalls of a
@@ -371,25 +388,30 @@ def main():
         mean = (time.perf_counter() - t0) / k * 1e3
         return median_interval(marks) or mean
 
-    launch_trial = None
-    if use_graphs and args.launch == "auto":
-        kt = max(5, min(20, args.steps))
-        launch_trial = {"graph_ms_per_step": round(trial(graph_step, kt), 3), "eager_ms_per_step": round(trial(eager_step, kt), 3),
-                        "steps_each": kt}
-        prefer_eager = launch_trial["eager_ms_per_step"] < launch_trial["graph_ms_per_step"]
+    def pick_launch(c, k, forced=None):
+        """time every candidate launch mode of one step (k steps each, two interleaved rounds, the better round counts) and
+        pick the fastest; every rank takes the same one (times are max-reduced over the ranks first: N ranks share a host).
+        -> (name, {name_ms_per_step: ...})"""
+        names = sorted(c)
+        if forced in c:
+            return forced, None
+        if len(names) == 1:
+            return names[0], None
+        best = {n: 1e30 for n in names}
+        for _ in range(2):
+            for n in names:
+                best[n] = min(best[n], trial(c[n], k))
+        t = torch.tensor([best[n] for n in names], device=dev, dtype=torch.float64)
         if world > 1:
-            # every rank must take the same path, and N ranks share the host's cores: graph replay (a few launches per
-            # step) unless the trial prefers eager issue on EVERY rank
-            t = torch.tensor([launch_trial["graph_ms_per_step"], launch_trial["eager_ms_per_step"]], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            launch_trial["graph_ms_per_step"], launch_trial["eager_ms_per_step"] = round(float(t[0]), 3), round(float(t[1]), 3)
-            v = torch.tensor([1.0 if prefer_eager else 0.0], device=dev)
-            dist.all_reduce(v, op=dist.ReduceOp.MIN)
-            prefer_eager = bool(v.item() > 0.5)
-            launch_trial["ranks_preferring_eager"] = "all" if prefer_eager else "not all"
-        if prefer_eager:
-            step = eager_step
-    timed_graphs = use_graphs and step is not eager_step
+        vals = [float(x) for x in t.tolist()]
+        tr_ = {"%s_ms_per_step" % n: round(v, 3) for n, v in zip(names, vals)}
+        tr_["steps_each"] = k
+        return names[vals.index(min(vals))], tr_
+
+    chosen, launch_trial = pick_launch(cands, max(5, min(20, args.steps)), None if args.launch == "auto" else args.launch)
+    step = cands[chosen]
+    timed_graphs = chosen == "graph"
     for _ in range(args.warmup):
         step()
 
@@ -429,8 +451,7 @@ def main():
         per_rank_ms = [round(1000.0 * float(x) / args.steps, 3) for x in every.tolist()]
         dt = float(every.max().item())
 
-    host_ms_graph = host_enqueue_ms(graph_step) if use_graphs else None
-    host_ms_eager = host_enqueue_ms(eager_step, 10)
+    host_ms = {n: host_enqueue_ms(f, 10 if n == "eager" else 20) for n, f in cands.items()}
     what = {"step": "training step fwd+bwd+allreduce+SGD",
             "infer": "eval-mode forward + detection post-processing per image"}.get(args.mode, "%s-mode forward" % args.mode)
     result = {
@@ -451,9 +472,10 @@ def main():
         "launch": ("hipGraph replay, %d graph launches per step (graphs.py)" % (
             (len(graphed["trainer"].graphs) + (graphed["trainer"].g_anchor is not None)) if args.mode == "step" else
             (1 + (graphed["forward"].g0 is not None) + (graphed["forward"].g2 is not None))))
-        if timed_graphs else "eager (one C-ABI call per kernel from Python)",
+        if timed_graphs else ("launch-program replay: the eager step's launches on its own streams, re-issued from one loop "
+                              "(program.py)" if chosen == "program" else "eager (one C-ABI call per kernel from Python)"),
         "launch_trial": launch_trial,
-        "host_enqueue_ms_per_step": {"graph": host_ms_graph, "eager": host_ms_eager},
+        "host_enqueue_ms_per_step": host_ms,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -484,28 +506,20 @@ def main():
         ks, kw = max(3, min(args.steps, 20)), 5  # the first iterations grow the allocator's pools
         for _ in range(kw):
             train_step()
-        eager_train_step = graph_train_step = train_step
-        ts_trial = None
+        eager_train_step = train_step
+        ts_cands = {"eager": eager_train_step}
         if use_graphs:
             from dana_amd.graphs import GraphedTrainer
             gtr = graphed["trainer"] = GraphedTrainer(trainer[0], *inputs)
-            graph_train_step = lambda: gtr.step(*gtr.inputs)  # noqa: E731
-            train_step = graph_train_step
-            if args.launch == "auto":
-                ts_trial = {"graph_ms_per_step": round(trial(graph_train_step, 12), 3),
-                            "eager_ms_per_step": round(trial(eager_train_step, 12), 3)}
-                ts_eager = ts_trial["eager_ms_per_step"] < ts_trial["graph_ms_per_step"]
-                if world > 1:
-                    t = torch.tensor([ts_trial["graph_ms_per_step"], ts_trial["eager_ms_per_step"]], device=dev)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    ts_trial["graph_ms_per_step"], ts_trial["eager_ms_per_step"] = round(float(t[0]), 3), round(float(t[1]), 3)
-                    v = torch.tensor([1.0 if ts_eager else 0.0], device=dev)
-                    dist.all_reduce(v, op=dist.ReduceOp.MIN)
-                    ts_eager = bool(v.item() > 0.5)
-                if ts_eager:
-                    train_step = eager_train_step
-            for _ in range(3):
-                train_step()
+            ts_cands["graph"] = lambda: gtr.step(*gtr.inputs)  # noqa: E731
+        if use_programs:
+            from dana_amd.program import ProgramTrainer
+            ptr = graphed["program_trainer"] = ProgramTrainer(trainer[0], *inputs)
+            ts_cands["program"] = lambda: ptr.step(*ptr.inputs)  # noqa: E731
+        ts_chosen, ts_trial = pick_launch(ts_cands, 12, None if args.launch == "auto" else args.launch)
+        train_step = ts_cands[ts_chosen]
+        for _ in range(3):
+            train_step()
         barrier()
         marks_s = [torch.cuda.Event(enable_timing=True)]
         marks_s[0].record()
@@ -529,10 +543,9 @@ def main():
             "ms_per_step": round(1000.0 * dts / ks, 3), "ms_per_step_median": median_interval(marks_s),
             "gradient_mbytes": round(4e-6 * sum(fb.numel for fb, _, _ in tr.groups), 1),
             "buckets": sum(len(fb.buckets) for fb, _, _ in tr.groups),
-            "launch": "hipGraph replay" if train_step is not eager_train_step else "eager",
+            "launch": {"graph": "hipGraph replay", "program": "launch-program replay", "eager": "eager"}[ts_chosen],
             "launch_trial": ts_trial,
-            "host_enqueue_ms_per_step": {"graph": host_enqueue_ms(graph_train_step, 10) if use_graphs else None,
-                                         "eager": host_enqueue_ms(eager_train_step, 5)},
+            "host_enqueue_ms_per_step": {n: host_enqueue_ms(f, 5 if n == "eager" else 10) for n, f in ts_cands.items()},
         }
 
         # The exchange, isolated (north_star's "RCCL all-reduce on the loss gradients only"; train.py:104-105,138-139): (a) the
@@ -882,6 +895,13 @@ def main():
                 if dtg < dt1:
                     dt1, launch1 = dtg, "hipGraph replay"
                 del run1
+            if use_programs and not m1.device_rng:
+                from dana_amd.program import ProgramDAnA
+                run1 = ProgramDAnA(m1, *inputs)
+                dtg = wall(lambda: run1(*run1.inputs))
+                if dtg < dt1:
+                    dt1, launch1 = dtg, "launch-program replay"
+                del run1
         result["configs_1_cisa_only"] = {"value": round(args.batch * k1 / dt1, 3), "unit": "query-images/sec",
                                          "ms_per_step": round(1e3 * dt1 / k1, 3), "steps": k1, "launch": launch1}
         del m1
@@ -900,11 +920,16 @@ def main():
         with torch.no_grad():
             eager2 = lambda: m2(*in2)  # noqa: E731
             t_eager = trial(eager2, k)
-            t_graph = None
+            t_graph = t_prog = None
             if use_graphs:
                 from dana_amd.graphs import GraphedDAnA
                 run2 = GraphedDAnA(m2, *in2)
                 t_graph = trial(lambda: run2(*run2.inputs), k)
+                del run2
+            if use_programs:
+                from dana_amd.program import ProgramDAnA
+                run2 = ProgramDAnA(m2, *in2)
+                t_prog = trial(lambda: run2(*run2.inputs), k)
                 del run2
             ops.PROFILE = []
             m2._single_stream = True
@@ -917,15 +942,17 @@ def main():
         f2 = sum(r[1] for r in prof2)
         x2 = sum(r[5] for r in prof2)
         t2 = sum(r[2].elapsed_time(r[3]) for r in prof2) * 1e-3
-        best = min(t_eager, t_graph) if t_graph is not None else t_eager
+        modes = {"eager": t_eager, "hipGraph replay": t_graph, "launch-program replay": t_prog}
+        launch2, best = min(((n, v) for n, v in modes.items() if v is not None), key=lambda nv: nv[1])
         pk = PEAK_SPLIT_TFLOPS if ops.get_mfma_mode() else PEAK_FP32_MFMA_TFLOPS
         del m2, in2
         torch.cuda.empty_cache()
         return {"workload": label, "value": round(batch / best * 1e3, 3), "unit": "query-images/sec",
                 "ms_per_step": round(best, 3), "steps": k, "batch": batch,
                 "timing": "median GPU-side interval between consecutive steps (trial()), not the wall-clock mean of the headline",
-                "launch": "hipGraph replay" if (t_graph is not None and t_graph <= t_eager) else "eager",
+                "launch": launch2,
                 "eager_ms_per_step": round(t_eager, 3), "graph_ms_per_step": None if t_graph is None else round(t_graph, 3),
+                "program_ms_per_step": None if t_prog is None else round(t_prog, 3),
                 "roofline": {"bound": "mfma", "achieved": round(f2 / t2 / 1e12, 2), "peak": pk, "unit": "TFLOP/s",
                              "frac": round(f2 / t2 / 1e12 / pk, 4), "launches_per_step": len(prof2) // k,
                              "algorithmic_gflop_per_step": round(f2 / k / 1e9, 1), "executed_gflop_per_step": round(x2 / k / 1e9, 1),

@@ -74,15 +74,19 @@ class _Lib:
 
     def call(self, name, *args):
         """Call an `int dana_*` entry point; raise DanaError with dana_last_error() on failure."""
-        rc = self.fn[name](*args)
+        fn = self.fn[name]
+        rc = fn(*args)
         if rc != 0:
             raise DanaError("%s failed (%d): %s" % (name, rc, self.cdll.dana_last_error().decode()))
+        if RECORDER is not None:  # program.LaunchProgram: the eager step's launch sequence, recorded for replay
+            RECORDER.add_call(fn, name, args)
 
     def query(self, name, *args):
         return self.fn[name](*args)
 
 
 _lib = None
+RECORDER = None  # set by program.LaunchProgram.recording(): every successful call is appended to the program
 
 
 def lib():

@@ -95,6 +95,12 @@ class FlatBuckets:
         self.launch_order.append(i)
         if not self.collective or getattr(self, "capture_only", False):
             return  # (capture_only: graphs.GraphedTrainer records the order and issues the collectives between replays)
+        rec = getattr(self, "recorder", None)
+        if rec is not None:
+            # program.ProgramTrainer: the collective is a HOST step inside the recorded backward -- issued now, and again at
+            # this position (on this stream) of every replay
+            rec.host_callback(lambda: self._works.append(self.reduce_bucket(i)))
+            return
         self._works.append(self.reduce_bucket(i))
 
     def reduce_bucket(self, i):
@@ -130,6 +136,15 @@ class FlatBuckets:
                                % (missing, self.buckets[missing[0]][2][:3]))
         for w in self._works:
             w.wait()  # nccl: the CURRENT stream waits for the collective; gloo: the host does
+        if self._works and self._comm is not None:
+            ops.cur_stream().wait_stream(self._comm)
+        self._works = []
+
+    def wait_issued(self):
+        """wait_all() for a replayed iteration (program.ProgramTrainer): the buckets were issued by the program's host
+        callbacks, not through mark_ready, so there is no pending count to check"""
+        for w in self._works:
+            w.wait()
         if self._works and self._comm is not None:
             ops.cur_stream().wait_stream(self._comm)
         self._works = []

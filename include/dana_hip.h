@@ -582,6 +582,24 @@ int dana_anchor_target_subsample_ctr(float* labels, const int* fg_list, const in
                                      float* inv_num_examples, dana_stream_t stream);
 int dana_counter_add(unsigned long long* counter_dev, unsigned long long inc, dana_stream_t stream);
 
+/* ---- launch programs -------------------------------------------------------------------------------------------------
+ * The reference's training iteration (train.py:125-143) is ~1 500 launches on this library; issued one by one from the host
+ * language they cost more host time than the GPU needs for them at eight ranks per host. A program is a recorded list of
+ * calls of THIS header's `int dana_*(...)` entry points (the stream is one of their arguments), hipEventRecord and
+ * hipStreamWaitEvent operations, re-issued in order from one C loop: the recorded step's launches with its arguments on
+ * its streams behind its event edges (dana_amd/program.py records them from the eager step). Host-only; no device memory,
+ * no synchronisation. A program is replayed by one thread at a time.
+ *   signature: one character per argument of the entry point -- i (int), l (long / size_t / unsigned long long), p (pointer /
+ *   dana_stream_t), f (float), d (double); words[k]: argument k as a 64-bit word (integers sign-extended, a float's bits in
+ *   the low half, a double's bits). dana_program_run re-issues entries [begin, end) and returns the first non-zero status. */
+int dana_program_create(void** program_out);
+int dana_program_destroy(void* program);
+int dana_program_add_call(void* program, void* entry_point, const char* signature, const unsigned long long* words, int nargs);
+int dana_program_add_event_record(void* program, void* event, dana_stream_t stream);
+int dana_program_add_event_wait(void* program, void* event, dana_stream_t stream);
+int dana_program_size(void* program);
+int dana_program_run(void* program, int begin, int end);
+
 #ifdef __cplusplus
 }
 #endif

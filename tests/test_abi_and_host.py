@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     # and nothing torch-typed leaks into the boundary: only C scalars and raw pointers
     allowed = {"int", "long", "float", "double", "size_t", "dana_stream_t", "const float*", "float*", "const int*",
                "int*", "const unsigned char*", "unsigned long long", "void*", "const unsigned long long*",
-               "unsigned long long*", "long long*", "const long long*"}
+               "unsigned long long*", "long long*", "const long long*", "void**", "const char*"}
     for name, (ret, args) in protos.items():
         assert ret in ("int", "size_t", "const char*"), (name, ret)
         for ty, _ in args:
@@ -55,6 +55,51 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.query("dana_nms_workspace_bytes", 12000, 4) == 4 * 12000 * 188 * 8 + 4 * (2 * 188 * 8 + 16) + 4 * 4 * 12000 * 8
     # empty inputs are a no-op, like the reference (nms.h:17-18, ROIAlign_cuda.cu:278-281)
     L.call("dana_roi_align_forward", None, None, None, 1, 8, 8, 8, 0, 1.0, 7, 7, 0, 0, 0, 0, None, None, 0, None)
+
+
+def test_launch_program_executor_reissues_recorded_calls_without_a_gpu():
+    """include/dana_hip.h "launch programs" (csrc/program.hip): recorded C-ABI calls are re-issued by one C loop through
+    libffi -- exercised here on entry points that need no GPU: a configuration call, the empty-input no-op of
+    dana_roi_align_forward (19 arguments, a float in the middle, five null pointers) and its argument-error path"""
+    import struct
+    from dana_amd.program import LaunchProgram
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    L.call("dana_program_create", ctypes.cast(ctypes.byref(h), ctypes.c_void_p))
+
+    def add(name, *args):
+        fn = L.fn[name]
+        sig = "".join(LaunchProgram._SIG[t] for t in fn.argtypes)
+        assert len(sig) == len(args)
+        words = (ctypes.c_ulonglong * len(args))()
+        for k, (c, a) in enumerate(zip(sig, args)):
+            if c == "f":
+                words[k] = struct.unpack("<I", struct.pack("<f", a))[0]
+            elif c == "d":
+                words[k] = struct.unpack("<Q", struct.pack("<d", a))[0]
+            else:
+                words[k] = (0 if a is None else int(a)) & 0xFFFFFFFFFFFFFFFF
+        L.call("dana_program_add_call", h, ctypes.cast(fn, ctypes.c_void_p), sig.encode(), ctypes.cast(words, ctypes.c_void_p),
+               len(args))
+
+    prev = ops.get_mfma_mode()
+    add("dana_set_mfma_mode", 0)
+    add("dana_roi_align_forward", None, None, None, 1, 8, 8, 8, 0, 1.0, 7, 7, 0, 0, 0, 0, None, None, 0, None)  # R = 0: no-op
+    add("dana_set_mfma_mode", 1)
+    add("dana_roi_align_forward", None, None, None, 1, 0, 8, 8, 1, 1.0, 7, 7, 0, 0, 0, 0, None, None, 0, None)  # C = 0: refused
+    add("dana_set_mfma_mode", 0)  # (never reached)
+    assert L.query("dana_program_size", h) == 5
+    ops.set_mfma_mode(1)
+    assert L.query("dana_program_run", h, 0, 2) == 0 and ops.get_mfma_mode() == 0
+    assert L.query("dana_program_run", h, 2, 5) == -1 and ops.get_mfma_mode() == 1  # stopped at the failing entry
+    assert b"bad shape" in L.cdll.dana_last_error()
+    with pytest.raises(_lib.DanaError, match="bad range"):
+        L.call("dana_program_run", h, 3, 9)
+    with pytest.raises(_lib.DanaError, match="signature character"):
+        L.call("dana_program_add_call", h, ctypes.cast(L.fn["dana_set_mfma_mode"], ctypes.c_void_p), b"q",
+               ctypes.cast((ctypes.c_ulonglong * 1)(0), ctypes.c_void_p), 1)
+    L.call("dana_program_destroy", h)
+    ops.set_mfma_mode(prev)
 
 
 def test_mfma_mode_switch_roundtrip_and_errors():
