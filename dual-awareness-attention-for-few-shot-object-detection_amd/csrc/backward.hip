@@ -45,6 +45,22 @@ axpy_kernel(float4* __restrict__ y, const float4* __restrict__ x, int C4, long l
   }
 }
 
+// y[r][c] *= x[r][c] (attention_type 'product': dana.py:155-156, 285-286)
+__global__ void __launch_bounds__(256)
+mul_rows_kernel(float4* __restrict__ y, const float4* __restrict__ x, int C4, long ldy4, long ldx4, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const long r = i / C4;
+    const int c = (int)(i % C4);
+    const float4 a = x[r * ldx4 + c];
+    float4 v = y[r * ldy4 + c];
+    v.x *= a.x;
+    v.y *= a.y;
+    v.z *= a.z;
+    v.w *= a.w;
+    y[r * ldy4 + c] = v;
+  }
+}
+
 // dw[n][:] *= scale[n]
 __global__ void __launch_bounds__(256)
 rowscale_kernel(float* __restrict__ dw, const float* __restrict__ scale, long K, long total) {
@@ -245,6 +261,18 @@ int dana_axpy_rows(float* y, const float* x, long rows, int channels, long ld_y,
   axpy_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((float4*)y, (const float4*)x, channels / 4, ld_y / 4,
                                                                      ld_x / 4, total, alpha, accumulate);
   DANA_CHECK_LAUNCH("dana_axpy_rows");
+  return DANA_OK;
+}
+
+int dana_mul_rows(float* y, const float* x, long rows, int channels, long ld_y, long ld_x, dana_stream_t stream) {
+  DANA_CHECK_ARG(y && x && rows > 0 && channels > 0 && channels % 4 == 0, "dana_mul_rows: bad args");
+  if (ld_y <= 0) ld_y = channels;
+  if (ld_x <= 0) ld_x = channels;
+  DANA_CHECK_ARG(ld_y % 4 == 0 && ld_x % 4 == 0 && (((uintptr_t)y | (uintptr_t)x) & 15) == 0, "dana_mul_rows: strides %% 4 != 0 or unaligned rows");
+  const long total = rows * (channels / 4);
+  mul_rows_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>((float4*)y, (const float4*)x, channels / 4, ld_y / 4,
+                                                                         ld_x / 4, total);
+  DANA_CHECK_LAUNCH("dana_mul_rows");
   return DANA_OK;
 }
 

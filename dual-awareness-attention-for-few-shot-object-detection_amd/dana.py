@@ -144,8 +144,8 @@ class DAnARCNN(nn.Module):
     def __init__(self, classes, attention_type="concat", rpn_reduce_dim=256, rcnn_reduce_dim=256, gamma=0.1,
                  semantic_enhance=False, num_layers=50, pretrained=False, num_way=2, num_shot=5, pos_encoding=True):
         super().__init__()
-        if attention_type != "concat":
-            raise NotImplementedError("only attention_type='concat' (what utils.get_model builds, utils.py:120)")
+        if attention_type not in ("concat", "product"):
+            raise ValueError("attention_type must be 'concat' or 'product' (dana.py:70-77)")
         self.model_path = "data/pretrained_model/resnet50_caffe.pth"
         self.dout_base_model = 1024
         self.pretrained = pretrained
@@ -198,8 +198,10 @@ class DAnARCNN(nn.Module):
         self.rcnn_adapt_k_layer = lin(dim_in, rcnn_reduce_dim)
         if self.semantic_enhance:
             self.rpn_channel_k_layer = lin(dim_in, 1)
-        self.RCNN_rpn = _RPNParams(2048)
-        self.rcnn_transform_layer = nn.Linear(2048, self.rcnn_dim)
+        # dana.py:70-77: 'concat' correlates [query | attended] (2048 channels), 'product' query * attended (1024)
+        corr_dim = 2048 if attention_type == "concat" else 1024
+        self.RCNN_rpn = _RPNParams(corr_dim)
+        self.rcnn_transform_layer = nn.Linear(corr_dim, self.rcnn_dim)
         self.output_score_layer = FFN(64 * 49, dim_in)
         self._plan = None
         self._consts = {}
@@ -921,6 +923,16 @@ class DAnARCNN(nn.Module):
         ops.attn_softmax_unary_(scores, unary, B * hw, hw, shot, L, K1, K1, self.unary_gamma, 1.0 / shot)
         ops.gemm_nt(scores, s_t, hw, 1024, K1, lda=K1, ldb=K1, out=corr.view(-1)[1024:], ldc=2048, batch=B,
                     batch_a=hw * K1, batch_b=1024 * K1, batch_c=hw * 2048)
+        product = self.attention_type == "product"
+        if product:
+            # dana.py:155-156: correlation_feat = base_feat * dense_support_feature -- in place in the attended half of the
+            # buffer (nothing else reads the attended rows); the RPN conv then reads that half only (cin 1024, pixel stride
+            # 2048), RoIAlign keeps reading base_feat from the first half
+            if ctx is not None:
+                raise NotImplementedError("attention_type='product' runs the forward (train and eval mode) on the HIP "
+                                          "kernels; its backward is not implemented -- train 'concat', what utils.get_model "
+                                          "builds (utils.py:120-123)")
+            ops.mul_rows_(corr.view(-1)[1024:], corr, B * hw, 1024, ld_y=2048, ld_x=2048)
         if inter is not None:
             inter["corr"] = (corr, B, fh, fw)
         if ctx is not None:
@@ -929,15 +941,16 @@ class DAnARCNN(nn.Module):
         mark("rpn-level attention (incl. wait for support stream)")
         # -- RPN head + proposals (rpn.py:58-78, proposal_layer.py:49-190) --
         rpn = self.RCNN_rpn
+        rpn_in = corr.view(-1)[1024:] if product else corr  # (product: the attended half, pixel stride 2048)
         if plan["rpn_conv_u"] is not None:
             kv = [] if ctx is not None else None
-            x, _, _ = ops.conv3x3_winograd(corr, B, fh, fw, 2048, plan["rpn_conv_b3"] or plan["rpn_conv_u"], 512,
-                                           shift=plan["rpn_conv_b"], relu=True, keep_v=kv)
+            x, _, _ = ops.conv3x3_winograd(rpn_in, B, fh, fw, rpn.din, plan["rpn_conv_b3"] or plan["rpn_conv_u"], 512,
+                                           shift=plan["rpn_conv_b"], relu=True, keep_v=kv, in_stride=2048)
             if kv:
                 ctx["rpn_v"] = kv[0]  # the input's Winograd transform: the weight gradient does not repeat it
         else:
-            x, _, _ = ops.conv2d_nhwc(corr, B, fh, fw, 2048, plan["rpn_conv_b3"] or plan["rpn_conv_w"], 512, 3, 3, 1, 1,
-                                      shift=plan["rpn_conv_b"], relu=True)
+            x, _, _ = ops.conv2d_nhwc(rpn_in, B, fh, fw, rpn.din, plan["rpn_conv_b3"] or plan["rpn_conv_w"], 512, 3, 3, 1, 1,
+                                      shift=plan["rpn_conv_b"], relu=True, in_stride=2048)
         nh = rpn.nc_score_out + rpn.nc_bbox_out
         heads = ops.gemm_nt(x, plan["rpn_head_w3"] or plan["rpn_head_w"], B * hw, nh, 512, shift=plan["rpn_head_b"])  # [B*hw][2A | 4A]
         mark("rpn conv + heads")
@@ -964,7 +977,7 @@ class DAnARCNN(nn.Module):
             un2 = ops.rowdot(sp_pe, wu2, bu2, Ns * P2, 1024)
             ops.softmax_rows_(un2, Ns, P2)
             sw = None
-            if getattr(self, "fold_roi_attn", True):
+            if getattr(self, "fold_roi_attn", True) and not product:  # (product needs the attended rows themselves)
                 # The head's two contractions re-associated (dana.py:279-286): the attended rows only feed the second half
                 # of rcnn_transform_layer, and (A . S) . Wt_a^T = A . (S . Wt_a^T) -- S . Wt_a^T is a [147][64] table per
                 # image computed ONCE here (under the proposal layer), the per-RoI work drops from K = 147 -> 1024 -> 64
@@ -1057,7 +1070,8 @@ class DAnARCNN(nn.Module):
         # projections that consume it: (pooled + PE) W^T = pooled W^T + (PE W^T), a [49][N] table per weight version --
         # RoIAlign then writes ONE [n,49,1024] output instead of two (it is bound by its own writes), and the
         # Q projection and the query half of rcnn_transform_layer are ONE N = 128 GEMM over pooled (one read of it).
-        fold_pe = ctx is None and cfg.POOLING_MODE == "align" and getattr(self, "fold_roi_pe", True)
+        fold_pe = (ctx is None and cfg.POOLING_MODE == "align" and getattr(self, "fold_roi_pe", True)
+                   and self.attention_type == "concat")  # (product multiplies by pooled + PE itself: dana.py:286)
         if cfg.POOLING_MODE == "align" and fold_pe:
             pooled, q_pe = ops.roi_align_forward_nhwc(corr, B, fh, fw, 1024, 2048, rois.view(-1, 5), 1.0 / 16.0, P, 0)
         elif cfg.POOLING_MODE == "align":
@@ -1127,14 +1141,19 @@ class DAnARCNN(nn.Module):
         wt, bt_ = self._w(self.rcnn_transform_layer)
         w1, b1 = self._w(self.output_score_layer.linear1)
         w2, b2 = self._w(self.output_score_layer.linear2)
-        wt_q, wt_q_ld = self._lin_b(self.rcnn_transform_layer, 0, 1024)      # the two column halves of Wt [64][2048]
-        wt_a, wt_a_ld = self._lin_b(self.rcnn_transform_layer, 1024, 1024)
+        product = self.attention_type == "product"
         w1b3, w1ld = self._lin_b(self.output_score_layer.linear1)
-        if fold_pe:
-            tr_q, tr_q_ld = qt.view(-1)[dq:], qld  # the second column block of the fused projection
+        if product:  # dana.py:285-288: transform(query_mat * attended), Wt [64][1024]
+            wt_a, wt_a_ld = self._lin_b(self.rcnn_transform_layer)
+            tr_q, tr_q_ld = None, 0
         else:
-            tr_q = ops.gemm_nt(q_pe, wt_q, n_roi * P2, self.rcnn_dim, 1024, ldb=wt_q_ld, shift=bt_)  # [n*49][64]
-            tr_q_ld = self.rcnn_dim
+            wt_q, wt_q_ld = self._lin_b(self.rcnn_transform_layer, 0, 1024)      # the two column halves of Wt [64][2048]
+            wt_a, wt_a_ld = self._lin_b(self.rcnn_transform_layer, 1024, 1024)
+            if fold_pe:
+                tr_q, tr_q_ld = qt.view(-1)[dq:], qld  # the second column block of the fused projection
+            else:
+                tr_q = ops.gemm_nt(q_pe, wt_q, n_roi * P2, self.rcnn_dim, 1024, ldb=wt_q_ld, shift=bt_)  # [n*49][64]
+                tr_q_ld = self.rcnn_dim
         q_ready = ops.record_event()
 
         # cls_prob of both heads in one buffer (positive rows, then negative rows: the torch.cat of dana.py:193)
@@ -1163,8 +1182,12 @@ class DAnARCNN(nn.Module):
                 dense = torch.empty((n_roi * P2, 1024), dtype=torch.float32, device=dev)
                 ops.gemm_nt(sc2, st2, R * P2, 1024, K2p, lda=K2p, ldb=K2p, out=dense, ldc=1024, batch=B,
                             batch_a=R * P2 * K2p, batch_b=1024 * K2p, batch_c=R * P2 * 1024, k_true=K2)
-                tr = ops.gemm_nt(dense, wt_a, n_roi * P2, rd_, 1024, ldb=wt_a_ld,
-                                 residual=tr_q, ldr=tr_q_ld)  # [n*49][64] == [n][3136]
+                if product:
+                    ops.mul_rows_(dense, q_pe, n_roi * P2, 1024)  # query_mat * attended (dana.py:286)
+                    tr = ops.gemm_nt(dense, wt_a, n_roi * P2, rd_, 1024, ldb=wt_a_ld, shift=bt_)
+                else:
+                    tr = ops.gemm_nt(dense, wt_a, n_roi * P2, rd_, 1024, ldb=wt_a_ld,
+                                     residual=tr_q, ldr=tr_q_ld)  # [n*49][64] == [n][3136]
             hid = ops.gemm_nt(tr, w1b3, n_roi, w1.size(0), P2 * self.rcnn_dim, ldb=w1ld, shift=b1, relu=True)
             score = ops.gemm_nt(hid, w2, n_roi, 2, w1.size(0), shift=b2)
             prob = ops.softmax_rows_to(score, prob_all[(n_roi if offset else 0):], n_roi, 2)[:n_roi]

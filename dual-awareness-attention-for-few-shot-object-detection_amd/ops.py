@@ -1366,6 +1366,12 @@ def axpy_rows_(y, x, rows, channels, ld_y=0, ld_x=0, alpha=1.0, accumulate=True)
     return y
 
 
+def mul_rows_(y, x, rows, channels, ld_y=0, ld_x=0):
+    """y *= x over strided rows (attention_type 'product')"""
+    lib().call("dana_mul_rows", _p(_chk(y, "y")), _p(_chk(x, "x")), rows, channels, ld_y, ld_x, _stream())
+    return y
+
+
 def rowscale_(dw, scale, rows, cols):
     lib().call("dana_rowscale", _p(_chk(dw, "dw")), _p(_chk(scale, "scale")), rows, cols, _stream())
     return dw

@@ -119,6 +119,18 @@ def tame_fsod_weights(sd):
     return sd
 
 
+def tame_product_weights(sd):
+    """test-profile weights for attention_type='product' (dana.py:155-156,285-286): query * attended has ~10x the magnitude
+    of the concatenated features, so the two layers that consume it are scaled down to keep the RPN objectness logits and
+    the class scores away from saturation (the reference's CPU NMS re-sorts tied scores in an unstable order,
+    nms_cpu.cpp:24: saturated scores make the proposal order arbitrary). Applied identically by the golden generator and
+    the tests."""
+    sd = dict(sd)
+    sd["RCNN_rpn.RPN_Conv.weight"] = sd["RCNN_rpn.RPN_Conv.weight"] * 0.05
+    sd["rcnn_transform_layer.weight"] = sd["rcnn_transform_layer.weight"] * 0.05
+    return sd
+
+
 def tame_fgn_weights(sd):
     """test-profile weights for the `fgn` sibling: its RPN runs on base_feat * mean(support) (magnitude ~7x base_feat),
     so RPN_Conv is scaled down to keep the objectness logits away from saturation (exactly tied scores make the proposal

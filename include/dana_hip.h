@@ -452,6 +452,9 @@ int dana_relu_mask(float* grad, const float* act, long rows, int channels, long 
                    dana_stream_t stream);                       /* grad *= (saved output > 0) */
 int dana_axpy_rows(float* y, const float* x, long rows, int channels, long ld_y, long ld_x, float alpha,
                    int accumulate, dana_stream_t stream);        /* y (+)= alpha * x, strided rows */
+/* y *= x over strided rows: the correlation of attention_type 'product' (dana.py:155-156: base_feat * dense_support_feature;
+ * :285-286: query_mat * dense_support_feature), in place in the attended buffer */
+int dana_mul_rows(float* y, const float* x, long rows, int channels, long ld_y, long ld_x, dana_stream_t stream);
 int dana_rowscale(float* dw, const float* scale, int rows, long cols, dana_stream_t stream); /* frozen-BN scale on dW rows */
 int dana_unpack_conv_weight_grad(const float* packed, float* w_oihw, int cout, int cin, int kh, int kw, int accumulate,
                                  dana_stream_t stream);          /* packed [O][KH][KW][I] -> OIHW (.grad layout) */

@@ -218,6 +218,8 @@ def rpn_attention(base_feat, pos_support_feat, sd, n_shot, use_ba, inter=None):
     if inter is not None:
         inter["rpn_q"] = q
         inter["dense_support_feature"] = dense
+    if sd["RCNN_rpn.RPN_Conv.weight"].shape[1] == 1024:  # attention_type 'product' (dana.py:155-156): _RPN(1024)
+        return base_feat * dense
     return torch.cat([base_feat, dense], 1)
 
 
@@ -423,7 +425,10 @@ def rcnn_head(pooled, support_pooled, sd, n_shot, inter=None):
         a = a + 0.1 * u.transpose(1, 2)
         feats.append(torch.bmm(a, s))
     dense = torch.stack(feats, 0).mean(0)
-    corr = _lin(torch.cat([qmat, dense], 2), sd, "rcnn_transform_layer")
+    if sd["rcnn_transform_layer.weight"].shape[1] == 1024:  # attention_type 'product' (dana.py:285-286)
+        corr = _lin(qmat * dense, sd, "rcnn_transform_layer")
+    else:
+        corr = _lin(torch.cat([qmat, dense], 2), sd, "rcnn_transform_layer")
     x = F.relu(_lin(corr.reshape(n_roi, -1), sd, "output_score_layer.linear1"))
     score = _lin(x, sd, "output_score_layer.linear2")
     if inter is not None:

@@ -125,11 +125,13 @@ def R_iou(a, b):
     return it / ((a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1) + (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1) - it)
 
 
-def e2e(tag, use_ba, training, B, way, shot, H, W, nms_seed=7, slim=False):
+def e2e(tag, use_ba, training, B, way, shot, H, W, nms_seed=7, slim=False, attention_type="concat"):
     """Run reference + oracle on the seeded episode; store reference outputs (slim: the eight outputs only, no strided
     intermediates -- the full-size train-mode fixtures stay a few tens of KB)."""
-    m = R.build_model(use_ba, way, shot)
+    m = R.build_model(use_ba, way, shot, attention_type)
     sd = S.fill_state_dict(m.state_dict(), seed=11, profile="test")
+    if attention_type == "product":
+        sd = S.tame_product_weights(sd)
     m.load_state_dict(sd)
     im_data, im_info, gt, nb, sup = S.episode_inputs(B, way if training else 1, shot, H, W, seed=1996)
     m.train() if training else m.eval()
@@ -172,7 +174,8 @@ def e2e(tag, use_ba, training, B, way, shot, H, W, nms_seed=7, slim=False):
         assert diff <= tol, (n, diff)
         store[n] = a.numpy()
     if slim:
-        store["meta"] = np.array([int(use_ba), int(training), B, way, shot, H, W, 11, 1996, nms_seed])
+        store["meta"] = np.array([int(use_ba), int(training), B, way, shot, H, W, 11, 1996, nms_seed,
+                                  int(attention_type == "product")])
         save("e2e_" + tag, **store)
         return
     # strided intermediates from the ORACLE trace (pinned to the reference through the outputs above)
@@ -208,7 +211,8 @@ def e2e(tag, use_ba, training, B, way, shot, H, W, nms_seed=7, slim=False):
             store["dets_" + thr_tag] = dets.numpy()
             store["dets_tied_scores"] = np.array(sorted(tied), dtype=np.float32)
             print("  postprocess thresh %.2f: %d detections" % (thr, dets.shape[0]))
-    store["meta"] = np.array([int(use_ba), int(training), B, way, shot, H, W, 11, 1996, nms_seed])
+    store["meta"] = np.array([int(use_ba), int(training), B, way, shot, H, W, 11, 1996, nms_seed,
+                              int(attention_type == "product")])
     save("e2e_" + tag, **store)
 
 
@@ -345,6 +349,9 @@ if __name__ == "__main__":
         print("eval 192x256 BA off"); e2e("eval_small_cisa", False, False, 1, 1, 3, 192, 256)
         print("eval 192x256 BA on"); e2e("eval_small_ba", True, False, 1, 1, 3, 192, 256)
         print("train 192x256 B=2 BA on"); e2e("train_small_ba", True, True, 2, 2, 3, 192, 256)
+        # attention_type='product' (dana.py:74-77,155-156,285-286: valid reference code that utils.get_model never selects)
+        print("eval 192x256 product"); e2e("eval_small_product", True, False, 1, 1, 3, 192, 256, slim=True, attention_type="product")
+        print("train 192x256 B=2 product"); e2e("train_small_product", True, True, 2, 2, 3, 192, 256, slim=True, attention_type="product")
         print("fgn eval 192x256"); e2e_fgn("eval_small", False, 1, 1, 3, 192, 256)
         print("fgn train 192x256 B=2"); e2e_fgn("train_small", True, 2, 2, 3, 192, 256)
         print("fsod eval 192x256"); e2e_fsod("eval_small", False, 1, 1, 3, 192, 256)

@@ -94,9 +94,9 @@ def load():
     return _state
 
 
-def build_model(use_ba, way, shot):
+def build_model(use_ba, way, shot, attention_type="concat"):
     r = load()
-    m = r["dana"].DAnARCNN(["fg", "bg"], "concat", 256, 256, pretrained=False, semantic_enhance=use_ba,
+    m = r["dana"].DAnARCNN(["fg", "bg"], attention_type, 256, 256, pretrained=False, semantic_enhance=use_ba,
                            num_way=way, num_shot=shot)
     m.create_architecture()
     return m

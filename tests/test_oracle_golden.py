@@ -63,14 +63,28 @@ def test_positional_encoding(G):
         assert np.array_equal(O.positional_encoding(L)[0, ::7, ::37].numpy(), G["pe%d_sample" % L])
 
 
-@pytest.mark.parametrize("tag", ["eval_small_cisa", "eval_small_ba", "train_small_ba"])
+@pytest.mark.parametrize("tag", ["eval_small_cisa", "eval_small_ba", "train_small_ba", "eval_small_product",
+                                 "train_small_product"])
 def test_oracle_forward_reproduces_reference_outputs(golden_dir, tag):
+    """(the *_product fixtures: attention_type='product', dana.py:74-77,155-156,285-286 -- the oracle takes the type from the
+    shapes of RCNN_rpn.RPN_Conv / rcnn_transform_layer in the state dict)"""
     import dana_amd
     from dana_amd import synthetic as S
+    from dana_amd.dana import DAnARCNN
     g = np.load(os.path.join(golden_dir, "e2e_%s.npz" % tag))
-    use_ba, training, B, way, shot, H, W, wseed, iseed, nseed = [int(v) for v in g["meta"]]
-    m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=bool(use_ba), way=way, shot=shot, classes=["fg", "bg"])
+    use_ba, training, B, way, shot, H, W, wseed, iseed, nseed = [int(v) for v in g["meta"][:10]]
+    if len(g["meta"]) > 10 and int(g["meta"][10]):
+        m = DAnARCNN(["fg", "bg"], "product", 256, 256, pretrained=False, semantic_enhance=bool(use_ba), num_way=way,
+                     num_shot=shot)
+        m.create_architecture()
+        assert m.RCNN_rpn.RPN_Conv.weight.shape[1] == 1024 and m.rcnn_transform_layer.weight.shape == (64, 1024)
+        product = True
+    else:
+        product = False
+        m = dana_amd.get_model("DAnA", pretrained=False, use_BA_block=bool(use_ba), way=way, shot=shot, classes=["fg", "bg"])
     sd = S.fill_state_dict(m.state_dict(), seed=wseed, profile="test")
+    if product:
+        sd = S.tame_product_weights(sd)
     inputs = S.episode_inputs(B, way if training else 1, shot, H, W, seed=iseed)
     np.random.seed(nseed)
     torch.set_num_threads(8)
