@@ -56,7 +56,15 @@ at::Tensor nms(const at::Tensor& dets, const at::Tensor& scores, double threshol
                  ws2.data_ptr(), (size_t)ws2.numel(), stream_of(d)), "dana_nms");
   const int k = num.item<int>();  // the variable-length result needs the count on the host, as the reference's host scan
   const auto kept = idx.index_select(0, keep.slice(0, 0, k).to(at::kLong));
-  return std::get<0>(at::sort(kept));
+  if (k == 0 || n >= (1 << 24)) return k == 0 ? kept : std::get<0>(at::sort(kept));
+  // ascending ORIGINAL indices (nms.cu:125-131): this library's own sort on the negated indices (exact in fp32 below 2^24)
+  const auto neg = kept.to(at::kFloat).neg().contiguous();
+  auto order2 = at::empty({1, k}, d.options().dtype(at::kInt));
+  auto sorted2 = at::empty({1, k}, d.options());
+  auto ws3 = at::empty({(int64_t)dana_sort_desc_workspace_bytes(1, k) + 16}, d.options().dtype(at::kByte));
+  check(dana_sort_desc(neg.data_ptr<float>(), 1, k, order2.data_ptr<int>(), sorted2.data_ptr<float>(), ws3.data_ptr(),
+                       (size_t)ws3.numel(), stream_of(d)), "dana_sort_desc");
+  return sorted2.view({k}).neg().to(at::kLong);
 }
 
 // shape / dtype / device contract shared by the RoI operators (ROIAlign.h:11-42, ROIPool.h:11-41: 4-D float maps,

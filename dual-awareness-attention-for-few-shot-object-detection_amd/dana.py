@@ -382,7 +382,12 @@ class DAnARCNN(nn.Module):
     # the training iteration (profiles/r5_role_streams.md). So all five are created together, in this order, at the first
     # request, and used once -- streams that a caller creates later (graph capture, RCCL) cannot move them -- and no role
     # creates more.
+    # ONE DRIVER THREAD PER DEVICE: the five streams are per process and device, shared by every model instance on it.
+    # Two host threads driving two models on the SAME device would interleave their launches on these streams (and an
+    # eager forward of one would issue into a capture of the other) -- the supported multi-threaded form is the
+    # reference's: one thread per device (nn.DataParallel, train.py:104-105), one process per GPU in the Trainer.
     _ROLE_STREAMS = ("support", "targets", "layer4", "neg_head", "wgrad")
+    _untouched = set()  # devices whose role streams were created inside a capture and have not taken their queues yet
     _role_streams = {}  # (role, device) -> stream; per PROCESS, shared by every model on the device (a second model -- the
     #                     bench's secondary workloads, a sibling -- must not open five more and land on other queues)
 
@@ -403,6 +408,14 @@ class DAnARCNN(nn.Module):
                     with torch.cuda.stream(r):
                         torch.zeros(1, device=dev)
             st = DAnARCNN._role_streams[key]
+            if not touch:
+                DAnARCNN._untouched.add(str(dev))
+        elif str(dev) in DAnARCNN._untouched and not torch.cuda.is_current_stream_capturing():
+            # created inside a capture (no launch possible there): take the hardware queues now, in role order
+            DAnARCNN._untouched.discard(str(dev))
+            for role in self._ROLE_STREAMS:
+                with torch.cuda.stream(DAnARCNN._role_streams[(role, str(dev))]):
+                    torch.zeros(1, device=dev)
         return st
 
     def _rng_counter(self, dev):
@@ -746,7 +759,7 @@ class DAnARCNN(nn.Module):
         shot = self.n_shot
         way = self.n_way if training else 1  # eval reshapes supports as [*, n_shot] (dana.py:111)
         inter = getattr(self, "_capture", None)
-        tl = getattr(self, "_timeline", None)  # optional host-side phase clock (tools/hosttime.py)
+        tl = getattr(self, "_timeline", None)  # optional host-side phase clock (debug)
         if tl is not None:
             import time as _time
             tl.append(("begin", _time.perf_counter()))

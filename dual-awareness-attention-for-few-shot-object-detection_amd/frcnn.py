@@ -7,10 +7,8 @@ to autograd (`_LossBridge`), `loss.backward()` runs backward.frcnn_backward / me
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
-from . import targets as T
 from .config import cfg
 from .dana import DAnARCNN, _LossBridge, _RPNParams
 
@@ -152,10 +150,10 @@ class FasterRCNN(DAnARCNN):
         RCNN_loss_cls = RCNN_loss_bbox = 0
         rpn_loss_cls, rpn_loss_bbox = st["rpn_loss_cls"], st["rpn_loss_bbox"]
         if self.training:  # faster_rcnn.py:93-98
-            if ctx is None:
-                RCNN_loss_cls = F.cross_entropy(cls_score, st["rois_label"])
-                RCNN_loss_bbox = T._smooth_l1_loss(bbox_pred, st["rois_target"], st["rois_inside_ws"],
-                                                   st["rois_outside_ws"])
+            if ctx is None:  # the same fused launch, without the gradient seeds
+                l2, _ = ops.plain_rcnn_losses(cls_score, st["rois_label"], bbox_pred, st["rois_target"],
+                                              st["rois_inside_ws"], st["rois_outside_ws"], with_grad=False)
+                RCNN_loss_cls, RCNN_loss_bbox = l2[0], l2[1]
             else:
                 # the two loss tails ([n_roi][2], [n_roi][4]) and their gradient seeds: one HIP launch (dana_plain_rcnn_loss)
                 l2, (d_cls, d_bbox) = ops.plain_rcnn_losses(cls_score, st["rois_label"], bbox_pred, st["rois_target"],

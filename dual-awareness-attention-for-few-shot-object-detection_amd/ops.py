@@ -10,7 +10,7 @@ import torch
 
 from ._lib import lib, DanaError  # noqa: F401
 
-HOST_WAIT = [0.0]  # seconds the host spent blocked in the training forward's one D2H read (bench.py / tools/hosttime.py)
+HOST_WAIT = [0.0]  # seconds the host spent blocked in the training forward's one D2H read (bench.py, tools/program_hostprof.py)
 
 NCHW, NHWC = 0, 1
 EPI_RELU, CONV_STEM7, W_SPLIT3, A_SPLIT3 = 1, 2, 256, 512
@@ -292,8 +292,15 @@ def nms(dets, scores, threshold, inclusive=False):
     boxes = dets[order[0].long()].contiguous().view(1, -1, 4)
     keep, num = nms_sorted(boxes, threshold, inclusive)
     k = int(num[0].item())
-    kept = order[0][keep[0, :k].long()].long()
-    return torch.sort(kept)[0]
+    if k == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dets.device)
+    kept = order[0][keep[0, :k].long()]
+    # ascending ORIGINAL indices (nms.cu:125-131 returns them sorted): this library's own sort on the negated indices
+    # (exact in fp32 below 2^24 boxes) -- no torch / rocPRIM sort kernel on the operator's path either
+    if dets.size(0) >= (1 << 24):
+        return torch.sort(kept.long())[0]
+    _, neg_sorted = sort_desc((-kept.float()).view(1, -1))
+    return (-neg_sorted[0]).long()
 
 
 def proposal_layer(cls, cls_strides, cls_is_prob, bbox, bbox_strides, im_info, base_anchors, B, A, H, W,

@@ -70,7 +70,7 @@ int dana_roi_align_forward(const float* input, const float* rois, float* output,
 /* ROIAlign_backward: lib/model/csrc/ROIAlign.h:27-45 -> cuda/ROIAlign_cuda.cu:308-346.
  * grad_in [B][C][H][W] (NCHW) or [B][H][W][C] (NHWC) is completely (over)written: NCHW zero-fills it and scatters with
  * fp32 atomics like the reference (unordered sum); NHWC (channels % 4 == 0, pooled sides <= 8) gathers per feature cell
- * in a fixed (roi, bin) order -- no atomics, bit-reproducible (DANA_ROI_BWD_GATHER=0: the atomic scatter). */
+ * in a fixed (roi, bin) order -- no atomics, bit-reproducible. */
 int dana_roi_align_backward(const float* grad_out, const float* rois, float* grad_in, int batch, int channels,
                             int height, int width, int num_rois, float spatial_scale, int pooled_h,
                             int pooled_w, int sampling_ratio, int layout, dana_stream_t stream);
