@@ -57,18 +57,20 @@ def _make_layer(inplanes, planes, blocks, stride):
 
 
 class _ResNet50Params(nn.Module):
-    """resnet50() of resnet.py:188 (layers [3,4,6,3]); init as resnet.py:122-128."""
+    """resnet50() of resnet.py:188 (layers [3,4,6,3]); init as resnet.py:122-128. layers=(3, 4, 23, 3): resnet101()'s
+    trunk (resnet.py:199), which the reference defines but DAnARCNN never builds (dana.py:337 calls resnet50() whatever
+    num_layers says) -- an opt-in here (DAnARCNN.trunk_layers) for BASELINE configs[3], checked against the oracle only."""
 
-    def __init__(self):
+    def __init__(self, layers=(3, 4, 6, 3)):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=0, ceil_mode=True)
-        self.layer1 = _make_layer(64, 64, 3, 1)
-        self.layer2 = _make_layer(256, 128, 4, 2)
-        self.layer3 = _make_layer(512, 256, 6, 2)
-        self.layer4 = _make_layer(1024, 512, 3, 2)
+        self.layer1 = _make_layer(64, 64, layers[0], 1)
+        self.layer2 = _make_layer(256, 128, layers[1], 2)
+        self.layer3 = _make_layer(512, 256, layers[2], 2)
+        self.layer4 = _make_layer(1024, 512, layers[3], 2)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
@@ -219,8 +221,12 @@ class DAnARCNN(nn.Module):
         self._init_modules()
         self._init_weights()
 
+    # blocks per trunk stage. The reference builds resnet50() unconditionally (dana.py:337); (3, 4, 23, 3) -- set BEFORE
+    # create_architecture() -- is resnet.py:199's resnet101 trunk for BASELINE configs[3]: no reference run exists for it
+    trunk_layers = (3, 4, 6, 3)
+
     def _init_modules(self):
-        resnet = _ResNet50Params()
+        resnet = _ResNet50Params(tuple(self.trunk_layers))
         if self.pretrained:
             print("Loading pretrained weights from %s" % (self.model_path))
             state_dict = torch.load(self.model_path)

@@ -131,6 +131,16 @@ def tame_product_weights(sd):
     return sd
 
 
+def tame_res101_weights(sd):
+    """test-profile weights for the opt-in resnet101 trunk (DAnARCNN.trunk_layers = (3, 4, 23, 3)): 17 more residual
+    blocks in layer3 leave base_feat ~6x larger than the res50 profile was tuned for, so the RPN conv is scaled down to
+    keep objectness logits and box deltas away from saturation / the unclamped exp of bbox_transform_inv. Applied
+    identically by the tests and bench.py."""
+    sd = dict(sd)
+    sd["RCNN_rpn.RPN_Conv.weight"] = sd["RCNN_rpn.RPN_Conv.weight"] * 0.1
+    return sd
+
+
 def tame_fgn_weights(sd):
     """test-profile weights for the `fgn` sibling: its RPN runs on base_feat * mean(support) (magnitude ~7x base_feat),
     so RPN_Conv is scaled down to keep the objectness logits away from saturation (exactly tied scores make the proposal

@@ -166,9 +166,12 @@ def rcnn_base(x, sd):
     """dana.py:344-345: conv1, bn1, relu, maxpool, layer1..3 (keys RCNN_base.0/1/4/5/6)"""
     x = F.relu(_bn(F.conv2d(x, sd["RCNN_base.0.weight"], stride=2, padding=3), sd, "RCNN_base.1"))
     x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
-    x = layer(x, sd, "RCNN_base.4", 3, 1)
-    x = layer(x, sd, "RCNN_base.5", 4, 2)
-    return layer(x, sd, "RCNN_base.6", 6, 2)
+    # blocks per stage from the state dict itself: [3, 4, 6] for resnet50() (what dana.py:337 always builds), [3, 4, 23]
+    # for the resnet101 trunk of resnet.py:199 (the build's opt-in for BASELINE configs[3])
+    nb = [1 + max(int(k.split(".")[2]) for k in sd if k.startswith("RCNN_base.%d." % s)) for s in (4, 5, 6)]
+    x = layer(x, sd, "RCNN_base.4", nb[0], 1)
+    x = layer(x, sd, "RCNN_base.5", nb[1], 2)
+    return layer(x, sd, "RCNN_base.6", nb[2], 2)
 
 
 def rcnn_top(x, sd):

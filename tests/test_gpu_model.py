@@ -164,6 +164,55 @@ def test_eval_forward_vs_oracle_fresh_inputs_cuda_nms_rule(dev):
     assert np.abs(out[2].cpu().numpy() - ref[2].numpy())[matched].max() <= 1e-4
 
 
+def test_res101_trunk_opt_in_vs_oracle(dev):
+    """BASELINE configs[3]'s well-defined half: the resnet101 trunk of resnet.py:199 ([3, 4, 23, 3] blocks) behind
+    DAnARCNN.trunk_layers. The reference never builds it (dana.py:337: resnet50() whatever num_layers says), so there is no
+    reference golden: the oracle (pinned to the reference on the res50 goldens, its trunk loop driven by the state dict's
+    own block count) is the checker -- eval forward, and one training iteration's losses under the same np.random stream."""
+    from dana_amd import synthetic as S
+    from dana_amd.dana import DAnARCNN
+    from dana_amd.trainer import Trainer
+    from oracle import model_ref as O
+    torch.set_num_threads(min(64, max(torch.get_num_threads(), os.cpu_count() or 1)))
+
+    def build(way, shot):
+        m = DAnARCNN(["fg", "bg"], "concat", 256, 256, pretrained=False, semantic_enhance=True, num_way=way, num_shot=shot)
+        m.trunk_layers = (3, 4, 23, 3)
+        m.create_architecture()
+        assert len(m.RCNN_base[6]) == 23 and len(m.state_dict()) == 346 + 17 * 18  # 17 more bottlenecks x 18 tensors
+        sd = S.tame_res101_weights(S.fill_state_dict(m.state_dict(), seed=11, profile="test"))
+        m.load_state_dict(sd)
+        return m.to(dev), sd
+
+    m, sd = build(1, 2)
+    m.eval()
+    inputs = S.episode_inputs(1, 1, 2, 160, 224, seed=77)
+    with torch.no_grad():
+        out = m(*[t.to(dev) for t in inputs])
+        ref = O.forward(sd, *inputs, False, 1, 2, True, nms_inclusive=False)
+    r, rg = out[0].cpu().numpy().reshape(-1, 5), ref[0].numpy().reshape(-1, 5)
+    matched = _iou(r[:, 1:], rg[:, 1:]) >= 1 - 1e-3
+    assert matched.mean() >= 0.99
+    assert np.abs(out[1].cpu().numpy() - ref[1].numpy())[matched].max() <= 1e-4
+    assert np.abs(out[2].cpu().numpy() - ref[2].numpy())[matched].max() <= 1e-4
+    # train mode: forward losses vs the oracle, then one Trainer iteration moves all 23 layer-3 blocks
+    m, sd = build(2, 2)
+    m.train()
+    tin = S.episode_inputs(1, 2, 2, 160, 224, seed=9)
+    np.random.seed(3)
+    with torch.no_grad():
+        ref_t = O.forward(sd, *tin, True, 2, 2, True, nms_inclusive=False)
+    tr = Trainer(m, 1e-3)
+    w0 = m.RCNN_base[6][22].conv2.weight.detach().clone()
+    np.random.seed(3)
+    out_t = tr.step(*[t.to(dev) for t in tin])
+    torch.cuda.synchronize()
+    for a_, b_ in zip(out_t[3:5], ref_t[3:5]):
+        assert abs(float(a_.detach()) - float(b_)) <= 1e-4 * max(1.0, abs(float(b_)))
+    assert not torch.equal(w0, m.RCNN_base[6][22].conv2.weight.detach())
+    assert all(torch.isfinite(p_).all() for p_ in m.parameters())
+
+
 def test_product_attention_type_trains_only_forward(dev):
     """attention_type='product': forward in both modes on the HIP kernels (goldens above); a forward that would save for
     the backward says so instead of producing gradients of another model"""
