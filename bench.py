@@ -786,13 +786,13 @@ def main():
             result["roofline"].update(pmc)
         else:
             try:
-                with open(os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r6_pmc_traffic.json")) as fh:
                     j = json.load(fh)
                 pre = traffic_kernel.replace(" ", "").rstrip(">")
                 ms_ = [v for k, v in j.items() if k.replace(" ", "").startswith(pre)]
                 result["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ms_) /
                                                       sum(v["launches"] for v in ms_))
-                result["roofline"]["traffic_source"] = "profiles/r5_pmc_traffic.json (committed PMC run, not this run)"
+                result["roofline"]["traffic_source"] = "profiles/r6_pmc_traffic.json (committed PMC run, not this run)"
             except (OSError, KeyError, ValueError, ZeroDivisionError):
                 pass
         if tprof is not None:

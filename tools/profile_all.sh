@@ -28,7 +28,8 @@ run_stats default --launch eager $COMMON
 run_stats single_stream --launch eager $COMMON --single-stream
 if [ "$2" != cfg4 ]; then
   run_stats graph --launch graph $COMMON
-  run_stats train_step --launch eager --mode step --steps 10 --warmup 5 --no-cpu-baseline
+  run_stats program --launch program $COMMON
+  run_stats train_step --launch program --mode step --steps 10 --warmup 5 --no-cpu-baseline
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
@@ -43,5 +44,9 @@ python $R/tools/secondary.py $O/single_stream_kernel_stats.csv $O/pmc_traffic.js
 cd $R && python bench.py $CFG --dump-launches $O/launches.txt > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
 if [ "$2" != cfg4 ]; then
   python tools/phase_times.py 30 > $O/phase_times.txt 2>&1
-  python tools/chain_bound.py 300 > $O/chain_bound.md 2>&1
+  python tools/roundtrip_gap.py 2>&1 | grep -v amdgpu.ids > $O/roundtrip_gap.txt
+  python tools/program_hostprof.py 20 2>&1 | grep -v amdgpu.ids > $O/program_hostprof.txt
+  python tools/stress_host_8proc.py 8 8 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" > $O/host_8proc.md
+  bash tools/exposed_time.sh step program > $O/exposed_time_step.txt 2>&1
+  bash tools/exposed_time.sh train program rcnn_loss_c > $O/exposed_time_forward.txt 2>&1
 fi
