@@ -911,6 +911,25 @@ def main():
                         "as one hipGraph", "value": round(args.batch * kd / dtd, 3), "unit": "query-images/sec",
                 "ms_per_step": round(1e3 * dtd / kd, 3), "steps": kd}
             del rung
+            if use_programs or args.launch in ("auto", "program"):
+                # ... and as ONE launch program: no host round trip AND the eager step's GPU schedule -- what the sync-free
+                # design of row N2 exists for (the one-graph replay loses 6-8 % on the GPU to hipGraphLaunch's scheduling)
+                from dana_amd.program import ProgramDAnA
+                runp = ProgramDAnA(model, *inputs)
+                for _ in range(5):
+                    runp(*runp.inputs)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(kd):
+                    runp(*runp.inputs)
+                torch.cuda.synchronize()
+                dtp = time.perf_counter() - t0
+                result["device_rng_one_program"] = {
+                    "what": "the same device-RNG forward replayed as one launch program (program.py): no host round trip, the "
+                            "eager step's own launches on its own streams", "value": round(args.batch * kd / dtp, 3),
+                    "unit": "query-images/sec", "ms_per_step": round(1e3 * dtp / kd, 3), "steps": kd,
+                    "host_enqueue_ms_per_step": host_enqueue_ms(lambda: runp(*runp.inputs), 20)}
+                del runp
         finally:
             model.device_rng = False
     if rank == 0 and world == 1 and args.mode == "train" and args.ba and not args.no_secondary and args.model == "DAnA":
@@ -1053,6 +1072,7 @@ def main():
             "configs_4": {"img_s": pick("configs_4", "value"), "ms": pick("configs_4", "ms_per_step"), "frac": pick("configs_4", "roofline", "frac")},
             "configs_3": {"img_s": pick("configs_3", "value"), "ms": pick("configs_3", "ms_per_step"), "frac": pick("configs_3", "roofline", "frac")},
             "configs_1": pick("configs_1_cisa_only", "value"), "device_rng_one_graph": pick("device_rng_one_graph", "value"),
+            "device_rng_one_program": pick("device_rng_one_program", "value"),
             "cpu_img_s": pick("cpu_baseline", "value"),
         }
         cb = result.pop("cpu_baseline", None)

@@ -151,6 +151,30 @@ int dana_program_add_event_wait(void* program, void* event, dana_stream_t stream
   return DANA_OK;
 }
 
+// The three torch ops a recorded backward consists of besides this library's launches (zeros / zero_, copy_ / clone between
+// device tensors, grad.add_): as entry points, so that a launch program re-issues them from the same C loop
+int dana_fill_zero(void* dst, size_t bytes, dana_stream_t stream) {
+  if (bytes == 0) return DANA_OK;
+  DANA_CHECK_ARG(dst, "dana_fill_zero: null pointer");
+  const hipError_t e = hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    dana_set_error("dana_fill_zero: %s", hipGetErrorString(e));
+    return DANA_ERR_HIP;
+  }
+  return DANA_OK;
+}
+
+int dana_copy_d2d(void* dst, const void* src, size_t bytes, dana_stream_t stream) {
+  if (bytes == 0) return DANA_OK;
+  DANA_CHECK_ARG(dst && src, "dana_copy_d2d: null pointer");
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    dana_set_error("dana_copy_d2d: %s", hipGetErrorString(e));
+    return DANA_ERR_HIP;
+  }
+  return DANA_OK;
+}
+
 int dana_program_size(void* program) {
   return program ? (int)((Program*)program)->entries.size() : 0;
 }

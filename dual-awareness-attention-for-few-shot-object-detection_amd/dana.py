@@ -805,8 +805,9 @@ class DAnARCNN(nn.Module):
             if self.device_rng:  # counter-based device RNG (opt-in): (seed, 2 * forward counter [+ 1])
                 rng = (int(self.rng_seed), 2 * self._rng_calls)
                 self._rng_calls += 1
-                if capturing:
-                    # inside a hipGraph the call counter must be DATA: a uint64 in device memory, advanced by the graph
+                if capturing or getattr(self, "_rng_counter_as_data", False):  # (a launch-program recording: program.py)
+                    # inside a hipGraph / a launch program the call counter must be DATA: a uint64 in device memory,
+                    # advanced by the replay itself
                     ctr = self._consts.get(("rng_counter", str(dev)))
                     if ctr is None:
                         raise RuntimeError("capture with device_rng needs model._rng_counter(device) created BEFORE the "

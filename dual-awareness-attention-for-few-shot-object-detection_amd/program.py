@@ -75,6 +75,9 @@ class _AtenRecorder(TorchDispatchMode):
         if name == "contiguous" or (torch.is_tensor(out) and any(out is t for t in tens) and not name.endswith("_")):
             return out  # returned its input unchanged
         st = ops._get_cur(ops._raw_device())
+        if prog._as_call(name, args, kwargs, out, tens):
+            prog.keep.append(out)
+            return out  # (re-issued by the C loop: a fill, a device-to-device copy or an axpy of this library)
         if name.endswith("_") or func.__name__.endswith(".out"):
             prog._add((_ATEN, func, (args, kwargs, st)))            # in place / into a given output: the same call again
         elif name in ("zeros", "zeros_like"):
@@ -127,6 +130,37 @@ class LaunchProgram:
             else:
                 conv.append(ty(a))  # converted ONCE: the replay hands ctypes its own types
         self.entries.append((_CALL, fn, tuple(conv)))
+
+    def _as_call(self, name, args, kwargs, out, tens):
+        """the backward's three torch ops -- zeros / zero_, copy_ / clone between device tensors, grad.add_ -- as C-ABI
+        entries of the program (same bytes / same fp32 additions), so that they sit INSIDE the C loop's runs instead of
+        cutting them; anything else stays a torch entry"""
+        if not torch.is_tensor(out) or not out.is_cuda or not out.is_contiguous() or kwargs.get("alpha", 1) != 1:
+            return False
+        L, s = _lib.lib(), ops._stream()
+        nbytes = out.numel() * out.element_size()
+        if name in ("zeros", "zeros_like", "zero_"):
+            self.add_call(L.fn["dana_fill_zero"], "dana_fill_zero", (out.data_ptr(), nbytes, s))
+            return True
+        src = None
+        if name == "copy_" and len(args) >= 2 and torch.is_tensor(args[1]):
+            src = args[1]
+        elif name in ("clone", "_to_copy") and len(tens) == 1:
+            src = tens[0]
+        if src is not None:
+            if (src.is_cuda and src.is_contiguous() and src.dtype == out.dtype and src.numel() == out.numel()
+                    and src.device == out.device):
+                self.add_call(L.fn["dana_copy_d2d"], "dana_copy_d2d", (out.data_ptr(), src.data_ptr(), nbytes, s))
+                return True
+            return False
+        if name == "add_" and len(args) == 2 and torch.is_tensor(args[1]):
+            x = args[1]
+            if (x.is_cuda and x.is_contiguous() and x.dtype == out.dtype == torch.float32 and x.numel() == out.numel()
+                    and out.numel() % 4 == 0 and out.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and out.numel() > 0):
+                self.add_call(L.fn["dana_axpy_rows"], "dana_axpy_rows", (out.data_ptr(), x.data_ptr(), 1, out.numel(), 0, 0, 1.0,
+                                                                          1, s))
+                return True
+        return False
 
     def host_callback(self, fn):
         """run `fn()` now (unrecorded) and again at this position of every replay: a host-side step that must stay live
@@ -327,27 +361,34 @@ class ProgramDAnA:
             raise RuntimeError("ProgramDAnA needs HIP tensors")
         if not hasattr(model, "_forward_gen"):
             raise RuntimeError("ProgramDAnA drives DAnARCNN (the siblings run eagerly)")
-        if getattr(model, "device_rng", False) and model.training:
-            # a launch program bakes the Philox call counter in as a launch ARGUMENT; in a hipGraph it is data
-            raise RuntimeError("ProgramDAnA: device_rng forwards replay through graphs.GraphedDAnA")
         self.model = model
         self.inputs = [_static_like(t) for t in example_inputs]
         with torch.no_grad():
             for _ in range(warmup):  # eager: fills the plan / constant caches, creates the role streams
                 model(*self.inputs)
         torch.cuda.synchronize(dev)
+        self._device_rng = bool(getattr(model, "device_rng", False)) and model.training
+        if self._device_rng:
+            # the Philox call counter must be DATA in a replay (a launch argument would redraw the recording's numbers):
+            # the uint64 in device memory the hipGraph path uses, continuing the eager call sequence
+            model._rng_counter(dev).fill_(2 * model._rng_calls)
+            model._rng_counter_as_data = True
+            torch.cuda.synchronize(dev)
         self.p1 = LaunchProgram(dev)
         self.p2 = self.req = self.drawn = None
         calls0 = model._rng_calls
         gen = model._forward_gen(*self.inputs)
         out = None
-        with self.p1.recording():
-            try:
-                req = next(gen)
-                if req["stage"] == "anchor":
+        try:
+            with self.p1.recording():
+                try:
                     req = next(gen)
-            except StopIteration as done:
-                req, out = None, done.value
+                    if req["stage"] == "anchor":
+                        req = next(gen)
+                except StopIteration as done:
+                    req, out = None, done.value
+        finally:
+            model._rng_counter_as_data = False
         if req is not None:
             assert req["stage"] == "draw"
             self.req = req
@@ -361,7 +402,9 @@ class ProgramDAnA:
                 except StopIteration as done:
                     out = done.value
         self.outputs = out
-        model._rng_calls = calls0
+        # host RNG: the recording drew nothing that counts. Device RNG: the recording WAS forward number calls0 (its
+        # kernels ran and advanced the device counter), every replay is one more
+        model._rng_calls = calls0 + (1 if self._device_rng else 0)
         torch.cuda.synchronize(dev)
 
     def __call__(self, *inputs):
@@ -372,6 +415,8 @@ class ProgramDAnA:
         if self.p2 is not None:
             ops.draw_and_upload(self.req, self.drawn.device, static=self.drawn)
             self.p2.run()
+        if self._device_rng:
+            self.model._rng_calls += 1  # (the replay advanced the device Philox counter by one forward)
         return self.outputs
 
 
@@ -390,8 +435,6 @@ class ProgramTrainer:
         self.trainer, self.model = trainer, trainer.model
         if not hasattr(self.model, "_forward_gen"):
             raise RuntimeError("ProgramTrainer drives DAnARCNN (the siblings train eagerly)")
-        if getattr(self.model, "device_rng", False):
-            raise RuntimeError("ProgramTrainer: host RNG only (device_rng iterations replay through graphs.GraphedTrainer)")
         dev = example_inputs[0].device
         self.inputs = [_static_like(t) for t in example_inputs]
         snap = None
@@ -429,39 +472,57 @@ class ProgramTrainer:
         model.save_for_backward = True
         self.p1 = self.p2 = self.outputs = None  # (a re-record: the old programs' pool dies here, outside any routing)
         self.p1 = LaunchProgram(dev)
-        self.p2 = LaunchProgram(dev, pool=self.p1.pool)
+        self.p2 = self.req = self.drawn = None
         for fb, _, _ in tr.groups:
             fb.zero_grad_bookkeeping()
+        self._device_rng = bool(getattr(model, "device_rng", False))
+        calls0 = model._rng_calls
+        if self._device_rng:  # the Philox call counter as data in device memory (see ProgramDAnA)
+            model._rng_counter(dev).fill_(2 * calls0)
+            model._rng_counter_as_data = True
+            torch.cuda.synchronize(dev)
+
+        def backward_and_sgd(prog):
+            # multi-rank: a bucket that becomes complete leaves on its all-reduce from a host callback (FlatBuckets._launch),
+            # re-issued at the same position of every replay
+            for fb, _, _ in tr.groups:
+                fb.recorder = prog
+            BW.model_backward(model, (1.0, 1.0, 1.0, 1.0))
+            prog.host_callback(self._wait_buckets)
+            for (fb, lr_mult, wd), buf in zip(tr.groups, tr.bufs):
+                # first_step=False: with a zero momentum buffer  buf = m * 0 + g  IS torch.optim.SGD's first step
+                ops.sgd_momentum_(fb.params, fb.grads, buf, tr.lr * lr_mult, tr.momentum, wd, grad_scale=1.0 / fb.world,
+                                  first_step=False)
+
         try:
             gen = model._forward_gen(*self.inputs)
-            with self.p1.recording():
+            out = None
+            with self.p1.recording() as p1:
                 for fb, _, _ in tr.groups:
                     fb.grads.zero_()
-                req = next(gen)
-                if req["stage"] == "anchor":
-                    req = next(gen)
-            assert req["stage"] == "draw"
-            self.req = req
-            self.drawn = torch.zeros((req["layout"]["words"],), dtype=torch.int32, device=dev)
-            ops.draw_and_upload(req, dev, static=self.drawn)
-            with self.p2.recording() as p2:
                 try:
-                    gen.send(self.drawn)
-                    raise RuntimeError("the forward paused more often than expected")
-                except StopIteration as done:
-                    out = done.value
-                # multi-rank: a bucket that becomes complete leaves on its all-reduce from a host callback (FlatBuckets._launch),
-                # re-issued at the same position of every replay
-                for fb, _, _ in tr.groups:
-                    fb.recorder = p2
-                BW.model_backward(model, (1.0, 1.0, 1.0, 1.0))
-                p2.host_callback(self._wait_buckets)
-                for (fb, lr_mult, wd), buf in zip(tr.groups, tr.bufs):
-                    # first_step=False: with a zero momentum buffer  buf = m * 0 + g  IS torch.optim.SGD's first step
-                    ops.sgd_momentum_(fb.params, fb.grads, buf, tr.lr * lr_mult, tr.momentum, wd, grad_scale=1.0 / fb.world,
-                                      first_step=False)
+                    req = next(gen)
+                    if req["stage"] == "anchor":
+                        req = next(gen)
+                except StopIteration as done:  # device RNG: no host round trip, the whole iteration is ONE program
+                    req, out = None, done.value
+                    backward_and_sgd(p1)
+            if req is not None:
+                assert req["stage"] == "draw"
+                self.req = req
+                self.drawn = torch.zeros((req["layout"]["words"],), dtype=torch.int32, device=dev)
+                ops.draw_and_upload(req, dev, static=self.drawn)
+                self.p2 = LaunchProgram(dev, pool=self.p1.pool)
+                with self.p2.recording() as p2:
+                    try:
+                        gen.send(self.drawn)
+                        raise RuntimeError("the forward paused more often than expected")
+                    except StopIteration as done:
+                        out = done.value
+                    backward_and_sgd(p2)
         finally:
             model.save_for_backward = prev_save
+            model._rng_counter_as_data = False
             for fb, _, _ in tr.groups:
                 fb.recorder = None
         self.outputs = tuple(t.detach() if torch.is_tensor(t) else t for t in out)
@@ -471,6 +532,9 @@ class ProgramTrainer:
         for b_, b0 in zip(tr.bufs, snap[1]):
             b_.copy_(b0)
         _np.random.set_state(snap[2])
+        model._rng_calls = calls0
+        if self._device_rng:
+            model._rng_counter(dev).fill_(2 * calls0)
         model._epoch += 1
         torch.cuda.synchronize(dev)
 
@@ -491,7 +555,10 @@ class ProgramTrainer:
         for fb, _, _ in self.trainer.groups:
             fb.zero_grad_bookkeeping()
         self.p1.run()
-        ops.draw_and_upload(self.req, self.drawn.device, static=self.drawn)
-        self.p2.run()
+        if self.p2 is not None:
+            ops.draw_and_upload(self.req, self.drawn.device, static=self.drawn)
+            self.p2.run()
+        if self._device_rng:
+            self.model._rng_calls += 1
         self._after_step()
         return self.outputs

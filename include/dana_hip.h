@@ -601,6 +601,10 @@ int dana_program_add_call(void* program, void* entry_point, const char* signatur
 int dana_program_add_event_record(void* program, void* event, dana_stream_t stream);
 int dana_program_add_event_wait(void* program, void* event, dana_stream_t stream);
 int dana_program_size(void* program);
+/* device memory zero fill / device-to-device copy on a stream (hipMemsetAsync / hipMemcpyAsync): what torch's zeros / zero_
+ * and copy_ / clone do inside a recorded backward, as entry points a launch program can re-issue from its C loop */
+int dana_fill_zero(void* dst, size_t bytes, dana_stream_t stream);
+int dana_copy_d2d(void* dst, const void* src, size_t bytes, dana_stream_t stream);
 int dana_program_run(void* program, int begin, int end);
 
 #ifdef __cplusplus
