@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     # and nothing torch-typed leaks into the boundary: only C scalars and raw pointers
     allowed = {"int", "long", "float", "double", "size_t", "dana_stream_t", "const float*", "float*", "const int*",
                "int*", "const unsigned char*", "unsigned long long", "void*", "const unsigned long long*",
-               "unsigned long long*", "long long*", "const long long*", "void**", "const char*"}
+               "unsigned long long*", "long long*", "const long long*", "void**", "const char*", "const void*"}
     for name, (ret, args) in protos.items():
         assert ret in ("int", "size_t", "const char*"), (name, ret)
         for ty, _ in args:
