@@ -183,6 +183,11 @@ class DAnARCNN(nn.Module):
         # forward-only runs: RoI-level positional encoding folded into one fused query projection (see _roi_query_fold)
         self.fold_roi_pe = True
         self.fold_roi_attn = True  # forward-only: A.(S.Wt^T) instead of (A.S).Wt^T
+        # saving forward: the backward's weight-only launches (data-gradient weights) issued under the proposal layer, on this
+        # role stream (None: at the backward's start). Same-process A/B of the replayed iteration (tools/ab_prefetch.py):
+        # layer4 15.34-15.51 ms, neg_head 15.42-15.59, none 15.59-15.73, wgrad 16.10-16.26, targets 16.16-16.38 -- which
+        # hardware queue the launches land on decides (profiles/r5_role_streams.md)
+        self.prefetch_dgrad = "layer4"
         self.nms_inclusive = False  # False: IoU > thr as the reference CUDA op (nms.cu:60); True: CPU op (>=)
         dim_in = self.pool_feat_dim
 
@@ -1014,6 +1019,11 @@ class DAnARCNN(nn.Module):
             support_roi_done = ops.record_event()
             if ctx is not None:
                 ctx.update(sp_pe=sp_pe, k2=k2, un2=un2, sup_map=(sh_, sw_), sup_pool=pool)
+        if ctx is not None:
+            # the backward's weight-only launches, on the (idle) weight-gradient stream: they run under the proposal layer and
+            # the host round trip, where the chip has nothing else to do (backward.prefetch_dgrad_weights)
+            from . import backward as BW
+            BW.prefetch_dgrad_weights(self, ctx, dev)
         A = plan["anchors"].size(0)
         key = "TRAIN" if training else "TEST"
         rois = ops.proposal_layer(heads, (hw * nh, 1, nh), False, heads.view(-1)[rpn.nc_score_out:], (hw * nh, 1, nh),

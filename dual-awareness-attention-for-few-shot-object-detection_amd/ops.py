@@ -1459,6 +1459,15 @@ def broadcast_rows(x, groups, positions, channels, alpha=1.0, out=None):
     return out
 
 
+def ba_backward_prep(s, weights, grad_s, groups, length, dim):
+    """-> (gvec [groups][dim] = weights^T s per group, gsum [groups][dim] = column sums of grad_s per group): one launch"""
+    gvec = torch.empty((groups, dim), dtype=torch.float32, device=s.device)
+    gsum = torch.empty((groups, dim), dtype=torch.float32, device=s.device)
+    lib().call("dana_ba_backward_prep", _p(_chk(s, "s")), _p(_chk(weights, "weights")), _p(_chk(grad_s, "grad_s")), _p(gvec),
+               _p(gsum), groups, length, dim, _stream())
+    return gvec, gsum
+
+
 def ba_backward_(grad_s, s, weights, gvec, gsum, groups, length, dim, gamma=0.1, slope=0.01):
     grad_w = torch.empty((groups * length,), dtype=torch.float32, device=s.device)
     lib().call("dana_ba_backward", _p(_chk(grad_s, "grad_s")), _p(_chk(s, "s")), _p(_chk(weights, "weights")),

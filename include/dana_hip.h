@@ -490,6 +490,9 @@ int dana_broadcast_rows(const float* in, float* out, long groups, int positions,
                         int accumulate, dana_stream_t stream);
 /* adjoint of dana_ba_apply (dana.py:133-137), in place on grad_s [groups*length][dim]: s = the block's INPUT,
  * gvec[groups][dim] = weights^T s, gsum[groups][dim] = column sums of grad_s per group; grad_weights[groups*length] out */
+/* ... its two per-group reductions in one launch: gvec[g][:] = weights[g]^T s[g], gsum[g][:] = column sums of grad_s[g] */
+int dana_ba_backward_prep(const float* s, const float* weights, const float* grad_s, float* gvec, float* gsum, long groups,
+                          int length, int dim, dana_stream_t stream);
 int dana_ba_backward(float* grad_s, const float* s, const float* weights, const float* gvec, const float* gsum,
                      float* grad_weights, long groups, int length, int dim, float gamma, float slope,
                      dana_stream_t stream);
