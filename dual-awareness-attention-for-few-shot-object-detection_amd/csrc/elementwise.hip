@@ -358,6 +358,20 @@ add_pe_kernel(const float4* __restrict__ in, const float4* __restrict__ pe, floa
   }
 }
 
+// out[g][r][c] = in[g * in_group + r * C + c] + pe[r % L][c]: the positive supports of every image in ONE launch (their maps
+// sit way * shot images apart in the support batch: dana.py:103,126-130)
+__global__ void __launch_bounds__(256)
+add_pe_groups_kernel(const float4* __restrict__ in, const float4* __restrict__ pe, float4* __restrict__ out, int L, int C4,
+                     long rows_per_group, long in_group4, long out_group4, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)blockDim.x * gridDim.x) {
+    const int c = (int)(i % C4);
+    const long rr = i / C4;
+    const long g = rr / rows_per_group, r = rr % rows_per_group;
+    const float4 a = in[g * in_group4 + r * C4 + c], b = pe[(r % L) * C4 + c];
+    out[g * out_group4 + r * C4 + c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
 // x[g][l][d] -= mean_l x[g][l][d] in two passes over row chunks (fixed summation order, no atomics):
 // (1) partial[g][chunk][d] = sum of the chunk's rows; (2) every chunk re-adds the partials in chunk
 // order, divides by L and subtracts. grid = (D/64 column slabs, chunks, G); block = 64 cols x 4 row lanes.
@@ -389,6 +403,33 @@ colmean_apply_kernel(float* __restrict__ x, const float* __restrict__ partial, i
   float* base = x + (long)blockIdx.z * L * ld;
   const int l0 = blockIdx.y * CM_ROWS, l1 = min(L, l0 + CM_ROWS);
   for (int l = l0 + rl; l < l1; l += 4) base[(long)l * ld + col] -= mean;
+}
+
+// the same in ONE launch for short groups (L <= 1 024 rows: the 400 positions of a support map, the 49 of a RoI): one block
+// per (64-column slab, group) walks the chunks itself -- the SAME chunked, ordered summation as the two-pass pair, hence the
+// same bits -- and then subtracts; saves a dependent launch where the chain is latency-bound.
+__global__ void __launch_bounds__(256)
+colmean_fused_kernel(float* __restrict__ x, int L, int D, long ld) {
+  __shared__ float part[4][64];
+  __shared__ float mean_s[64];
+  const int tc = threadIdx.x & 63, col = blockIdx.x * 64 + tc, rl = threadIdx.x >> 6;
+  float* base = x + (long)blockIdx.z * L * ld;
+  float total = 0.f;
+  for (int l0 = 0; l0 < L; l0 += CM_ROWS) {
+    const int l1 = min(L, l0 + CM_ROWS);
+    float s = 0.f;
+    if (col < D)
+      for (int l = l0 + rl; l < l1; l += 4) s += base[(long)l * ld + col];
+    part[rl][tc] = s;
+    __syncthreads();
+    if (rl == 0) total += (part[0][tc] + part[1][tc]) + (part[2][tc] + part[3][tc]);
+    __syncthreads();
+  }
+  if (rl == 0) mean_s[tc] = total / (float)L;
+  __syncthreads();
+  if (col >= D) return;
+  const float mean = mean_s[tc];
+  for (int l = rl; l < L; l += 4) base[(long)l * ld + col] -= mean;
 }
 
 // batched transpose in[g][R][C] -> out[g][C][ldo] (32x32 LDS tiles); zero_pad: the grid covers ldo (not R) output
@@ -745,6 +786,21 @@ int dana_add_pe(const float* in, const float* pe, float* out, long rows, int len
   return DANA_OK;
 }
 
+int dana_add_pe_groups(const float* in, const float* pe, float* out, long groups, long rows_per_group, int length, int channels,
+                       long in_group_stride, long out_group_stride, dana_stream_t stream) {
+  DANA_CHECK_ARG(groups >= 0 && rows_per_group > 0 && length > 0 && channels > 0 && channels % 4 == 0 &&
+                     in_group_stride % 4 == 0 && out_group_stride % 4 == 0,
+                 "dana_add_pe_groups: bad shape");
+  if (groups == 0) return DANA_OK;
+  DANA_CHECK_ARG(in && pe && out, "dana_add_pe_groups: null pointer");
+  const long total = groups * rows_per_group * (channels / 4);
+  add_pe_groups_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      (const float4*)in, (const float4*)pe, (float4*)out, length, channels / 4, rows_per_group, in_group_stride / 4,
+      out_group_stride / 4, total);
+  DANA_CHECK_LAUNCH("dana_add_pe_groups");
+  return DANA_OK;
+}
+
 size_t dana_colmean_sub_workspace_bytes(int groups, int length, int dim) {
   if (groups <= 0 || length <= 0 || dim <= 0) return 0;
   return (size_t)groups * ((length + CM_ROWS - 1) / CM_ROWS) * dim * sizeof(float);
@@ -760,6 +816,12 @@ int dana_colmean_sub(float* x, int groups, int length, int dim, long ld, void* w
   if (!workspace || workspace_bytes < need) {
     dana_set_error("dana_colmean_sub: workspace %zu < %zu", workspace_bytes, need);
     return DANA_ERR_WORKSPACE;
+  }
+  if (length <= 1024 && groups <= 65535) {  // short groups: one launch, same summation order (colmean_fused_kernel)
+    dim3 grid1(dana_ceil_div(dim, 64), 1, groups);
+    colmean_fused_kernel<<<grid1, 256, 0, (hipStream_t)stream>>>(x, length, dim, ld);
+    DANA_CHECK_LAUNCH("dana_colmean_sub(fused)");
+    return DANA_OK;
   }
   dim3 grid(dana_ceil_div(dim, 64), dana_ceil_div(length, CM_ROWS), groups);
   DANA_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "dana_colmean_sub: too many chunks/groups");

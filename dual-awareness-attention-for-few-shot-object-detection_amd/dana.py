@@ -188,6 +188,8 @@ class DAnARCNN(nn.Module):
         # layer4 15.34-15.51 ms, neg_head 15.42-15.59, none 15.59-15.73, wgrad 16.10-16.26, targets 16.16-16.38 -- which
         # hardware queue the launches land on decides (profiles/r5_role_streams.md)
         self.prefetch_dgrad = "layer4"
+        # role stream for the RPN-level unary term + S^T beside the K projection (None: one chain on the support stream)
+        self.rpn_side_role = "wgrad"
         self.nms_inclusive = False  # False: IoU > thr as the reference CUDA op (nms.cu:60); True: CPU op (>=)
         dim_in = self.pool_feat_dim
 
@@ -912,9 +914,8 @@ class DAnARCNN(nn.Module):
             sup.record_stream(sup_stream)
             # RPN-level support side (dana.py:126-145): PE, BA block, K projection, unary term, S^T
             s_pe = torch.empty((B, shot * L, 1024), dtype=torch.float32, device=dev)
-            sup3 = sup.view(Ns, L * 1024)
-            for b in range(B):  # positives = the first `shot` supports of each image (dana.py:103)
-                ops.add_pe(sup3[b * way * shot], self._pe_table(L, dev), shot * L, L, 1024, out=s_pe[b])
+            # positives = the first `shot` supports of each image (dana.py:103), way * shot maps apart: one launch
+            ops.add_pe_groups(sup, self._pe_table(L, dev), B, shot * L, L, 1024, way * shot * L * 1024, s_pe)
             if self.semantic_enhance:  # BA block (dana.py:133-137)
                 wc, bc = self._w(self.rpn_channel_k_layer)
                 wgt = ops.rowdot(s_pe, wc, bc, B * shot * L, 1024)
@@ -922,14 +923,34 @@ class DAnARCNN(nn.Module):
                 if ctx is not None:
                     ctx.update(s_pre=s_pe.clone(), ba_w=wgt)
                 ops.ba_apply_(s_pe, wgt, B * shot, L, 1024, gamma=self.channel_gamma, slope=0.01)
+            # three independent consumers of the (BA-enhanced) support rows: K projection, unary term, S^T. The chain behind
+            # the support trunk is latency-bound (small dependent launches, 0.24 ms of which the caller's stream WAITS 0.125:
+            # tools/phase_times.py), so the unary term and the transpose run beside the K projection on an idle role stream
+            br_role = getattr(self, "rpn_side_role", "wgrad")
+            br = self._stream(br_role, dev) if (br_role and not getattr(self, "_single_stream", False)
+                                                and not torch.cuda.is_current_stream_capturing()) else None
+
+            def unary_and_transpose():
+                wu, bu = self._w(self.rpn_unary_layer)
+                u_ = ops.rowdot(s_pe, wu, bu, B * shot * L, 1024)
+                ops.softmax_rows_(u_, B * shot, L)
+                return u_, ops.transpose_batched(s_pe, B, K1, 1024)  # [B][1024][K1]
+
+            if br is not None:
+                s_pe_ready = ops.record_event()
+                br.wait_event(s_pe_ready)
+                s_pe.record_stream(br)
+                with ops.on_stream(br):
+                    unary, s_t = unary_and_transpose()
+                    branch_done = ops.record_event()
             wk, bk = self._w(self.rpn_adapt_k_layer)
             kb3, kld = self._lin_b(self.rpn_adapt_k_layer)
             kp = ops.gemm_nt(s_pe, kb3, B * shot * L, d, 1024, ldb=kld, shift=bk)
             ops.colmean_sub_(kp, B * shot, L, d)
-            wu, bu = self._w(self.rpn_unary_layer)
-            unary = ops.rowdot(s_pe, wu, bu, B * shot * L, 1024)
-            ops.softmax_rows_(unary, B * shot, L)
-            s_t = ops.transpose_batched(s_pe, B, K1, 1024)  # [B][1024][K1]
+            if br is not None:
+                sup_stream.wait_event(branch_done)
+            else:
+                unary, s_t = unary_and_transpose()
             for t_ in (kp, unary, s_t):
                 t_.record_stream(main)
             support_done = ops.record_event()
@@ -941,7 +962,9 @@ class DAnARCNN(nn.Module):
         qb3, qld = self._lin_b(self.rpn_adapt_q_layer)
         qp = ops.gemm_nt(corr, qb3, B * hw, d, 1024, lda=2048, ldb=qld, shift=bq)
         ops.colmean_sub_(qp, B, hw, d)
+        mark("rpn-level Q projection")
         main.wait_event(support_done)
+        mark("... wait for the support side (trunk + RPN-level K / unary / S^T chain)")
         scores = torch.empty((B, hw, K1), dtype=torch.float32, device=dev)
         ops.gemm_nt(qp, kp, hw, K1, d, out=scores, ldc=K1, batch=B, batch_a=hw * d, batch_b=K1 * d, batch_c=hw * K1,
                     alpha=1.0 / math.sqrt(d))

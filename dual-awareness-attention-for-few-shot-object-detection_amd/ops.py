@@ -1142,6 +1142,13 @@ def add_pe(x, pe, rows, length, channels, in_stride=0, out=None, out_stride=0):
     return out
 
 
+def add_pe_groups(x, pe, groups, rows_per_group, length, channels, in_group_stride, out):
+    """out[g][r] = x[g * in_group_stride + r * channels ...] + pe[r % length] for every group in one launch"""
+    lib().call("dana_add_pe_groups", _p(_chk(x, "x")), _p(_chk(pe, "pe")), _p(_chk(out, "out")), groups, rows_per_group, length,
+               channels, in_group_stride, rows_per_group * channels, _stream())
+    return out
+
+
 def colmean_sub_(x, groups, length, dim, ld=0):
     _chk(x, "x")
     ws = _ws(lib().query("dana_colmean_sub_workspace_bytes", groups, length, dim), x.device)

@@ -309,6 +309,10 @@ int dana_scale_rows_by_group(const float* x, const float* group_vec, float* out,
 /* PositionalEncoding.forward: dana.py:322-324; out[r] = in[r] + pe[r % length] */
 int dana_add_pe(const float* in, const float* pe, float* out, long rows, int length, int channels,
                 long in_stride, long out_stride, dana_stream_t stream);
+/* ... for `groups` row groups whose inputs sit in_group_stride floats apart (the positive supports of every image of the
+ * batch, way * shot maps apart: dana.py:103,126-130) in one launch; out[g][r] = in[g][r] + pe[r % length] */
+int dana_add_pe_groups(const float* in, const float* pe, float* out, long groups, long rows_per_group, int length, int channels,
+                       long in_group_stride, long out_group_stride, dana_stream_t stream);
 /* x - x.mean(1, keepdim=True): dana.py:125,141,267,272; x[groups][length][ld], in place */
 size_t dana_colmean_sub_workspace_bytes(int groups, int length, int dim);
 int dana_colmean_sub(float* x, int groups, int length, int dim, long ld, void* workspace, size_t workspace_bytes,
