@@ -355,6 +355,14 @@ def main():
                     for i in range(rois.size(0))]
         return step_
 
+    def all_agree(flag):
+        """1.0 on every rank -> True (a launch mode is used by all ranks or by none)"""
+        if world > 1:
+            t_ = torch.tensor([flag], device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+            flag = float(t_.item())
+        return flag > 0.5
+
     if use_graphs:
         # hipGraph replay (graphs.py): the forward = two captured graphs around the one host round trip (the reference's
         # np.random draws need the fg / bg counts), the training iteration likewise (+ backward + SGD; multi-rank: cut
@@ -372,13 +380,22 @@ def main():
         # re-issued from one Python loop -- two programs around the host round trip; multi-rank: the bucket all-reduces
         # are host callbacks inside the second one
         from dana_amd.program import ProgramDAnA, ProgramTrainer
-        if args.mode == "step":
-            train_step()
-            ptr = graphed["program_trainer"] = ProgramTrainer(trainer[0], *inputs)
-            cands["program"] = lambda: ptr.step(*ptr.inputs)  # noqa: E731
-        else:
-            prun = graphed["program_forward"] = ProgramDAnA(model, *inputs)
-            cands["program"] = with_postprocess(prun) if args.mode == "infer" else (lambda: prun(*prun.inputs))
+        ok_, why_ = 1.0, None
+        try:
+            if args.mode == "step":
+                train_step()
+                ptr = graphed["program_trainer"] = ProgramTrainer(trainer[0], *inputs)
+                cands["program"] = lambda: ptr.step(*ptr.inputs)  # noqa: E731
+            else:
+                prun = graphed["program_forward"] = ProgramDAnA(model, *inputs)
+                cands["program"] = with_postprocess(prun) if args.mode == "infer" else (lambda: prun(*prun.inputs))
+        except Exception as e_:  # noqa: BLE001  (a replay mode that cannot be recorded here must not cost the line)
+            ok_, why_ = 0.0, "%s: %s" % (type(e_).__name__, str(e_)[:160])
+        ok_ = all_agree(ok_)
+        if not ok_:
+            cands.pop("program", None)
+            use_programs = False
+            graphed["program_error"] = why_ or "another rank could not record its programs"
     graph_step = cands.get("graph")
 
     def median_interval(evs):
@@ -492,6 +509,7 @@ def main():
         if timed_graphs else ("launch-program replay: the eager step's launches on its own streams, re-issued from one loop "
                               "(program.py)" if chosen == "program" else "eager (one C-ABI call per kernel from Python)"),
         "launch_trial": launch_trial,
+        "launch_program_error": graphed.get("program_error"),
         "host_enqueue_ms_per_step": host_ms,
         "higher_is_better": True,
         "scaling": "weak",
@@ -532,8 +550,15 @@ def main():
             ts_cands["graph"] = lambda: gtr.step(*gtr.inputs)  # noqa: E731
         if use_programs:
             from dana_amd.program import ProgramTrainer
-            ptr = graphed["program_trainer"] = ProgramTrainer(trainer[0], *inputs)
-            ts_cands["program"] = lambda: ptr.step(*ptr.inputs)  # noqa: E731
+            ok_ = 1.0
+            try:
+                ptr = graphed["program_trainer"] = ProgramTrainer(trainer[0], *inputs)
+                ts_cands["program"] = lambda: ptr.step(*ptr.inputs)  # noqa: E731
+            except Exception as e_:  # noqa: BLE001
+                ok_ = 0.0
+                graphed["program_error"] = "%s: %s" % (type(e_).__name__, str(e_)[:160])
+            if not all_agree(ok_):
+                ts_cands.pop("program", None)
         ts_chosen, ts_trial = pick_launch(ts_cands, 12, None if args.launch == "auto" else args.launch)
         train_step = ts_cands[ts_chosen]
         for _ in range(3):
