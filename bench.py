@@ -249,6 +249,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    _t_start = time.perf_counter()
+
+    def phase(name):
+        if os.environ.get("DANA_BENCH_TIMING") and rank == 0:
+            print("[bench %7.1f s] %s" % (time.perf_counter() - _t_start, name), file=sys.stderr, flush=True)
+
     def dist_barrier():
         if backend == "nccl":
             dist.barrier(device_ids=[local])
@@ -432,7 +438,7 @@ def main():
         if len(names) == 1:
             return names[0], None
         best = {n: 1e30 for n in names}
-        for _ in range(2):
+        for _ in range(2 if world == 1 else 1):  # (N ranks: every trial step is a collective step; one round)
             for n in names:
                 best[n] = min(best[n], trial(c[n], k))
         t = torch.tensor([best[n] for n in names], device=dev, dtype=torch.float64)
@@ -443,6 +449,7 @@ def main():
         tr_["steps_each"] = k
         return names[vals.index(min(vals))], tr_
 
+    phase("launch modes built (graph capture / program recording)")
     chosen, launch_trial = pick_launch(cands, max(5, min(20, args.steps)), None if args.launch == "auto" else args.launch)
     step = cands[chosen]
     timed_graphs = chosen == "graph"
@@ -467,6 +474,7 @@ def main():
             dist_barrier()
         torch.cuda.synchronize()
 
+    phase("launch trial done: %s" % chosen)
     barrier()
     marks_f = [torch.cuda.Event(enable_timing=True)]
     marks_f[0].record()
@@ -536,6 +544,7 @@ def main():
                                    if ops.get_mfma_mode() else "v_mfma_f32_32x32x2_f32"},
     }
 
+    phase("timed region + host enqueue times done")
     if args.mode == "train" and not args.no_train_step:
         # secondary measurement, every rank: variant S, the full training iteration with the
         # gradient all-reduce over RCCL as its one exchange step. Same episodes, same timing protocol.
@@ -559,7 +568,7 @@ def main():
                 graphed["program_error"] = "%s: %s" % (type(e_).__name__, str(e_)[:160])
             if not all_agree(ok_):
                 ts_cands.pop("program", None)
-        ts_chosen, ts_trial = pick_launch(ts_cands, 12, None if args.launch == "auto" else args.launch)
+        ts_chosen, ts_trial = pick_launch(ts_cands, max(3, min(12, args.steps)), None if args.launch == "auto" else args.launch)
         train_step = ts_cands[ts_chosen]
         for _ in range(3):
             train_step()
@@ -673,6 +682,7 @@ def main():
         torch.cuda.synchronize()
         model._single_stream = bool(args.single_stream)
         tprof, ops.PROFILE = ops.PROFILE, None
+    phase("train_step (incl. exchange) done")
     if rank == 0 and not args.no_roofline and args.mode != "step":
         # dominant kernel family: the implicit-GEMM contraction (every conv / Linear / bmm). Same K steps, each launch
         # bracketed by HIP events recorded on the stream the kernel is launched on (torch's current stream).
@@ -912,6 +922,7 @@ def main():
                              "frac": round(f0 / t0s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                              "kernel_ms_per_step": round(t0s * 1e3 / k0, 3)},
             }
+    phase("roofline passes done")
     if (rank == 0 and world == 1 and args.mode == "train" and not args.no_secondary and args.model == "DAnA"
             and not args.device_rng and not args.single_stream):
         # secondary object: the same forward with the training targets sampled by the device Philox RNG -- no host round
