@@ -552,6 +552,8 @@ def main():
         for _ in range(kw):
             train_step()
         eager_train_step = train_step
+        # (gloo moves the 148 MB through the host, ~0.4 s per iteration: the test-only backend gets shorter side measurements)
+        slow_exchange = world > 1 and backend != "nccl"
         ts_cands = {"eager": eager_train_step}
         if use_graphs:
             from dana_amd.graphs import GraphedTrainer
@@ -597,7 +599,8 @@ def main():
             "buckets": sum(len(fb.buckets) for fb, _, _ in tr.groups),
             "launch": {"graph": "hipGraph replay", "program": "launch-program replay", "eager": "eager"}[ts_chosen],
             "launch_trial": ts_trial,
-            "host_enqueue_ms_per_step": {n: host_enqueue_ms(f, 5 if n == "eager" else 10) for n, f in ts_cands.items()},
+            "host_enqueue_ms_per_step": {n: host_enqueue_ms(f, 3 if slow_exchange else (5 if n == "eager" else 10))
+                                         for n, f in ts_cands.items()},
         }
 
         # The exchange, isolated (north_star's "RCCL all-reduce on the loss gradients only"; train.py:104-105,138-139): (a) the
@@ -626,7 +629,7 @@ def main():
             torch.cuda.synchronize()
             flush_c_stdout()
             alone = []
-            for _ in range(7):
+            for _ in range(3 if slow_exchange else 7):
                 barrier()
                 for fb in fbs:
                     fb.zero_grad_bookkeeping()
@@ -642,13 +645,13 @@ def main():
                 torch.cuda.synchronize()
                 alone.append(ev0.elapsed_time(ev1))
             t_on, t_off = [], []
-            for _ in range(2):
+            for _ in range(1 if slow_exchange else 2):
                 set_coll(True)
                 barrier()
-                t_on.append(trial(eager_train_step, 6))
+                t_on.append(trial(eager_train_step, 3 if slow_exchange else 6))
                 set_coll(False)
                 barrier()
-                t_off.append(trial(eager_train_step, 6))
+                t_off.append(trial(eager_train_step, 3 if slow_exchange else 6))
             for fb, c in zip(fbs, coll_prev):
                 fb.collective = c
             ex = torch.tensor([sorted(alone)[len(alone) // 2], min(t_on), min(t_off)], device=dev, dtype=torch.float64)
