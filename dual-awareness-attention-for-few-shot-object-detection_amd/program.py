@@ -72,8 +72,12 @@ class _AtenRecorder(TorchDispatchMode):
         on_gpu = any(t.is_cuda for t in tens) or (torch.is_tensor(out) and out.is_cuda)
         if not on_gpu:
             return out
-        if name == "contiguous" or (torch.is_tensor(out) and any(out is t for t in tens) and not name.endswith("_")):
+        if torch.is_tensor(out) and any(out is t for t in tens) and not name.endswith("_"):
             return out  # returned its input unchanged
+        if torch.is_tensor(out) and not out.is_cuda:
+            # a device-to-host read: whatever the host does with it would be baked into the program as of the recording
+            raise RuntimeError("LaunchProgram: torch op %s reads device data to the host inside a recorded step: it has no "
+                               "replay rule (host logic belongs between two programs, or in a host_callback)" % func.__name__)
         st = ops._get_cur(ops._raw_device())
         if prog._as_call(name, args, kwargs, out, tens):
             prog.keep.append(out)

@@ -100,6 +100,10 @@ def test_program_refuses_what_it_cannot_replay(dev):
     with pytest.raises(RuntimeError, match="no replay rule"):
         with p.recording():
             float(x.sum())  # a host read of device data inside a program: the cut between two programs is the place for it
+    p = program.LaunchProgram(dev)
+    with pytest.raises(RuntimeError, match="no replay rule"):
+        with p.recording():
+            x.cpu()  # ... also as a plain device-to-host copy
     # ... and the in-place / factory forms it knows replay into the SAME memory
     p = program.LaunchProgram(dev)
     with p.recording():
