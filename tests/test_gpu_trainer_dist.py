@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, same_inputs, q, name="DAnA"):
+def _worker(rank, world, port, same_inputs, q, name="DAnA", replay=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
@@ -42,9 +42,17 @@ def _worker(rank, world, port, same_inputs, q, name="DAnA"):
         inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=seed)]
         if name == "frcnn":
             inputs = inputs[:4]  # faster_rcnn.py:35: no supports
+        step = tr.step
+        if replay:
+            # the same two iterations replayed from launch programs (program.ProgramTrainer): every bucket's all-reduce is a
+            # host callback inside the second program -- a REAL exchange between the two processes at every replay
+            from dana_amd.program import ProgramTrainer
+            pt = ProgramTrainer(tr, *inputs, warmup=0)
+            assert pt.p2.stats["host_callbacks"] == 1 + sum(len(fb.buckets) for fb, _, _ in tr.groups)
+            step = pt.step
         for it in range(2):
             np.random.seed(40 + it)
-            tr.step(*inputs)
+            step(*inputs)
         torch.cuda.synchronize()
         vec = torch.cat([p.detach().reshape(-1)[::97] for p in m.parameters() if p.requires_grad]).cpu()
         nb = sum(len(fb.buckets) for fb, _, _ in tr.groups)
@@ -57,12 +65,12 @@ def _worker(rank, world, port, same_inputs, q, name="DAnA"):
             dist.destroy_process_group()
 
 
-def _run(world, same_inputs, name="DAnA"):
+def _run(world, same_inputs, name="DAnA", replay=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, same_inputs, q, name)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, same_inputs, q, name, replay)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
@@ -85,6 +93,19 @@ def test_two_rank_training_iteration_over_gloo_on_one_gpu(dev):
     diff = _run(2, False)
     assert np.array_equal(diff[0][2], diff[1][2])  # different shards: replicas stay bit-identical
     assert np.abs(diff[0][2] - single[2]).max() > 0  # and the other shard's gradient did arrive
+
+
+def test_two_rank_training_iteration_replayed_from_launch_programs(dev):
+    """world size 2 over gloo on one GPU, the iteration replayed from launch programs: the bucket all-reduces are re-issued
+    by the programs' host callbacks, the replicas stay bit-identical and equal the eager single-rank trajectory"""
+    single = _run(1, True)[0]
+    same = _run(2, True, replay=True)
+    assert np.array_equal(same[0][2], same[1][2])
+    for r in same:
+        d = np.abs(r[2] - single[2]).max()
+        assert d <= 1e-6 + 1e-4 * np.abs(single[2]).max(), d
+    diff = _run(2, False, replay=True)
+    assert np.array_equal(diff[0][2], diff[1][2]) and np.abs(diff[0][2] - single[2]).max() > 0
 
 
 def test_two_rank_training_iteration_of_the_frcnn_sibling(dev):
@@ -123,9 +144,17 @@ def _rccl_worker(rank, world, port, q, always_reduce):
         m.to(dev).train()
         tr = Trainer(m, 0.01, bucket_bytes=8 << 20, always_reduce=always_reduce)
         inputs = [t.to(dev) for t in S.episode_inputs(1, 2, 2, 160, 224, seed=6 + rank)]
+        step = tr.step
+        if replay:
+            # the same two iterations replayed from launch programs (program.ProgramTrainer): every bucket's all-reduce is a
+            # host callback inside the second program -- a REAL exchange between the two processes at every replay
+            from dana_amd.program import ProgramTrainer
+            pt = ProgramTrainer(tr, *inputs, warmup=0)
+            assert pt.p2.stats["host_callbacks"] == 1 + sum(len(fb.buckets) for fb, _, _ in tr.groups)
+            step = pt.step
         for it in range(2):
             np.random.seed(40 + it)
-            tr.step(*inputs)
+            step(*inputs)
         torch.cuda.synchronize()
         vec = torch.cat([p.detach().reshape(-1)[::97] for p in m.parameters() if p.requires_grad]).cpu()
         seen = dist.get_world_size() if inited else 0
