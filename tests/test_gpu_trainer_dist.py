@@ -122,7 +122,7 @@ def test_two_rank_training_iteration_of_the_frcnn_sibling(dev):
 
 
 # ---- RCCL (backend "nccl" on ROCm): the path the 8-GPU runs take -------------------------------------------------
-def _rccl_worker(rank, world, port, q, always_reduce):
+def _rccl_worker(rank, world, port, q, always_reduce, replay=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
@@ -168,12 +168,12 @@ def _rccl_worker(rank, world, port, q, always_reduce):
             dist.destroy_process_group()
 
 
-def _run_rccl(world, always_reduce):
+def _run_rccl(world, always_reduce, replay=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q, always_reduce)) for r in range(world)]
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q, always_reduce, replay)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r[0])
@@ -195,6 +195,10 @@ def test_training_iteration_over_rccl_single_rank_group(dev):
     assert rccl[3] >= 3  # several buckets left through RCCL
     d = np.abs(rccl[2] - plain[2]).max()
     assert d <= 1e-6 + 1e-4 * np.abs(plain[2]).max(), d
+    # ... and with the iteration replayed from launch programs: the RCCL all-reduces are re-issued by the host callbacks
+    prog = _run_rccl(1, True, replay=True)[0]
+    d = np.abs(prog[2] - plain[2]).max()
+    assert d <= 1e-6 + 1e-4 * np.abs(plain[2]).max(), d
 
 
 def test_two_rank_training_iteration_over_rccl():
@@ -208,3 +212,7 @@ def test_two_rank_training_iteration_over_rccl():
     assert two[0][4] == 2 and two[0][5] == "nccl"
     assert np.array_equal(two[0][2], two[1][2])
     assert np.abs(two[0][2] - single[2]).max() > 0
+    rep = _run_rccl(2, False, replay=True)  # the same two iterations replayed from launch programs
+    assert np.array_equal(rep[0][2], rep[1][2])
+    d = np.abs(rep[0][2] - two[0][2]).max()
+    assert d <= 1e-6 + 1e-4 * np.abs(two[0][2]).max(), d
