@@ -41,7 +41,7 @@ rm -rf /tmp/pmc_mfma
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_mfma -o pmc -- python $R/bench.py $CFG --launch eager --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-train-step --no-secondary --no-pmc --single-stream > $O/pmc_mfma.log 2>&1
 cp $(find /tmp/pmc_mfma -name "*counter_collection.csv" | head -1) $O/pmc_mfma_counter_collection.csv
 python $R/tools/secondary.py $O/single_stream_kernel_stats.csv $O/pmc_traffic.json $O/pmc_mfma_counter_collection.csv $O/secondary_rooflines.md "$WHAT" $B $H $W $SHOT $ROIS | tail -12
-cd $R && python bench.py $CFG --dump-launches $O/launches.txt > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
+cd $R && python bench.py $CFG --dump-launches $O/launches.txt 2> $O/bench.err | grep '^{' > $O/bench.json; cut -c1-300 $O/bench.json  # (RCCL prints a banner on stdout)
 if [ "$2" != cfg4 ]; then
   python tools/phase_times.py 30 > $O/phase_times.txt 2>&1
   python tools/roundtrip_gap.py 2>&1 | grep -v amdgpu.ids > $O/roundtrip_gap.txt
