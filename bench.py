@@ -234,6 +234,11 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE line, the JSON: everything else this process (or a C library inside it: RCCL's version banner)
+    # writes to descriptor 1 goes to stderr from here on, the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch.distributed as dist
     # test hook (1-GPU boxes): DANA_BENCH_BACKEND=gloo runs every rank on cuda:0 and exchanges over gloo, to exercise
     # the multi-rank control flow where RCCL (one rank per device) cannot; the driver's runs use nccl = RCCL
@@ -1129,7 +1134,7 @@ def main():
             result["cpu_baseline"] = cb
         result["summary"] = summary
         flush_c_stdout()
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if world > 1:
         dist_barrier()  # the other ranks wait for rank 0's roofline pass before tearing down
     if dist.is_initialized():
